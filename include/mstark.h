@@ -1,0 +1,122 @@
+/* mstark.h — C ABI of the MI355X (gfx950) prover for multi-stark's GoldilocksBlake3Config hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an int32 status (0 = ok, <0 = error,
+ * text via ms_last_error()) and never unwinds across the boundary: the reference's panics/asserts
+ * (src/prover.rs:323-326,522-525,637-641; src/system.rs:149,171-178,249-264) become error codes.
+ *
+ * Data conventions: Goldilocks elements are canonical u64 (little-endian on the wire); an Ext2
+ * value is two consecutive u64 (c0, c1) — the layout `flatten_to_base` produces (src/prover.rs:417,495);
+ * matrices cross the ABI row-major (what `RowMajorMatrix.values` holds); digests are 32 raw bytes.
+ * The caller owns every host buffer for the duration of a call; the library owns device memory behind the
+ * opaque handles below. A ms_ctx is bound to one HIP device and is not thread-safe.
+ *
+ * What each group replaces in /root/reference:
+ *   ms_system_*    System::new + ProverKey                      src/system.rs:115-203 (preprocessed commit :190-195)
+ *   ms_witness_*   SystemWitness / from_stage_1                 src/system.rs:225-328
+ *   ms_prove       System::prove_multiple_claims                src/prover.rs:290-603
+ *   ms_dft_batch   Radix2DitParallel::dft_batch                 src/prover.rs:650,716 (type fixed at :440)
+ *   ms_coset_lde_batch  the LDE inside Pcs::commit              src/prover.rs:350,419; layout pinned by :975-999
+ *   ms_quotient_lde     shifted_quotient_slices + lde_from_shifted_coefficients   src/prover.rs:631-717
+ *   ms_mmcs_*      MerkleTreeMmcs commit / open_batch           src/types.rs:82-83,202-207; Pcs::commit_ldes src/prover.rs:526
+ *   ms_stage2_trace     LookupValues::stage_2_traces            src/lookup.rs:472-555
+ *   ms_claims_accumulator   the claims loop                     src/prover.rs:382-387
+ *   ms_quotient_values      quotient_values(+_inner)            src/prover.rs:756-962 (sweep: src/eval.rs:67-106;
+ *                                                               logUp: src/lookup.rs:152-256)
+ *   ms_blake3      Blake3 as used by the challenger             src/types.rs:28-29 (HashChallenger<u8,Blake3,32>)
+ */
+#ifndef MSTARK_H
+#define MSTARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ms_ctx ms_ctx;         /* one HIP device + stream + twiddle tables + memory pool */
+typedef struct ms_system ms_system;   /* System<GoldilocksBlake3Config> + ProverKey (device-resident preprocessed LDE/tree) */
+typedef struct ms_witness ms_witness; /* SystemWitness + claims, resident in HBM */
+typedef struct ms_mmcs ms_mmcs;       /* ProverData of one commitment */
+
+enum {
+  MS_OK = 0,
+  MS_ERR = -1,            /* generic failure, see ms_last_error() */
+  MS_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure at context creation */
+  MS_ERR_BUFFER = -3      /* caller-provided capacity too small; the needed size is reported */
+};
+
+const char* ms_last_error(void);
+
+/* ---- context */
+int32_t ms_ctx_create(int32_t device, ms_ctx** out);
+void ms_ctx_destroy(ms_ctx* ctx);
+int32_t ms_ctx_sync(ms_ctx* ctx);
+/* release pooled device memory back to the driver */
+int32_t ms_ctx_trim(ms_ctx* ctx);
+/* Per-kernel-class timing with HIP events on the library's stream. mask bit i enables class i. */
+int32_t ms_ctx_set_profile_mask(ms_ctx* ctx, uint32_t mask);
+int32_t ms_ctx_kernel_stats(ms_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* ms, double* alg_bytes);
+int32_t ms_ctx_reset_stats(ms_ctx* ctx);
+int32_t ms_kernel_count(void);
+const char* ms_kernel_name(int32_t kernel_id);
+
+/* ---- System::new (src/system.rs:115-203). `blob` is the front-end's system blob: params, then per circuit the
+ * compiled node program (graph::ConstraintGraph fields, src/graph.rs:62-76), lookups and preprocessed trace. */
+int32_t ms_system_create(ms_ctx* ctx, const uint8_t* blob, size_t len, ms_system** out);
+void ms_system_destroy(ms_system* sys);
+/* preprocessed commitment (System.preprocessed_commit): writes n_digests * 32 bytes; n_digests = 0 if none */
+int32_t ms_system_preprocessed_commit(const ms_system* sys, uint8_t* out, size_t cap, size_t* n_digests);
+/* [main_width, pre_width, pre_height, num_lookups, stage2_width, constraint_count, max_constraint_degree,
+ *  quotient_degree, args_width] */
+int32_t ms_system_circuit_info(const ms_system* sys, size_t circuit, uint64_t out9[9]);
+
+/* ---- SystemWitness (src/system.rs:225-233) + claims. traces[i]: heights[i] x main_width_i row-major (height 0 =
+ * inactive circuit). mult[i] / args[i]: the flat LookupValues storage (src/lookup.rs:392-405); pass mult = NULL
+ * to have the library run SystemWitness::from_stage_1 (src/system.rs:244-328) on the host. Claims are given as
+ * offsets (n_claims + 1) into claim_data. Everything is uploaded once; ms_prove does not consume it. */
+int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights,
+                          const uint64_t* const* mult, const uint64_t* const* args, size_t n_claims,
+                          const uint64_t* claim_offsets, const uint64_t* claim_data, ms_witness** out);
+void ms_witness_destroy(ms_witness* w);
+
+/* ---- System::prove_multiple_claims (src/prover.rs:290-603). Writes Proof::to_bytes (src/prover.rs:241-248).
+ * stage_ms (optional, 6 doubles): stage1_commit, lookup_construction, stage2_commit, quotient, fri_open, total —
+ * the reference's span names (src/prover.rs:336-538). Returns MS_ERR_BUFFER with *proof_len = needed size if
+ * cap is too small. */
+int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms);
+
+/* ---- PCS-level entry points (host buffers in, host buffers out) */
+/* out[k] = sum_j in[j] w_h^{jk} per column (inverse != 0: the inverse transform incl. 1/h); natural order both sides */
+int32_t ms_dft_batch(ms_ctx* ctx, const uint64_t* in, size_t h, size_t w, int32_t inverse, uint64_t* out);
+/* coset_lde_batch(evals, log_blowup, GENERATOR).bit_reverse_rows(): (h << log_blowup) x w */
+int32_t ms_coset_lde_batch(ms_ctx* ctx, const uint64_t* in, size_t h, size_t w, uint32_t log_blowup, uint64_t* out);
+/* quotient evaluations in natural order on the quotient domain ((n q) x D) -> committed LDE ((n B) x (q D)) */
+int32_t ms_quotient_lde(ms_ctx* ctx, const uint64_t* in, uint32_t log_n, uint32_t log_q, uint32_t log_blowup, size_t D,
+                        uint64_t* out);
+/* Merkle commit over matrices of power-of-two heights (mixed heights allowed); cap_out: 32 << cap_height bytes */
+int32_t ms_mmcs_commit(ms_ctx* ctx, size_t n, const uint64_t* const* mats, const uint64_t* heights,
+                       const uint64_t* widths, uint32_t cap_height, uint8_t* cap_out, ms_mmcs** out);
+/* open_batch(index): opened rows concatenated in matrix order; siblings bottom-up; *n_siblings written */
+int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proof_out, size_t* n_siblings);
+void ms_mmcs_destroy(ms_mmcs* m);
+int32_t ms_blake3(ms_ctx* ctx, const uint8_t* bytes, size_t len, uint8_t out32[32]);
+
+/* ---- in-tree kernels of the reference */
+int32_t ms_stage2_trace(ms_ctx* ctx, size_t height, size_t num_lookups, const uint64_t* mult,
+                        const uint64_t* arg_offsets, const uint64_t* args, const uint64_t beta[2],
+                        const uint64_t gamma[2], const uint64_t acc_in[2], uint64_t* trace_out, uint64_t acc_out[2]);
+int32_t ms_claims_accumulator(ms_ctx* ctx, size_t n_claims, const uint64_t* claim_offsets, const uint64_t* claim_data,
+                              const uint64_t beta[2], const uint64_t gamma[2], uint64_t acc_out[2]);
+/* traces given as natural-order evaluations on the quotient domain ((n q) rows each, row-major); out: (n q) x 2 */
+int32_t ms_quotient_values(ms_system* sys, size_t circuit, const uint64_t publics8[8], uint32_t log_n, uint32_t log_q,
+                           const uint64_t* pre_q, const uint64_t* s1_q, const uint64_t* s2_q, const uint64_t alpha[2],
+                           uint64_t* out);
+/* element-wise field ops on device, for arithmetic known-answer tests: op 0 add, 1 sub, 2 mul, 3 inverse(a),
+ * 4 ext2 mul (pairs), 5 ext2 inverse (pairs) */
+int32_t ms_field_op(ms_ctx* ctx, int32_t op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSTARK_H */

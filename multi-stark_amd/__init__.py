@@ -1,0 +1,309 @@
+"""multi-stark hot path on MI355X: Python host mirror of the reference's interface over the C ABI.
+
+Names follow the reference: `System.new(config, circuits)` (src/system.rs:115), `SystemWitness.from_stage_1`
+(src/system.rs:244), `System.prove_multiple_claims` (src/prover.rs:290), `Proof.to_bytes` (src/prover.rs:245).
+All computation happens in `libmstark_hip.so` (hand-written gfx950 kernels behind include/mstark.h); there is no
+CPU fallback: loading fails loudly if the library or a HIP device is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import frontend  # noqa: F401
+from .frontend import Params, bench_params, test_params, compile_circuit, system_blob, pack_claims  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmstark_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+
+class MstarkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (never a substitute): raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MstarkError("libmstark_hip.so is missing: run `python multi-stark_amd/build.py` (needs hipcc)")
+        L = C.CDLL(LIB_PATH)
+        L.ms_last_error.restype = C.c_char_p
+        L.ms_kernel_name.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
+    return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
+            "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
+            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create",
+            "ms_witness_destroy", "ms_prove", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
+            "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_stage2_trace", "ms_claims_accumulator",
+            "ms_quotient_values", "ms_field_op"]
+
+
+def _check(rc):
+    if rc != 0:
+        raise MstarkError(lib().ms_last_error().decode() or ("mstark error %d" % rc))
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def _b(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """One HIP device (ms_ctx)."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().ms_ctx_create(C.c_int32(device), C.byref(self.h))
+        if rc != 0:
+            raise MstarkError("cannot create a HIP context: " + lib().ms_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ms_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().ms_ctx_sync(self.h))
+
+    def trim(self):
+        _check(lib().ms_ctx_trim(self.h))
+
+    # ---- profiling
+    def kernel_names(self):
+        return [lib().ms_kernel_name(C.c_int32(i)).decode() for i in range(lib().ms_kernel_count())]
+
+    def set_profile(self, names):
+        all_names = self.kernel_names()
+        mask = 0
+        for n in names:
+            mask |= 1 << all_names.index(n)
+        _check(lib().ms_ctx_set_profile_mask(self.h, C.c_uint32(mask)))
+
+    def reset_stats(self):
+        _check(lib().ms_ctx_reset_stats(self.h))
+
+    def kernel_stats(self):
+        out = {}
+        for i, n in enumerate(self.kernel_names()):
+            launches, ms, byts = C.c_uint64(), C.c_double(), C.c_double()
+            _check(lib().ms_ctx_kernel_stats(self.h, C.c_int32(i), C.byref(launches), C.byref(ms), C.byref(byts)))
+            out[n] = {"launches": launches.value, "ms": ms.value, "alg_bytes": byts.value}
+        return out
+
+    # ---- PCS-level entry points
+    def dft_batch(self, m, inverse=False):
+        m = _u64(m)
+        out = np.empty_like(m)
+        _check(lib().ms_dft_batch(self.h, _p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]), C.c_int32(int(inverse)), _p(out)))
+        return out
+
+    def coset_lde_batch(self, m, log_blowup):
+        m = _u64(m)
+        out = np.empty((m.shape[0] << log_blowup, m.shape[1]), dtype=np.uint64)
+        _check(lib().ms_coset_lde_batch(self.h, _p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]), C.c_uint32(log_blowup), _p(out)))
+        return out
+
+    def quotient_lde(self, q, log_n, log_q, log_blowup):
+        q = _u64(q)
+        D = q.shape[1]
+        out = np.empty((1 << (log_n + log_blowup), D << log_q), dtype=np.uint64)
+        _check(lib().ms_quotient_lde(self.h, _p(q), C.c_uint32(log_n), C.c_uint32(log_q), C.c_uint32(log_blowup), C.c_size_t(D), _p(out)))
+        return out
+
+    def blake3(self, data: bytes) -> bytes:
+        buf = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(32, dtype=np.uint8)
+        _check(lib().ms_blake3(self.h, _b(buf), C.c_size_t(len(data)), _b(out)))
+        return out.tobytes()
+
+    def stage2_trace(self, mult, arg_offsets, args, beta, gamma, acc_in):
+        mult, args, arg_offsets = _u64(mult), _u64(args), _u64(arg_offsets)
+        h, L = mult.shape
+        tr = np.zeros((h, max(L, 1) * 2), dtype=np.uint64)
+        acc = np.zeros(2, dtype=np.uint64)
+        _check(lib().ms_stage2_trace(self.h, C.c_size_t(h), C.c_size_t(L), _p(mult), _p(arg_offsets), _p(args), _p(_u64(beta)),
+                                     _p(_u64(gamma)), _p(_u64(acc_in)), _p(tr), _p(acc)))
+        return tr, (int(acc[0]), int(acc[1]))
+
+    def claims_accumulator(self, claims_packed, beta, gamma):
+        offs, data = claims_packed
+        data = data if data.size else np.zeros(1, dtype=np.uint64)
+        acc = np.zeros(2, dtype=np.uint64)
+        _check(lib().ms_claims_accumulator(self.h, C.c_size_t(len(offs) - 1), _p(offs), _p(data), _p(_u64(beta)), _p(_u64(gamma)), _p(acc)))
+        return int(acc[0]), int(acc[1])
+
+    def field_op(self, op, a, b=None):
+        a = _u64(a)
+        bb = _u64(b) if b is not None else None
+        out = np.empty_like(a)
+        n = a.size // 2 if op >= 4 else a.size
+        _check(lib().ms_field_op(self.h, C.c_int32(op), _p(a), _p(bb) if bb is not None else None, C.c_size_t(n), _p(out)))
+        return out
+
+
+class Mmcs:
+    """ProverData of one MerkleTreeMmcs commitment (ms_mmcs)."""
+
+    def __init__(self, ctx, mats, cap_height=0):
+        self.ctx = ctx
+        self.mats = [_u64(m) for m in mats]
+        n = len(self.mats)
+        ptrs = (u64p * n)(*[_p(m) for m in self.mats])
+        hs = _u64([m.shape[0] for m in self.mats])
+        ws = _u64([m.shape[1] for m in self.mats])
+        maxh = int(hs.max())
+        cap = np.zeros(32 * min(1 << cap_height, maxh), dtype=np.uint8)
+        self.h = C.c_void_p()
+        _check(lib().ms_mmcs_commit(ctx.h, C.c_size_t(n), ptrs, _p(hs), _p(ws), C.c_uint32(cap_height), _b(cap), C.byref(self.h)))
+        self.cap = cap.tobytes()
+        self.log_max = maxh.bit_length() - 1
+        self.widths = ws
+
+    def open(self, index):
+        vals = np.zeros(int(self.widths.sum()), dtype=np.uint64)
+        proof = np.zeros(32 * (self.log_max + 1), dtype=np.uint8)
+        ns = C.c_size_t()
+        _check(lib().ms_mmcs_open(self.h, C.c_size_t(index), _p(vals), _b(proof), C.byref(ns)))
+        return vals, proof[: 32 * ns.value].tobytes()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ms_mmcs_destroy(self.h)
+            self.h = None
+
+
+class Proof:
+    """Serialized `Proof<GoldilocksBlake3Config>` (src/prover.rs:213-254)."""
+
+    def __init__(self, data: bytes, stage_ms=None):
+        self._bytes = data
+        self.stage_ms = stage_ms
+
+    def to_bytes(self) -> bytes:
+        return self._bytes
+
+    @staticmethod
+    def from_bytes(data: bytes):
+        return Proof(bytes(data))
+
+
+class SystemWitness:
+    """Device-resident SystemWitness + claims (ms_witness). Built by `System.witness`."""
+
+    def __init__(self, handle, rows):
+        self.h = handle
+        self.rows = rows  # sum of active trace heights
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ms_witness_destroy(self.h)
+            self.h = None
+
+
+class System:
+    """System<GoldilocksBlake3Config> + ProverKey on one device."""
+
+    def __init__(self, ctx, blob: bytes, n_circuits: int):
+        self.ctx = ctx
+        self.n_circuits = n_circuits
+        self.blob = blob
+        a = np.frombuffer(blob, dtype=np.uint8)
+        self.h = C.c_void_p()
+        _check(lib().ms_system_create(ctx.h, _b(a), C.c_size_t(len(blob)), C.byref(self.h)))
+
+    @staticmethod
+    def new(ctx, params, circuit_inputs):
+        """`System::new(config, inputs)`: compiles each circuit with the front-end and commits the preprocessed traces."""
+        compiled = [compile_circuit(ci) for ci in circuit_inputs]
+        return System(ctx, system_blob(params, compiled), len(compiled))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ms_system_destroy(self.h)
+            self.h = None
+
+    def preprocessed_commit(self):
+        out = np.zeros(32 * 256, dtype=np.uint8)
+        n = C.c_size_t()
+        _check(lib().ms_system_preprocessed_commit(self.h, _b(out), C.c_size_t(out.size), C.byref(n)))
+        return out[: 32 * n.value].tobytes() if n.value else None
+
+    def circuit_info(self, ci):
+        o = np.zeros(9, dtype=np.uint64)
+        _check(lib().ms_system_circuit_info(self.h, C.c_size_t(ci), _p(o)))
+        keys = ["main_width", "pre_width", "pre_height", "num_lookups", "stage2_width", "constraint_count",
+                "max_constraint_degree", "quotient_degree", "args_width"]
+        return dict(zip(keys, (int(x) for x in o)))
+
+    def witness(self, traces, claims_packed, lookups=None):
+        """`SystemWitness::from_stage_1` (lookups=None) or an explicit SystemWitness{traces, lookups}; uploads to HBM."""
+        trs = [_u64(t) if t is not None and len(t) else np.zeros((0, 1), dtype=np.uint64) for t in traces]
+        n = self.n_circuits
+        if len(trs) != n:
+            raise MstarkError("expected one trace per circuit")
+        tptr = (u64p * n)(*[_p(t) for t in trs])
+        hs = _u64([t.shape[0] for t in trs])
+        mptr = aptr = None
+        keep = []
+        if lookups is not None:
+            ms, as_ = [], []
+            for (m, a) in lookups:
+                m, a = _u64(m), _u64(a)
+                keep += [m, a]
+                ms.append(_p(m))
+                as_.append(_p(a))
+            mptr, aptr = (u64p * n)(*ms), (u64p * n)(*as_)
+        offs, data = claims_packed
+        data = data if data.size else np.zeros(1, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().ms_witness_create(self.h, tptr, _p(hs), mptr, aptr, C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(h)))
+        return SystemWitness(h, int(hs.sum()))
+
+    def prove_multiple_claims(self, witness, want_times=False):
+        cap = getattr(self, "_proof_cap", 1 << 21)
+        times = np.zeros(6, dtype=np.float64)
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            n = C.c_size_t()
+            rc = lib().ms_prove(self.h, witness.h, _b(out), C.c_size_t(cap), C.byref(n),
+                                times.ctypes.data_as(C.POINTER(C.c_double)) if want_times else None)
+            if rc == -3:
+                cap = n.value
+                self._proof_cap = cap
+                continue
+            _check(rc)
+            keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]
+            return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
+
+    prove = prove_multiple_claims
+
+    def quotient_values(self, ci, publics8, log_n, log_q, pre_q, s1_q, s2_q, alpha):
+        N = 1 << (log_n + log_q)
+        out = np.zeros((N, 2), dtype=np.uint64)
+        pre = _u64(pre_q) if pre_q is not None else np.zeros(1, dtype=np.uint64)
+        _check(lib().ms_quotient_values(self.h, C.c_size_t(ci), _p(_u64(publics8)), C.c_uint32(log_n), C.c_uint32(log_q), _p(pre),
+                                        _p(_u64(s1_q)), _p(_u64(s2_q)), _p(_u64(alpha)), _p(out)))
+        return out

@@ -1,0 +1,347 @@
+// extern "C" boundary (include/mstark.h). No C++ exception crosses it.
+#include <string>
+
+#include "../../include/mstark.h"
+#include "host.h"
+
+using namespace msamd;
+
+struct ms_ctx {
+  Ctx ctx;
+  explicit ms_ctx(int dev) : ctx(dev) {}
+};
+struct ms_system {
+  std::unique_ptr<HSystem> sys;
+};
+struct ms_witness {
+  std::unique_ptr<HWitness> w;
+};
+struct ms_mmcs {
+  Ctx* ctx;
+  PcsData data;
+};
+
+static thread_local std::string g_err;
+
+#define MS_TRY try {
+#define MS_CATCH                    \
+  }                                 \
+  catch (const std::exception& e) { \
+    g_err = e.what();               \
+    (void)hipGetLastError();        \
+    return MS_ERR;                  \
+  }                                 \
+  catch (...) {                     \
+    g_err = "unknown error";        \
+    return MS_ERR;                  \
+  }
+
+namespace {
+// host row-major -> device column-major (optionally bit-reversed rows)
+DBuf<u64> upload_colmajor(Ctx& ctx, const u64* host, size_t h, size_t w, bool bitrev_rows) {
+  for (size_t i = 0; i < h * w; i++)
+    if (host[i] >= GL_P) throw std::runtime_error("non-canonical field element in input");
+  DBuf<u64> raw(ctx, h * w), col(ctx, h * w);
+  ctx.h2d(raw.p, host, h * w * 8);
+  transpose_in(ctx, raw.p, col.p, h, w, bitrev_rows);
+  ctx.sync();
+  return col;
+}
+void download_rowmajor(Ctx& ctx, const u64* col, size_t h, size_t w, bool bitrev_rows, u64* host) {
+  DBuf<u64> row(ctx, h * w);
+  transpose_out(ctx, col, row.p, h, w, bitrev_rows);
+  ctx.d2h(host, row.p, h * w * 8);
+}
+void check_pow2(size_t h) {
+  if (h == 0 || (h & (h - 1))) throw std::runtime_error("height must be a power of two");
+}
+}  // namespace
+
+extern "C" {
+
+const char* ms_last_error(void) { return g_err.c_str(); }
+
+int32_t ms_ctx_create(int32_t device, ms_ctx** out) {
+  try {
+    *out = new ms_ctx(device);
+    return MS_OK;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    *out = nullptr;
+    return MS_ERR_NO_DEVICE;
+  }
+}
+void ms_ctx_destroy(ms_ctx* ctx) { delete ctx; }
+int32_t ms_ctx_sync(ms_ctx* ctx) {
+  MS_TRY ctx->ctx.sync();
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_ctx_trim(ms_ctx* ctx) {
+  MS_TRY ctx->ctx.trim();
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_ctx_set_profile_mask(ms_ctx* ctx, uint32_t mask) {
+  ctx->ctx.prof_mask = mask;
+  return MS_OK;
+}
+int32_t ms_ctx_kernel_stats(ms_ctx* ctx, int32_t id, uint64_t* launches, double* ms, double* alg_bytes) {
+  MS_TRY if (id < 0 || id >= K_COUNT) throw std::runtime_error("kernel id out of range");
+  ctx->ctx.prof_collect();
+  const KernelStat& s = ctx->ctx.stats[id];
+  *launches = s.launches;
+  *ms = s.ms;
+  *alg_bytes = s.alg_bytes;
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_ctx_reset_stats(ms_ctx* ctx) {
+  MS_TRY ctx->ctx.prof_collect();
+  for (auto& s : ctx->ctx.stats) s = KernelStat();
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_kernel_count(void) { return K_COUNT; }
+const char* ms_kernel_name(int32_t id) { return kernel_name(id); }
+
+int32_t ms_system_create(ms_ctx* ctx, const uint8_t* blob, size_t len, ms_system** out) {
+  *out = nullptr;
+  MS_TRY std::unique_ptr<ms_system> s(new ms_system());
+  s->sys = system_from_blob(ctx->ctx, blob, len);
+  *out = s.release();
+  return MS_OK;
+  MS_CATCH
+}
+void ms_system_destroy(ms_system* sys) { delete sys; }
+int32_t ms_system_preprocessed_commit(const ms_system* sys, uint8_t* out, size_t cap, size_t* n_digests) {
+  MS_TRY const HSystem& s = *sys->sys;
+  *n_digests = s.has_pre ? s.pre_commit.size() : 0;
+  if (*n_digests * 32 > cap) return MS_ERR_BUFFER;
+  for (size_t i = 0; i < *n_digests; i++) memcpy(out + 32 * i, s.pre_commit[i].b, 32);
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_system_circuit_info(const ms_system* sys, size_t ci, uint64_t out9[9]) {
+  MS_TRY const HSystem& s = *sys->sys;
+  if (ci >= s.circuits.size()) throw std::runtime_error("circuit index out of range");
+  const HCircuit& c = s.circuits[ci];
+  const uint64_t v[9] = {c.main_width,       c.pre_width,           c.pre_height,         c.num_lookups, c.stage2_width,
+                         c.constraint_count, c.max_constraint_degree, c.quotient_degree(), c.args_width};
+  memcpy(out9, v, sizeof(v));
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, const uint64_t* const* mult,
+                          const uint64_t* const* args, size_t n_claims, const uint64_t* claim_offsets,
+                          const uint64_t* claim_data, ms_witness** out) {
+  *out = nullptr;
+  MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
+  w->w = witness_create(*sys->sys, traces, heights, mult, args, n_claims, claim_offsets, claim_data);
+  *out = w.release();
+  return MS_OK;
+  MS_CATCH
+}
+void ms_witness_destroy(ms_witness* w) { delete w; }
+
+int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms) {
+  MS_TRY StageMs st;
+  std::vector<uint8_t> bytes = prove(*sys->sys, *w->w, stage_ms ? &st : nullptr);
+  if (stage_ms) memcpy(stage_ms, st.v, sizeof(st.v));
+  *proof_len = bytes.size();
+  if (bytes.size() > cap) return MS_ERR_BUFFER;
+  memcpy(proof_out, bytes.data(), bytes.size());
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_dft_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, int32_t inverse, uint64_t* out) {
+  MS_TRY Ctx& ctx = c->ctx;
+  check_pow2(h);
+  if (w == 0) return MS_OK;
+  unsigned logn = log2_strict(h);
+  DBuf<u64> col = upload_colmajor(ctx, in, h, w, true);  // bit-reversed rows feed the in-place DIT
+  u64 scale = inverse ? gl_inv((u64)h % GL_P) : 1;
+  ntt_dit(ctx, col.p, logn, w, inverse != 0, scale);
+  download_rowmajor(ctx, col.p, h, w, false, out);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_coset_lde_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, uint32_t log_blowup, uint64_t* out) {
+  MS_TRY Ctx& ctx = c->ctx;
+  check_pow2(h);
+  if (w == 0) return MS_OK;
+  unsigned logn = log2_strict(h);
+  if (logn > NTT_MAX_LOG || logn + log_blowup > TW_LOG) throw std::runtime_error("matrix too tall");
+  DBuf<u64> col = upload_colmajor(ctx, in, h, w, true);
+  DBuf<u64> lde(ctx, (h << log_blowup) * w);
+  coset_lde(ctx, col.p, lde.p, logn, log_blowup, w);
+  download_rowmajor(ctx, lde.p, h << log_blowup, w, false, out);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_quotient_lde(ms_ctx* c, const uint64_t* in, uint32_t log_n, uint32_t log_q, uint32_t log_blowup, size_t D,
+                        uint64_t* out) {
+  MS_TRY Ctx& ctx = c->ctx;
+  size_t nq = size_t(1) << (log_n + log_q);
+  if (log_n + log_q > NTT_MAX_LOG || log_n + log_blowup > TW_LOG) throw std::runtime_error("matrix too tall");
+  DBuf<u64> col = upload_colmajor(ctx, in, nq, D, true);  // storage (bit-reversed) order, as the quotient kernel writes
+  size_t H = size_t(1) << (log_n + log_blowup), W = D << log_q;
+  DBuf<u64> lde(ctx, H * W);
+  quotient_lde(ctx, col.p, lde.p, log_n, log_q, log_blowup, D);
+  download_rowmajor(ctx, lde.p, H, W, false, out);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_mmcs_commit(ms_ctx* c, size_t n, const uint64_t* const* mats, const uint64_t* heights, const uint64_t* widths,
+                       uint32_t cap_height, uint8_t* cap_out, ms_mmcs** out) {
+  *out = nullptr;
+  MS_TRY Ctx& ctx = c->ctx;
+  std::unique_ptr<ms_mmcs> m(new ms_mmcs());
+  m->ctx = &ctx;
+  std::vector<DMat> ms;
+  for (size_t i = 0; i < n; i++) {
+    check_pow2(heights[i]);
+    DMat dm;
+    dm.h = heights[i];
+    dm.w = widths[i];
+    dm.buf = upload_colmajor(ctx, mats[i], dm.h, dm.w, false);
+    ms.push_back(std::move(dm));
+  }
+  commit_matrices(ctx, std::move(ms), cap_height, m->data);
+  std::vector<Digest> cap = merkle_cap(ctx, m->data.tree);
+  for (size_t i = 0; i < cap.size(); i++) memcpy(cap_out + 32 * i, cap[i].b, 32);
+  *out = m.release();
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proof_out, size_t* n_siblings) {
+  MS_TRY Ctx& ctx = *m->ctx;
+  const DTree& t = m->data.tree;
+  unsigned lmh = log2_strict(t.max_height());
+  if (index >= t.max_height()) throw std::runtime_error("index out of range");
+  std::vector<GatherReq> reqs;
+  size_t off = 0;
+  for (auto& dm : m->data.ldes) {
+    GatherReq q{dm.d(), dm.h, index >> (lmh - log2_strict(dm.h)), (uint32_t)dm.w, 0, off};
+    reqs.push_back(q);
+    off += dm.w * 8;
+  }
+  size_t vals_bytes = off;
+  size_t ns = t.cap_layer();
+  for (size_t i = 0; i < ns; i++) {
+    GatherReq q{t.digests.p + t.layer_off[i], 0, (index >> i) ^ 1, 1, 1, off};
+    reqs.push_back(q);
+    off += 32;
+  }
+  std::vector<uint8_t> g(off);
+  gather_rows(ctx, reqs, g.data(), off);
+  memcpy(vals_out, g.data(), vals_bytes);
+  memcpy(proof_out, g.data() + vals_bytes, ns * 32);
+  *n_siblings = ns;
+  return MS_OK;
+  MS_CATCH
+}
+void ms_mmcs_destroy(ms_mmcs* m) { delete m; }
+
+int32_t ms_blake3(ms_ctx* c, const uint8_t* bytes, size_t len, uint8_t out32[32]) {
+  MS_TRY Ctx& ctx = c->ctx;
+  size_t pl = len & 7, nw = len >> 3;
+  DBuf<uint8_t> pre(ctx, 8);
+  DBuf<u64> words(ctx, std::max<size_t>(nw, 1));
+  if (pl) ctx.h2d(pre.p, bytes, pl);
+  if (nw) ctx.h2d(words.p, bytes + pl, nw * 8);
+  Digest d = blake3_device(ctx, pre.p, pl, words.p, nw);
+  memcpy(out32, d.b, 32);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_stage2_trace(ms_ctx* c, size_t height, size_t L, const uint64_t* mult, const uint64_t* arg_offsets,
+                        const uint64_t* args, const uint64_t beta[2], const uint64_t gamma[2], const uint64_t acc_in[2],
+                        uint64_t* trace_out, uint64_t acc_out[2]) {
+  MS_TRY Ctx& ctx = c->ctx;
+  check_pow2(height);
+  DLookups lk;
+  lk.height = height;
+  lk.num_lookups = L;
+  std::vector<uint32_t> offs(L + 1);
+  for (size_t i = 0; i <= L; i++) offs[i] = (uint32_t)arg_offsets[i];
+  lk.args_width = offs[L];
+  lk.arg_offsets = DBuf<uint32_t>(ctx, L + 1);
+  ctx.h2d(lk.arg_offsets.p, offs.data(), (L + 1) * 4);
+  lk.mult = DBuf<u64>(ctx, std::max<size_t>(height * L, 1));
+  lk.args = DBuf<u64>(ctx, std::max<size_t>(height * lk.args_width, 1));
+  if (L) ctx.h2d(lk.mult.p, mult, height * L * 8);
+  if (lk.args_width) ctx.h2d(lk.args.p, args, height * lk.args_width * 8);
+  size_t w2 = std::max<size_t>(L, 1) * 2;
+  DBuf<u64> out(ctx, height * w2);
+  E2 total = stage2_build(ctx, lk, e2(beta[0], beta[1]), e2(gamma[0], gamma[1]), out.p);
+  E2 acc = e2_add(e2(acc_in[0], acc_in[1]), total);
+  acc_out[0] = acc.c0;
+  acc_out[1] = acc.c1;
+  download_rowmajor(ctx, out.p, height, w2, true, trace_out);  // undo the bit-reversed row order
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_claims_accumulator(ms_ctx* c, size_t n_claims, const uint64_t* offs, const uint64_t* data, const uint64_t beta[2],
+                              const uint64_t gamma[2], uint64_t acc_out[2]) {
+  MS_TRY Ctx& ctx = c->ctx;
+  size_t tot = n_claims ? offs[n_claims] : 0;
+  DBuf<u64> d_offs(ctx, n_claims + 1), d_data(ctx, std::max<size_t>(tot, 1));
+  ctx.h2d(d_offs.p, offs, (n_claims + 1) * 8);
+  if (tot) ctx.h2d(d_data.p, data, tot * 8);
+  E2 a = claims_accumulator(ctx, d_data.p, d_offs.p, n_claims, e2(beta[0], beta[1]), e2(gamma[0], gamma[1]));
+  acc_out[0] = a.c0;
+  acc_out[1] = a.c1;
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_quotient_values(ms_system* sys, size_t ci, const uint64_t publics8[8], uint32_t log_n, uint32_t log_q,
+                           const uint64_t* pre_q, const uint64_t* s1_q, const uint64_t* s2_q, const uint64_t alpha[2],
+                           uint64_t* out) {
+  MS_TRY HSystem& s = *sys->sys;
+  Ctx& ctx = *s.ctx;
+  if (ci >= s.circuits.size()) throw std::runtime_error("circuit index out of range");
+  const HCircuit& c = s.circuits[ci];
+  size_t nq = size_t(1) << (log_n + log_q);
+  DBuf<u64> pre, s1, s2;
+  if (c.pre_width) pre = upload_colmajor(ctx, pre_q, nq, c.pre_width, true);
+  s1 = upload_colmajor(ctx, s1_q, nq, c.main_width, true);
+  s2 = upload_colmajor(ctx, s2_q, nq, c.stage2_width, true);
+  QuotientArgs qa;
+  qa.pre = pre.p;
+  qa.s1 = s1.p;
+  qa.s2 = s2.p;
+  qa.pre_h = qa.s1_h = qa.s2_h = nq;
+  qa.log_n = log_n;
+  qa.log_q = log_q;
+  memcpy(qa.publics, publics8, 64);
+  qa.alpha = e2(alpha[0], alpha[1]);
+  DBuf<u64> q(ctx, nq * 2);
+  quotient_eval(ctx, c.prog, qa, q.p);
+  download_rowmajor(ctx, q.p, nq, 2, true, out);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_field_op(ms_ctx* c, int32_t op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  MS_TRY Ctx& ctx = c->ctx;
+  size_t words = op >= 4 ? 2 * n : n;
+  DBuf<u64> da(ctx, words), db(ctx, words), dout(ctx, words);
+  ctx.h2d(da.p, a, words * 8);
+  if (b) ctx.h2d(db.p, b, words * 8);
+  field_op(ctx, op, da.p, b ? db.p : da.p, n, dout.p);
+  ctx.d2h(out, dout.p, words * 8);
+  return MS_OK;
+  MS_CATCH
+}
+
+}  // extern "C"

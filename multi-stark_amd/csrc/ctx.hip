@@ -1,0 +1,174 @@
+// Device context: stream, twiddle tables, pooled memory, event-based per-kernel timing.
+#include "msamd.h"
+
+namespace msamd {
+
+static const char* KNAMES[K_COUNT] = {"ntt_strided", "ntt_contig", "leaf_hash", "compress_layer", "stage2", "quotient",
+                                      "bary_eval",   "deep_reduce", "fri_fold", "transpose",      "other"};
+const char* kernel_name(int id) { return id >= 0 && id < K_COUNT ? KNAMES[id] : "?"; }
+
+namespace {
+__global__ void field_op_k(int op, const u64* a, const u64* b, size_t n, u64* out) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  switch (op) {
+    case 0: out[i] = gl_add(a[i], b[i]); break;
+    case 1: out[i] = gl_sub(a[i], b[i]); break;
+    case 2: out[i] = gl_mul(a[i], b[i]); break;
+    case 3: out[i] = gl_inv(a[i]); break;
+    case 4: {
+      E2 r = e2_mul(e2(a[2 * i], a[2 * i + 1]), e2(b[2 * i], b[2 * i + 1]));
+      out[2 * i] = r.c0;
+      out[2 * i + 1] = r.c1;
+      break;
+    }
+    default: {
+      E2 r = e2_inv(e2(a[2 * i], a[2 * i + 1]));
+      out[2 * i] = r.c0;
+      out[2 * i + 1] = r.c1;
+      break;
+    }
+  }
+}
+}  // namespace
+
+void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out) {
+  hipLaunchKernelGGL(field_op_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, op, a, b, n, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+Ctx::Ctx(int dev) : device(dev) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) throw std::runtime_error("no HIP device available");
+  if (dev < 0 || dev >= count) throw std::runtime_error("HIP device index out of range");
+  HIP_CHECK(hipSetDevice(dev));
+  HIP_CHECK(hipStreamCreate(&stream));
+  const size_t T = size_t(1) << TW_HALF;
+  std::vector<u64> h(4 * T);
+  u64 W = gl_two_adic_generator(TW_LOG), Wi = gl_inv(W);
+  u64 Wh = gl_exp_pow2(W, TW_HALF), Whi = gl_exp_pow2(Wi, TW_HALF);
+  u64 a = 1, b = 1, c = 1, d = 1;
+  for (size_t i = 0; i < T; i++) {
+    h[i] = a;
+    h[T + i] = b;
+    h[2 * T + i] = c;
+    h[3 * T + i] = d;
+    a = gl_mul(a, W);
+    b = gl_mul(b, Wh);
+    c = gl_mul(c, Wi);
+    d = gl_mul(d, Whi);
+  }
+  u64* t = nullptr;
+  HIP_CHECK(hipMalloc(&t, 4 * T * sizeof(u64)));
+  HIP_CHECK(hipMemcpy(t, h.data(), 4 * T * sizeof(u64), hipMemcpyHostToDevice));
+  tw0 = t;
+  tw1 = t + T;
+  tw0i = t + 2 * T;
+  tw1i = t + 3 * T;
+}
+
+Ctx::~Ctx() {
+  (void)hipSetDevice(device);
+  (void)hipStreamSynchronize(stream);
+  for (auto& p : prof_pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto e : event_pool) (void)hipEventDestroy(e);
+  for (auto& kv : pool_free) (void)hipFree(kv.second);
+  for (auto& kv : pool_live) (void)hipFree(kv.first);
+  for (auto& kv : lde_scales) (void)hipFree(kv.second);
+  if (tw0) (void)hipFree(tw0);
+  (void)hipStreamDestroy(stream);
+}
+
+void* Ctx::alloc(size_t bytes) {
+  size_t sz = (bytes + 255) & ~size_t(255);
+  if (sz == 0) sz = 256;
+  auto it = pool_free.find(sz);
+  void* p = nullptr;
+  if (it != pool_free.end()) {
+    p = it->second;
+    pool_free.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      // give pooled blocks back and retry once
+      (void)hipGetLastError();
+      trim();
+      HIP_CHECK(hipMalloc(&p, sz));
+    }
+    pool_bytes += sz;
+  }
+  pool_live[p] = sz;
+  return p;
+}
+
+void Ctx::release(void* p) {
+  auto it = pool_live.find(p);
+  if (it == pool_live.end()) return;
+  pool_free.emplace(it->second, p);
+  pool_live.erase(it);
+}
+
+void Ctx::trim() {
+  (void)hipStreamSynchronize(stream);
+  for (auto& kv : pool_free) {
+    (void)hipFree(kv.second);
+    pool_bytes -= kv.first;
+  }
+  pool_free.clear();
+}
+
+void Ctx::h2d(void* dst, const void* src, size_t n) {
+  if (n == 0) return;
+  HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
+}
+
+void Ctx::d2h(void* dst, const void* src, size_t n) {
+  if (n) HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+hipEvent_t Ctx::prof_begin(int id) {
+  if (!prof_on(id)) return nullptr;
+  hipEvent_t a;
+  if (!event_pool.empty()) {
+    a = event_pool.back();
+    event_pool.pop_back();
+  } else {
+    HIP_CHECK(hipEventCreate(&a));
+  }
+  HIP_CHECK(hipEventRecord(a, stream));
+  return a;
+}
+
+void Ctx::prof_end(int id, hipEvent_t a, double bytes) {
+  if (!a) return;
+  hipEvent_t b;
+  if (!event_pool.empty()) {
+    b = event_pool.back();
+    event_pool.pop_back();
+  } else {
+    HIP_CHECK(hipEventCreate(&b));
+  }
+  HIP_CHECK(hipEventRecord(b, stream));
+  prof_pending.push_back(Pending{id, a, b, bytes});
+}
+
+void Ctx::prof_collect() {
+  if (prof_pending.empty()) return;
+  HIP_CHECK(hipStreamSynchronize(stream));
+  for (auto& p : prof_pending) {
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+    stats[p.id].launches++;
+    stats[p.id].ms += ms;
+    stats[p.id].alg_bytes += p.bytes;
+    event_pool.push_back(p.a);
+    event_pool.push_back(p.b);
+  }
+  prof_pending.clear();
+}
+
+}  // namespace msamd

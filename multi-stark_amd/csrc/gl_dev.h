@@ -1,0 +1,172 @@
+// Goldilocks (p = 2^64 - 2^32 + 1) and its quadratic extension X^2 = 7, for gfx950 device code and for
+// the host-side scalar work of the prover (challenges, alpha powers, selectors constants).
+// Field the reference instantiates: /root/reference/src/types.rs:24-27 (Val = Goldilocks, ExtVal =
+// BinomialExtensionField<Val, 2>); W recovered as X^D in src/system.rs:334-349.
+// All values are kept canonical (< p) in memory; 2^64 = 2^32 - 1 and 2^96 = -1 (mod p) drive the reduction.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+namespace msamd {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+static constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
+static constexpr u64 GL_EPS = 0xFFFFFFFFULL;
+static constexpr u64 GL_GEN = 7;                          // multiplicative generator (p3 Goldilocks::GENERATOR)
+static constexpr u64 GL_W32 = 1753635133440165772ULL;     // generator of the order-2^32 subgroup = 7^((p-1)/2^32)
+static constexpr u64 GL_EXT_W = 7;                        // X^2 = 7
+
+GL_HD u64 gl_add(u64 a, u64 b) {
+  u64 s = a + b;
+  if (s < a || s >= GL_P) s -= GL_P;
+  return s;
+}
+GL_HD u64 gl_sub(u64 a, u64 b) {
+  u64 d = a - b;
+  if (a < b) d += GL_P;
+  return d;
+}
+GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+
+GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  u64 t1 = hi_lo * GL_EPS;  // (hi_lo << 32) - hi_lo, fits in 64 bits
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
+
+GL_HD u64 gl_mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 lo = a * b;
+  u64 hi = __umul64hi(a, b);
+#else
+  unsigned __int128 x = (unsigned __int128)a * b;
+  u64 lo = (u64)x, hi = (u64)(x >> 64);
+#endif
+  return gl_reduce128(lo, hi);
+}
+GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+// multiply by a small constant c < 2^32: the high word is < 2^32 so only the 2^64 = 2^32 - 1 fold is needed
+GL_HD u64 gl_mul_small(u64 a, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 lo = a * (u64)c;
+  u64 hi = __umul64hi(a, (u64)c);
+#else
+  unsigned __int128 x = (unsigned __int128)a * c;
+  u64 lo = (u64)x, hi = (u64)(x >> 64);
+#endif
+  u64 t1 = hi * GL_EPS;
+  u64 r = lo + t1;
+  if (r < t1) r += GL_EPS;
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
+
+GL_HD u64 gl_pow(u64 b, u64 e) {
+  u64 r = 1;
+  while (e) {
+    if (e & 1) r = gl_mul(r, b);
+    b = gl_mul(b, b);
+    e >>= 1;
+  }
+  return r;
+}
+GL_HD u64 gl_exp_pow2(u64 a, unsigned k) {
+  for (unsigned i = 0; i < k; i++) a = gl_mul(a, a);
+  return a;
+}
+// a^(p-2) by an addition chain on the exponent 0xFFFFFFFEFFFFFFFF (72 multiplications)
+GL_HD u64 gl_inv(u64 a) {
+  u64 t2 = gl_mul(gl_sqr(a), a);                 // 2^2 - 1
+  u64 t3 = gl_mul(gl_sqr(t2), a);                // 2^3 - 1
+  u64 t6 = gl_mul(gl_exp_pow2(t3, 3), t3);       // 2^6 - 1
+  u64 t12 = gl_mul(gl_exp_pow2(t6, 6), t6);      // 2^12 - 1
+  u64 t24 = gl_mul(gl_exp_pow2(t12, 12), t12);   // 2^24 - 1
+  u64 t30 = gl_mul(gl_exp_pow2(t24, 6), t6);     // 2^30 - 1
+  u64 t31 = gl_mul(gl_sqr(t30), a);              // 2^31 - 1
+  u64 t32 = gl_mul(gl_sqr(t31), a);              // 2^32 - 1
+  // exponent = (2^31 - 1) * 2^33 + (2^32 - 1)
+  u64 r = gl_exp_pow2(t31, 33);
+  return gl_mul(r, t32);
+}
+GL_HD u64 gl_two_adic_generator(unsigned bits) { return gl_exp_pow2(GL_W32, 32 - bits); }
+
+struct E2 {
+  u64 c0, c1;
+};
+GL_HD E2 e2(u64 a, u64 b = 0) {
+  E2 r;
+  r.c0 = a;
+  r.c1 = b;
+  return r;
+}
+GL_HD E2 e2_add(E2 a, E2 b) { return e2(gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)); }
+GL_HD E2 e2_sub(E2 a, E2 b) { return e2(gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)); }
+GL_HD E2 e2_neg(E2 a) { return e2(gl_neg(a.c0), gl_neg(a.c1)); }
+GL_HD E2 e2_mul(E2 a, E2 b) {
+  // Karatsuba: 3 base multiplications + one multiplication by the small constant 7
+  u64 v0 = gl_mul(a.c0, b.c0), v1 = gl_mul(a.c1, b.c1);
+  u64 cross = gl_sub(gl_sub(gl_mul(gl_add(a.c0, a.c1), gl_add(b.c0, b.c1)), v0), v1);
+  return e2(gl_add(v0, gl_mul_small(v1, (u32)GL_EXT_W)), cross);
+}
+GL_HD E2 e2_sqr(E2 a) {
+  u64 v0 = gl_sqr(a.c0), v1 = gl_sqr(a.c1);
+  u64 m = gl_mul(a.c0, a.c1);
+  return e2(gl_add(v0, gl_mul_small(v1, (u32)GL_EXT_W)), gl_add(m, m));
+}
+GL_HD E2 e2_mul_base(E2 a, u64 b) { return e2(gl_mul(a.c0, b), gl_mul(a.c1, b)); }
+GL_HD E2 e2_inv(E2 a) {
+  u64 norm = gl_sub(gl_sqr(a.c0), gl_mul_small(gl_sqr(a.c1), (u32)GL_EXT_W));
+  u64 ni = gl_inv(norm);
+  return e2(gl_mul(a.c0, ni), gl_mul(gl_neg(a.c1), ni));
+}
+GL_HD bool e2_is_zero(E2 a) { return (a.c0 | a.c1) == 0; }
+GL_HD E2 e2_pow(E2 b, u64 e) {
+  E2 r = e2(1);
+  while (e) {
+    if (e & 1) r = e2_mul(r, b);
+    b = e2_sqr(b);
+    e >>= 1;
+  }
+  return r;
+}
+GL_HD E2 e2_exp_pow2(E2 a, unsigned k) {
+  for (unsigned i = 0; i < k; i++) a = e2_sqr(a);
+  return a;
+}
+
+GL_HD u32 bitrev32(u32 x, unsigned bits) {
+  if (bits == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x) >> (32 - bits);
+#else
+  u32 r = 0;
+  for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+  return r;
+#endif
+}
+GL_HD u64 bitrev64(u64 x, unsigned bits) {
+  u64 r = 0;
+  for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1ull) << (bits - 1 - i);
+  return r;
+}
+inline unsigned log2_strict(size_t n) {
+  unsigned l = 0;
+  while ((size_t(1) << l) < n) l++;
+  return l;
+}
+
+}  // namespace msamd

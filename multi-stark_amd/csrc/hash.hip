@@ -1,0 +1,350 @@
+// BLAKE3 Merkle tree build (p3 MerkleTreeMmcs<Goldilocks,u8,SerializingHasher<Blake3>,
+// CompressionFunctionFromHasher<Blake3,2,32>,2,32>, /root/reference/src/types.rs:82-83,202-207) and a
+// whole-buffer BLAKE3 for the claims part of the Fiat-Shamir transcript (src/prover.rs:369-373).
+//
+// One thread hashes one row: matrices are column-major, so lane i reads element (i, c) of every column c at
+// consecutive addresses (coalesced); each Goldilocks element contributes its canonical value as two
+// little-endian 32-bit message words. Shorter matrices are injected at the layer whose length equals their
+// height: node = compress(compress(l, r), hash(rows)).
+#include <algorithm>
+
+#include "b3_dev.h"
+#include "msamd.h"
+
+namespace msamd {
+
+namespace {
+
+struct RowIter {
+  const MatRef* g;
+  size_t H, row;
+  unsigned mi;
+  u32 c;
+  __device__ __forceinline__ u64 next() {
+    while (c == g[mi].w) {
+      mi++;
+      c = 0;
+    }
+    u64 v = g[mi].d[size_t(c) * H + row];
+    c++;
+    return v;
+  }
+};
+
+__device__ __forceinline__ void parent_cv(const u32 l[8], const u32 r[8], u32 flags_extra, u32 out[8]) {
+  u32 m[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    m[i] = l[i];
+    m[8 + i] = r[i];
+  }
+  b3_iv(out);
+  b3_compress(out, m, 0, 64, B3_PARENT | flags_extra);
+}
+
+// BLAKE3 of the serialised row (total_w elements, 8 bytes each). MULTI: rows longer than one 1024-byte chunk.
+template <bool MULTI>
+__device__ __forceinline__ void hash_row(const MatRef* g, size_t H, size_t row, u32 total_w, u32 out[8]) {
+  RowIter it{g, H, row, 0, 0};
+  u32 cv[8];
+  b3_iv(cv);
+  u32 m[16];
+  u32 stack[MULTI ? 8 * 10 : 8];  // chaining-value stack (up to 2^10 chunks = 1 MiB rows)
+  u32 stack_len = 0;
+  u64 chunk = 0;
+  u32 nvalid = 0;
+  for (u32 base = 0; base < total_w; base += 8) {
+    if (base > 0) {
+      // the block in m is full and more input follows
+      u32 bic = ((base >> 3) - 1) & 15;  // index of that block within its chunk
+      u32 flags = bic == 0 ? B3_CHUNK_START : 0;
+      if (MULTI && bic == 15) {
+        b3_compress(cv, m, chunk, 64, flags | B3_CHUNK_END);
+        u64 total_chunks = chunk + 1;
+        while ((total_chunks & 1) == 0) {
+          stack_len--;
+          u32 l[8], t[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) l[i] = stack[stack_len * 8 + i];
+          parent_cv(l, cv, 0, t);
+#pragma unroll
+          for (int i = 0; i < 8; i++) cv[i] = t[i];
+          total_chunks >>= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) stack[stack_len * 8 + i] = cv[i];
+        stack_len++;
+        chunk++;
+        b3_iv(cv);
+      } else {
+        b3_compress(cv, m, chunk, 64, flags);
+      }
+    }
+    nvalid = total_w - base < 8 ? total_w - base : 8;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+      u64 v = j < nvalid ? it.next() : 0;
+      m[2 * j] = (u32)v;
+      m[2 * j + 1] = (u32)(v >> 32);
+    }
+  }
+  u32 nblocks = (total_w + 7) >> 3;
+  u32 bic = (nblocks - 1) & 15;
+  u32 flags = (bic == 0 ? B3_CHUNK_START : 0) | B3_CHUNK_END;
+  if (!MULTI || stack_len == 0) flags |= B3_ROOT;
+  b3_compress(cv, m, chunk, nvalid * 8, flags);
+  if (MULTI) {
+    while (stack_len > 0) {
+      stack_len--;
+      u32 l[8], t[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) l[i] = stack[stack_len * 8 + i];
+      parent_cv(l, cv, stack_len == 0 ? B3_ROOT : 0, t);
+#pragma unroll
+      for (int i = 0; i < 8; i++) cv[i] = t[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
+__device__ __forceinline__ void store_digest(Digest* p, const u32 cv[8]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+  q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+__device__ __forceinline__ void load_digest(const Digest* p, u32 cv[8]) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  cv[0] = a.x;
+  cv[1] = a.y;
+  cv[2] = a.z;
+  cv[3] = a.w;
+  cv[4] = b.x;
+  cv[5] = b.y;
+  cv[6] = b.z;
+  cv[7] = b.w;
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256) void leaf_hash_k(const MatRef* __restrict__ g, size_t H, u32 total_w, Digest* out) {
+  size_t row = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (row >= H) return;
+  u32 cv[8];
+  hash_row<MULTI>(g, H, row, total_w, cv);
+  store_digest(out + row, cv);
+}
+
+// next[i] = compress(prev[2i], prev[2i+1]); with an injected group: compress(that, hash(rows i))
+template <bool INJECT, bool MULTI>
+__global__ __launch_bounds__(256) void compress_layer_k(const Digest* __restrict__ prev, Digest* __restrict__ next, size_t n,
+                                                        const MatRef* __restrict__ g, u32 total_w) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  u32 l[8], r[8], d[8];
+  load_digest(prev + 2 * i, l);
+  load_digest(prev + 2 * i + 1, r);
+  b3_compress_pair_root(l, r, d);
+  if (INJECT) {
+    u32 rh[8], e[8];
+    hash_row<MULTI>(g, n, i, total_w, rh);
+    b3_compress_pair_root(d, rh, e);
+    store_digest(next + i, e);
+  } else {
+    store_digest(next + i, d);
+  }
+}
+
+// ---- whole-stream BLAKE3. The stream is `prefix` (prefix_len bytes, any alignment) followed by `nwords`
+// little-endian u64 words (8-byte aligned), which is how the transcript up to the claims is shaped: a short
+// host-built prefix, then the length-prefixed claims as field elements.
+__device__ __forceinline__ u32 stream_byte(const uint8_t* __restrict__ prefix, size_t pl, const u64* __restrict__ words, size_t p) {
+  if (p < pl) return prefix[p];
+  size_t q = p - pl;
+  return (u32)((words[q >> 3] >> (8 * (q & 7))) & 0xff);
+}
+
+__global__ __launch_bounds__(256) void chunk_cv_k(const uint8_t* __restrict__ prefix, size_t pl, const u64* __restrict__ words,
+                                                  size_t len, size_t nchunks, Digest* out) {
+  size_t ch = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (ch >= nchunks) return;
+  size_t off = ch * 1024;
+  size_t clen = len - off < 1024 ? len - off : 1024;
+  u32 nblocks = clen == 0 ? 1 : (u32)((clen + 63) / 64);
+  u32 cv[8];
+  b3_iv(cv);
+  const bool single = nchunks == 1;
+  for (u32 b = 0; b < nblocks; b++) {
+    u32 m[16];
+    size_t boff = off + size_t(b) * 64;
+    u32 bl = (u32)(clen - size_t(b) * 64 < 64 ? clen - size_t(b) * 64 : 64);
+    if (bl == 64 && boff >= pl) {
+      size_t q = boff - pl;
+      const u64* w = words + (q >> 3);
+      unsigned s = (unsigned)(q & 7) * 8;
+      u64 cur = w[0];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        u64 x;
+        if (s == 0) {
+          x = cur;
+          if (k < 7) cur = w[k + 1];
+        } else {
+          u64 nxt = w[k + 1];
+          x = (cur >> s) | (nxt << (64 - s));
+          cur = nxt;
+        }
+        m[2 * k] = (u32)x;
+        m[2 * k + 1] = (u32)(x >> 32);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        u32 wv = 0;
+        for (int k = 0; k < 4; k++) {
+          u32 idx = 4 * i + k;
+          u32 byte = idx < bl ? stream_byte(prefix, pl, words, boff + idx) : 0;
+          wv |= byte << (8 * k);
+        }
+        m[i] = wv;
+      }
+    }
+    u32 flags = (b == 0 ? B3_CHUNK_START : 0) | (b == nblocks - 1 ? (B3_CHUNK_END | (single ? B3_ROOT : 0)) : 0);
+    b3_compress(cv, m, ch, bl, flags);
+  }
+  store_digest(out + ch, cv);
+}
+
+// one level of the left-full tree: pair adjacent chaining values, carry an odd last one up unchanged
+__global__ __launch_bounds__(256) void cv_level_k(const Digest* __restrict__ prev, Digest* __restrict__ next, size_t n_prev,
+                                                  u32 root_flag) {
+  size_t n_next = (n_prev + 1) / 2;
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= n_next) return;
+  u32 l[8];
+  load_digest(prev + 2 * i, l);
+  if (2 * i + 1 < n_prev) {
+    u32 r[8], o[8];
+    load_digest(prev + 2 * i + 1, r);
+    parent_cv(l, r, root_flag, o);
+    store_digest(next + i, o);
+  } else {
+    store_digest(next + i, l);
+  }
+}
+
+}  // namespace
+
+void merkle_alloc(Ctx& ctx, DTree& t, size_t maxh) {
+  t.layer_off.clear();
+  t.layer_len.clear();
+  size_t tot = 0;
+  for (size_t l = maxh;; l >>= 1) {
+    t.layer_off.push_back(tot);
+    t.layer_len.push_back(l);
+    tot += l;
+    if (l == 1) break;
+  }
+  t.digests = DBuf<Digest>(ctx, tot);
+}
+
+void merkle_compress_plain(Ctx& ctx, DTree& t) {
+  for (size_t li = 1; li < t.layer_len.size(); li++) {
+    size_t n = t.layer_len[li];
+    hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
+    hipLaunchKernelGGL((compress_layer_k<false, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream,
+                       t.digests.p + t.layer_off[li - 1], t.digests.p + t.layer_off[li], n, (const MatRef*)nullptr, 0u);
+    ctx.prof_end(K_COMPRESS, ev, double(n) * 96.0);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void merkle_build(Ctx& ctx, DTree& t) {
+  size_t nm = t.mat_d.size();
+  if (nm == 0) throw std::runtime_error("merkle_build: no matrices");
+  std::vector<size_t> order(nm);
+  for (size_t i = 0; i < nm; i++) {
+    order[i] = i;
+    if (t.mat_h[i] == 0 || (t.mat_h[i] & (t.mat_h[i] - 1))) throw std::runtime_error("merkle_build: heights must be powers of two");
+    if (t.mat_w[i] == 0 || t.mat_w[i] > 0xFFFFFFFFu) throw std::runtime_error("merkle_build: bad width");
+  }
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return t.mat_h[a] > t.mat_h[b]; });
+  size_t maxh = t.mat_h[order[0]];
+  merkle_alloc(ctx, t, maxh);
+  // group descriptors, sorted order
+  std::vector<MatRef> refs(nm);
+  for (size_t k = 0; k < nm; k++) refs[k] = MatRef{t.mat_d[order[k]], (uint32_t)t.mat_w[order[k]], 0};
+  DBuf<MatRef> drefs(ctx, nm);
+  ctx.h2d(drefs.p, refs.data(), nm * sizeof(MatRef));
+  size_t pos = 0;
+  auto take_group = [&](size_t height, size_t& first, u32& total_w, size_t& count) {
+    first = pos;
+    total_w = 0;
+    count = 0;
+    while (pos < nm && t.mat_h[order[pos]] == height) {
+      total_w += (u32)t.mat_w[order[pos]];
+      pos++;
+      count++;
+    }
+  };
+  size_t first, count;
+  u32 tw;
+  take_group(maxh, first, tw, count);
+  {
+    // descriptor list must end at the group's end: RowIter walks by widths, total_w bounds it
+    dim3 grid((unsigned)((maxh + 255) / 256));
+    hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
+    if (tw <= 128)
+      hipLaunchKernelGGL(leaf_hash_k<false>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.digests.p);
+    else
+      hipLaunchKernelGGL(leaf_hash_k<true>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.digests.p);
+    ctx.prof_end(K_LEAF_HASH, ev, double(maxh) * (8.0 * tw + 32.0));
+  }
+  for (size_t li = 1; li < t.layer_len.size(); li++) {
+    size_t n = t.layer_len[li];
+    take_group(n, first, tw, count);
+    const Digest* prev = t.digests.p + t.layer_off[li - 1];
+    Digest* next = t.digests.p + t.layer_off[li];
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
+    if (count == 0)
+      hipLaunchKernelGGL((compress_layer_k<false, false>), grid, dim3(256), 0, ctx.stream, prev, next, n, (const MatRef*)nullptr, 0u);
+    else if (tw <= 128)
+      hipLaunchKernelGGL((compress_layer_k<true, false>), grid, dim3(256), 0, ctx.stream, prev, next, n, drefs.p + first, tw);
+    else
+      hipLaunchKernelGGL((compress_layer_k<true, true>), grid, dim3(256), 0, ctx.stream, prev, next, n, drefs.p + first, tw);
+    ctx.prof_end(K_COMPRESS, ev, double(n) * (96.0 + 8.0 * tw));
+  }
+  if (pos != nm) throw std::runtime_error("merkle_build: matrix height not reached");
+  HIP_CHECK(hipGetLastError());
+}
+
+std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t) {
+  size_t cl = t.cap_layer();
+  std::vector<Digest> cap(t.layer_len[cl]);
+  ctx.d2h(cap.data(), t.digests.p + t.layer_off[cl], cap.size() * sizeof(Digest));
+  return cap;
+}
+
+Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords) {
+  size_t len = prefix_len + 8 * nwords;
+  size_t nchunks = len == 0 ? 1 : (len + 1023) / 1024;
+  DBuf<Digest> a(ctx, nchunks), b(ctx, (nchunks + 1) / 2);
+  hipLaunchKernelGGL(chunk_cv_k, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx.stream, d_prefix, prefix_len, d_words, len, nchunks, a.p);
+  Digest* cur = a.p;
+  Digest* nxt = b.p;
+  size_t n = nchunks;
+  while (n > 1) {
+    size_t nn = (n + 1) / 2;
+    hipLaunchKernelGGL(cv_level_k, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx.stream, cur, nxt, n,
+                       n == 2 ? (u32)B3_ROOT : 0u);
+    std::swap(cur, nxt);
+    n = nn;
+  }
+  HIP_CHECK(hipGetLastError());
+  Digest out;
+  ctx.d2h(&out, cur, sizeof(Digest));
+  return out;
+}
+
+}  // namespace msamd

@@ -1,0 +1,109 @@
+// Host side of the prover: Fiat-Shamir challenger, System / ProverKey / SystemWitness mirrors and prove().
+// Mirrors the reference's host orchestration (src/prover.rs:290-603, src/system.rs, src/types.rs) in C++ because
+// no Rust toolchain exists in this environment; all heavy steps are launches into the kernels of msamd.h.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "b3_dev.h"
+#include "msamd.h"
+#include "program.h"
+
+namespace msamd {
+
+// ---- BLAKE3 on the host (challenger, grinding)
+void blake3_host(const uint8_t* in, size_t len, uint8_t out[32]);
+
+// DeterministicPow<SerializingChallenger64<Goldilocks, HashChallenger<u8, Blake3, 32>>>, src/types.rs:28-81
+struct Challenger {
+  std::vector<uint8_t> input, output;
+  explicit Challenger(const std::vector<uint8_t>& seed) : input(seed) {}
+  void observe_bytes(const uint8_t* p, size_t n) {
+    output.clear();
+    input.insert(input.end(), p, p + n);
+  }
+  void observe(u64 v) {
+    uint8_t b[8];
+    for (int k = 0; k < 8; k++) b[k] = (uint8_t)(v >> (8 * k));
+    observe_bytes(b, 8);
+  }
+  void observe_ext(E2 e) {
+    observe(e.c0);
+    observe(e.c1);
+  }
+  void observe_cap(const std::vector<Digest>& cap) {
+    for (auto& d : cap) observe_bytes(d.b, 32);
+  }
+  // replace "hash(input_buffer)" by a digest computed elsewhere (device) for the pending flush
+  void flush_with(const Digest& d) {
+    input.assign(d.b, d.b + 32);
+    output.assign(d.b, d.b + 32);
+  }
+  uint8_t sample_byte();
+  u64 sample_u64();
+  u64 sample_base();
+  E2 sample_ext();
+  size_t sample_bits(unsigned bits);
+  u64 grind(unsigned bits);
+};
+
+struct Params {
+  u64 log_blowup = 1, cap_height = 0, log_final_poly_len = 0, max_log_arity = 1, num_queries = 1, commit_pow_bits = 0,
+      query_pow_bits = 0;
+};
+
+struct HCircuit {
+  std::vector<PNode> nodes;
+  std::vector<uint32_t> degrees, zeros;
+  std::vector<std::pair<uint32_t, std::vector<uint32_t>>> lookups;
+  size_t main_width = 0, pre_width = 0, pre_height = 0, num_lookups = 0, stage2_width = 0, constraint_count = 0,
+         max_constraint_degree = 0, args_width = 0, lookup_prefix_len = 0;
+  std::vector<u64> preprocessed;  // row-major
+  DProgram prog;
+  size_t quotient_degree() const {
+    size_t d = (max_constraint_degree > 2 ? max_constraint_degree : 2) - 1, q = 1;
+    while (q < d) q <<= 1;
+    return q;
+  }
+};
+
+// ProverData of one commitment: bit-reversed LDEs (column-major) + Merkle tree
+struct PcsData {
+  std::vector<DMat> ldes;
+  DTree tree;
+};
+
+struct HSystem {
+  Ctx* ctx = nullptr;
+  Params params;
+  std::vector<HCircuit> circuits;
+  bool has_pre = false;
+  std::vector<Digest> pre_commit;
+  std::vector<int> pre_indices;
+  PcsData pre_data;
+  std::vector<uint8_t> seed;
+};
+std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t len);
+
+struct HWitness {
+  HSystem* sys = nullptr;
+  std::vector<size_t> heights;
+  std::vector<DBuf<u64>> traces;  // row-major on device, as uploaded
+  std::vector<DLookups> lookups;
+  // claims: host copy (transcript for small inputs) and device copy
+  std::vector<u64> claim_offsets, claim_data;
+  DBuf<u64> d_claim_offsets, d_claim_data;
+};
+std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces, const u64* heights, const u64* const* mult,
+                                         const u64* const* args, size_t n_claims, const u64* claim_offsets,
+                                         const u64* claim_data);
+
+struct StageMs {
+  double v[6] = {0, 0, 0, 0, 0, 0};
+};
+std::vector<uint8_t> prove(HSystem& sys, HWitness& w, StageMs* times);
+
+void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out);
+void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out);
+
+}  // namespace msamd

@@ -1,0 +1,251 @@
+// logUp stage-2 trace construction and the claims accumulator on device.
+// Replaces LookupValues::stage_2_traces (/root/reference/src/lookup.rs:472-555: messages, batch inverse, the
+// serial running sum) and the serial claims loop of src/prover.rs:382-387. All sums are exact field sums, so a
+// parallel scan / tree reduction gives bit-identical values to the reference's serial loops.
+#include "msamd.h"
+
+namespace msamd {
+
+namespace {
+
+constexpr int INV_CHUNK = 8;  // Montgomery batch size per thread (one Ext2 inversion per chunk)
+
+// m = beta + sum_i args[i] gamma^i  (Horner over the reversed args, src/lookup.rs:375-384)
+__device__ __forceinline__ E2 message(const u64* __restrict__ a, u32 n, E2 beta, E2 gamma) {
+  E2 f = e2(0);
+  for (u32 k = n; k-- > 0;) {
+    f = e2_mul(f, gamma);
+    f.c0 = gl_add(f.c0, a[k]);
+  }
+  return e2_add(f, beta);
+}
+
+// Visit every lookup j of one row with its inverse message; F(j, inv_msg).
+template <class F>
+__device__ __forceinline__ void for_each_inverse(const u64* __restrict__ args_row, const u32* __restrict__ offs, u32 L, E2 beta,
+                                                 E2 gamma, F&& f) {
+  for (u32 j0 = 0; j0 < L; j0 += INV_CHUNK) {
+    E2 msg[INV_CHUNK], pre[INV_CHUNK];
+    E2 acc = e2(1);
+#pragma unroll
+    for (int t = 0; t < INV_CHUNK; t++) {
+      u32 j = j0 + t;
+      if (j < L) {
+        msg[t] = message(args_row + offs[j], offs[j + 1] - offs[j], beta, gamma);
+        pre[t] = acc;
+        acc = e2_mul(acc, msg[t]);
+      }
+    }
+    E2 inv = e2_inv(acc);
+#pragma unroll
+    for (int t = INV_CHUNK - 1; t >= 0; t--) {
+      u32 j = j0 + t;
+      if (j < L) {
+        E2 mi = e2_mul(inv, pre[t]);
+        inv = e2_mul(inv, msg[t]);
+        msg[t] = mi;  // now the inverse
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < INV_CHUNK; t++) {
+      u32 j = j0 + t;
+      if (j < L) f(j, msg[t]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void stage2_rowsum_k(const u64* __restrict__ mult, const u64* __restrict__ args,
+                                                       const u32* __restrict__ offs, size_t n, u32 L, u32 aw, E2 beta, E2 gamma,
+                                                       E2* __restrict__ rowsum) {
+  size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (r >= n) return;
+  E2 s = e2(0);
+  const u64* mrow = mult + r * L;
+  for_each_inverse(args + r * aw, offs, L, beta, gamma, [&](u32 j, E2 inv) { s = e2_add(s, e2_mul_base(inv, mrow[j])); });
+  rowsum[r] = s;
+}
+
+__global__ __launch_bounds__(256) void stage2_write_k(const u64* __restrict__ mult, const u64* __restrict__ args,
+                                                      const u32* __restrict__ offs, size_t n, unsigned logn, u32 L, u32 aw, E2 beta,
+                                                      E2 gamma, const E2* __restrict__ rowprefix, u64* __restrict__ out) {
+  size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (r >= n) return;
+  E2 run = rowprefix[r];
+  const u64* mrow = mult + r * L;
+  const size_t rr = bitrev64(r, logn);
+  for_each_inverse(args + r * aw, offs, L, beta, gamma, [&](u32 j, E2 inv) {
+    out[size_t(2 * j) * n + rr] = run.c0;
+    out[size_t(2 * j + 1) * n + rr] = run.c1;
+    run = e2_add(run, e2_mul_base(inv, mrow[j]));
+  });
+}
+
+// ---- exclusive scan of Ext2 values (field addition), three launches
+constexpr int SCAN_ITEMS = 4;
+__global__ __launch_bounds__(256) void scan_block_k(const E2* __restrict__ in, E2* __restrict__ out, size_t n, E2* __restrict__ block_tot) {
+  __shared__ E2 sh[256];
+  size_t base = (blockIdx.x * size_t(256) + threadIdx.x) * SCAN_ITEMS;
+  E2 v[SCAN_ITEMS];
+  E2 t = e2(0);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    v[k] = base + k < n ? in[base + k] : e2(0);
+    t = e2_add(t, v[k]);
+  }
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    E2 x = threadIdx.x >= d ? sh[threadIdx.x - d] : e2(0);
+    __syncthreads();
+    sh[threadIdx.x] = e2_add(sh[threadIdx.x], x);
+    __syncthreads();
+  }
+  E2 excl = threadIdx.x ? sh[threadIdx.x - 1] : e2(0);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (base + k < n) out[base + k] = excl;
+    excl = e2_add(excl, v[k]);
+  }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = sh[255];
+}
+// serial-over-tiles scan of the block totals by one workgroup; writes exclusive prefixes in place, total to *total
+__global__ __launch_bounds__(256) void scan_totals_k(E2* __restrict__ tot, size_t nb, E2* __restrict__ total) {
+  __shared__ E2 sh[256];
+  __shared__ E2 carry;
+  if (threadIdx.x == 0) carry = e2(0);
+  __syncthreads();
+  for (size_t base = 0; base < nb; base += 256) {
+    size_t i = base + threadIdx.x;
+    E2 v = i < nb ? tot[i] : e2(0);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      E2 x = threadIdx.x >= d ? sh[threadIdx.x - d] : e2(0);
+      __syncthreads();
+      sh[threadIdx.x] = e2_add(sh[threadIdx.x], x);
+      __syncthreads();
+    }
+    E2 c = carry;
+    if (i < nb) tot[i] = e2_add(c, e2_sub(sh[threadIdx.x], v));
+    __syncthreads();
+    if (threadIdx.x == 255) carry = e2_add(c, sh[255]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(256) void scan_add_k(E2* __restrict__ out, size_t n, const E2* __restrict__ block_prefix) {
+  size_t base = (blockIdx.x * size_t(256) + threadIdx.x) * SCAN_ITEMS;
+  E2 p = block_prefix[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++)
+    if (base + k < n) out[base + k] = e2_add(out[base + k], p);
+}
+
+__global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n, E2 beta,
+                                                    E2 gamma, E2* __restrict__ partial) {
+  __shared__ E2 sh[256];
+  size_t base = (blockIdx.x * size_t(256) + threadIdx.x) * INV_CHUNK;
+  E2 msg[INV_CHUNK], pre[INV_CHUNK];
+  E2 acc = e2(1), sum = e2(0);
+#pragma unroll
+  for (int t = 0; t < INV_CHUNK; t++) {
+    size_t i = base + t;
+    if (i < n) {
+      msg[t] = message(data + offs[i], (u32)(offs[i + 1] - offs[i]), beta, gamma);
+      pre[t] = acc;
+      acc = e2_mul(acc, msg[t]);
+    }
+  }
+  if (base < n) {
+    E2 inv = e2_inv(acc);
+#pragma unroll
+    for (int t = INV_CHUNK - 1; t >= 0; t--) {
+      size_t i = base + t;
+      if (i < n) {
+        sum = e2_add(sum, e2_mul(inv, pre[t]));
+        inv = e2_mul(inv, msg[t]);
+      }
+    }
+  }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) sh[threadIdx.x] = e2_add(sh[threadIdx.x], sh[threadIdx.x + d]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// words[0] = n; claim i: words[1 + i + offs[i]] = len_i, then its elements
+__global__ __launch_bounds__(256) void claims_words_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n,
+                                                      u64* __restrict__ words) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i == 0) words[0] = (u64)n;
+  if (i >= n) return;
+  u64 o = offs[i], len = offs[i + 1] - o;
+  u64* w = words + 1 + i + o;
+  w[0] = len;
+  for (u64 k = 0; k < len; k++) w[1 + k] = data[o + k];
+}
+
+}  // namespace
+
+static E2 scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n) {
+  size_t per = 256 * SCAN_ITEMS;
+  size_t nb = (n + per - 1) / per;
+  DBuf<E2> tot(ctx, nb + 1);
+  hipLaunchKernelGGL(scan_block_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, in, out, n, tot.p);
+  hipLaunchKernelGGL(scan_totals_k, dim3(1), dim3(256), 0, ctx.stream, tot.p, nb, tot.p + nb);
+  hipLaunchKernelGGL(scan_add_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, out, n, tot.p);
+  HIP_CHECK(hipGetLastError());
+  E2 total;
+  ctx.d2h(&total, tot.p + nb, sizeof(E2));
+  return total;
+}
+
+E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
+  size_t n = lk.height;
+  if (lk.num_lookups == 0) {
+    // pass-through accumulator column: zeros (src/lookup.rs:517-521)
+    HIP_CHECK(hipMemsetAsync(out, 0, n * 2 * sizeof(u64), ctx.stream));
+    return e2(0);
+  }
+  unsigned logn = log2_strict(n);
+  DBuf<E2> rowsum(ctx, n), prefix(ctx, n);
+  dim3 grid((unsigned)((n + 255) / 256));
+  u32 L = (u32)lk.num_lookups, aw = (u32)lk.args_width;
+  hipEvent_t ev = ctx.prof_begin(K_STAGE2);
+  hipLaunchKernelGGL(stage2_rowsum_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma,
+                     rowsum.p);
+  ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw));
+  E2 total = scan_exclusive(ctx, rowsum.p, prefix.p, n);
+  ev = ctx.prof_begin(K_STAGE2);
+  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, logn, L, aw, beta,
+                     gamma, prefix.p, out);
+  ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw + 2 * L));
+  HIP_CHECK(hipGetLastError());
+  return total;
+}
+
+E2 claims_accumulator(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, E2 beta, E2 gamma) {
+  if (n == 0) return e2(0);
+  size_t per = 256 * INV_CHUNK;
+  size_t nb = (n + per - 1) / per;
+  DBuf<E2> partial(ctx, nb);
+  hipLaunchKernelGGL(claims_acc_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, d_data, d_offs, n, beta, gamma, partial.p);
+  HIP_CHECK(hipGetLastError());
+  std::vector<E2> h(nb);
+  ctx.d2h(h.data(), partial.p, nb * sizeof(E2));
+  E2 s = e2(0);
+  for (auto& x : h) s = e2_add(s, x);
+  return s;
+}
+
+size_t claims_transcript_words(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, size_t total_elems, u64* d_words) {
+  size_t nwords = 1 + n + total_elems;
+  hipLaunchKernelGGL(claims_words_k, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, ctx.stream, d_data, d_offs, n, d_words);
+  HIP_CHECK(hipGetLastError());
+  return nwords;
+}
+
+}  // namespace msamd

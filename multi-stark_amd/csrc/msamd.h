@@ -1,0 +1,252 @@
+// Internal header of the MI355X prover library: device context, pooled device memory, kernel launchers.
+// Nothing here crosses the C ABI (include/mstark.h does).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gl_dev.h"
+
+namespace msamd {
+
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                               std::to_string(__LINE__));                                                 \
+  } while (0)
+
+static constexpr unsigned TW_LOG = 28;        // twiddle tables cover exponents of the order-2^28 root (LDE heights up to 2^28)
+static constexpr unsigned TW_HALF = 14;       // two-level split: W^e = T1[e >> 14] * T0[e & 16383]
+static constexpr unsigned NTT_MAX_LOG = 26;   // largest transform (trace height) supported
+
+struct Digest {
+  uint8_t b[32];
+};
+
+// kernel classes for which launch durations can be sampled with HIP events (bench.py roofline leg)
+enum KernelId : int {
+  K_NTT_STRIDED = 0,
+  K_NTT_CONTIG,
+  K_LEAF_HASH,
+  K_COMPRESS,
+  K_STAGE2,
+  K_QUOTIENT,
+  K_BARY,
+  K_DEEP,
+  K_FRI_FOLD,
+  K_TRANSPOSE,
+  K_OTHER,
+  K_COUNT
+};
+const char* kernel_name(int id);
+
+struct KernelStat {
+  uint64_t launches = 0;
+  double ms = 0;
+  double alg_bytes = 0;  // algorithmic bytes moved (each logical input read once, each output written once)
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  u64 *tw0 = nullptr, *tw1 = nullptr, *tw0i = nullptr, *tw1i = nullptr;
+  // pooled device memory: exact-size buckets, reused across proofs
+  std::multimap<size_t, void*> pool_free;
+  std::map<void*, size_t> pool_live;
+  size_t pool_bytes = 0;
+  // pinned staging for small D2H/H2D transfers
+  uint8_t* pinned = nullptr;
+  size_t pinned_cap = 0;
+  // LDE scale vectors (g w^k0)^j / n, per log_n and log_blowup
+  std::map<std::pair<unsigned, unsigned>, u64*> lde_scales;
+  // profiling
+  uint32_t prof_mask = 0;
+  struct Pending {
+    int id;
+    hipEvent_t a, b;
+    double bytes;
+  };
+  std::vector<Pending> prof_pending;
+  std::vector<hipEvent_t> event_pool;
+  KernelStat stats[K_COUNT];
+
+  explicit Ctx(int dev);
+  ~Ctx();
+  void* alloc(size_t bytes);
+  void release(void* p);
+  void trim();  // return pooled blocks to the driver
+  void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+  void h2d(void* dst, const void* src, size_t n);
+  void d2h(void* dst, const void* src, size_t n);  // synchronous (waits for the stream)
+  const u64* lde_scale(unsigned log_n, unsigned log_blowup);
+  // profiling hooks around one launch
+  bool prof_on(int id) const { return (prof_mask >> id) & 1u; }
+  hipEvent_t prof_begin(int id);
+  void prof_end(int id, hipEvent_t a, double bytes);
+  void prof_collect();
+};
+
+// RAII device buffer from the pool
+template <class T>
+struct DBuf {
+  Ctx* ctx = nullptr;
+  T* p = nullptr;
+  size_t n = 0;
+  DBuf() {}
+  DBuf(Ctx& c, size_t count) : ctx(&c), n(count) { p = count ? (T*)c.alloc(count * sizeof(T)) : nullptr; }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; }
+  DBuf& operator=(DBuf&& o) noexcept {
+    if (this != &o) {
+      reset();
+      ctx = o.ctx;
+      p = o.p;
+      n = o.n;
+      o.p = nullptr;
+    }
+    return *this;
+  }
+  void reset() {
+    if (p && ctx) ctx->release(p);
+    p = nullptr;
+  }
+  ~DBuf() { reset(); }
+};
+
+// column-major device matrix: element (r, c) at d[c * h + r]
+struct DMat {
+  DBuf<u64> buf;
+  size_t h = 0, w = 0;
+  u64* d() const { return buf.p; }
+};
+
+// ---------------------------------------------------------------- ntt.hip
+// In-place batched transforms over `ncols` contiguous columns of length 2^logn (column c at data + c * 2^logn).
+//   ntt_dif: natural-order input  -> bit-reversed-order output (storage row r holds frequency bitrev(r))
+//   ntt_dit: bit-reversed input   -> natural-order output
+// inverse = use w^-1 twiddles (no 1/n scaling unless out_mul is given). `src`/`scale` (optional) let the first
+// pass read from another buffer with a per-row factor: dst[c][r] <- transform(src[c_src][r] * scale[r]).
+struct NttSrc {
+  const u64* src = nullptr;      // column c read at src + (c / src_div) * 2^logn  (src_div copies per source column)
+  unsigned src_div = 1;
+  const u64* scale = nullptr;    // per destination column group: scale + (c % src_div) * 2^logn
+};
+void ntt_dif(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, const NttSrc* from = nullptr, u64 out_mul = 1);
+void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64 out_mul = 1);
+// row-major host layout (h x w) on device -> column-major, optionally with rows bit-reversed
+void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, bool bitrev_rows);
+void transpose_out(Ctx& ctx, const u64* colmajor, u64* rowmajor, size_t h, size_t w, bool bitrev_rows);
+// coefficients (unscaled inverse DFT output, natural order, column-major n x w) -> bit-reversed coset LDE (Bn x w)
+void lde_from_coeffs(Ctx& ctx, const u64* coef, u64* lde, unsigned logn, unsigned log_blowup, size_t w);
+// evaluations in bit-reversed row order (column-major n x w, destroyed) -> bit-reversed coset LDE (Bn x w)
+void coset_lde(Ctx& ctx, u64* evals_bitrev, u64* lde, unsigned logn, unsigned log_blowup, size_t w);
+// src/prover.rs:631-717 fused: quotient values in storage (bit-reversed) order, nq x D column-major (destroyed)
+// -> committed quotient LDE (B n x qD)
+void quotient_lde(Ctx& ctx, u64* qvals_bitrev, u64* lde, unsigned logn, unsigned logq, unsigned log_blowup, size_t D);
+
+// ---------------------------------------------------------------- hash.hip
+struct MatRef {
+  const u64* d;
+  uint32_t w;
+  uint32_t pad;
+};
+// Merkle tree over column-major matrices (heights powers of two), p3 MerkleTreeMmcs semantics
+struct DTree {
+  std::vector<const u64*> mat_d;   // matrices in input order (not owned)
+  std::vector<size_t> mat_h, mat_w;
+  DBuf<Digest> digests;            // all layers back to back, leaf layer first
+  std::vector<size_t> layer_off, layer_len;
+  unsigned cap_height = 0;
+  size_t max_height() const { return layer_len.empty() ? 0 : layer_len[0]; }
+  size_t cap_layer() const {
+    size_t L = layer_len.size();
+    size_t ch = cap_height < L - 1 ? cap_height : L - 1;
+    return L - 1 - ch;
+  }
+};
+void merkle_build(Ctx& ctx, DTree& t);                     // fills digests for t.mat_* (already set)
+void merkle_alloc(Ctx& ctx, DTree& t, size_t max_height);  // layer table + digest storage only
+void merkle_compress_plain(Ctx& ctx, DTree& t);            // layers 1.. from a filled leaf layer, no injection
+std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t);  // D2H of the cap layer (synchronises)
+// BLAKE3 of the byte stream prefix (prefix_len bytes) || nwords little-endian u64 words; result to host
+Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords);
+
+// ---------------------------------------------------------------- lookup.hip
+// device-resident LookupValues of one circuit (row-major as the reference stores them)
+struct DLookups {
+  size_t height = 0, num_lookups = 0, args_width = 0;
+  DBuf<u64> mult, args;
+  DBuf<uint32_t> arg_offsets;  // num_lookups + 1
+};
+// stage-2 trace of one circuit: writes column-major (n x max(L,1)*2) with rows bit-reversed (ready for the
+// inverse DIT); returns the circuit's total contribution sum_{r,j} mult/msg
+E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev);
+E2 claims_accumulator(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma);
+// the claims part of the transcript as u64 words: count, then per claim its length and elements
+// (src/prover.rs:369-373); d_words must hold 1 + n_claims + total_elems words; returns that count
+size_t claims_transcript_words(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims,
+                               size_t total_elems, u64* d_words);
+
+// ---------------------------------------------------------------- quotient.hip
+struct DProgram {
+  // register-allocated straight-line program for one circuit (see quotient.hip)
+  DBuf<uint32_t> code;      // 4 words per instruction
+  DBuf<u64> consts;
+  size_t n_instr = 0, n_slots = 0;
+  DBuf<uint32_t> zero_slots;     // slot of each user constraint root
+  DBuf<uint32_t> lookup_slots;   // per lookup: mult slot, nargs, arg slots...
+  size_t n_zeros = 0, n_lookups = 0, constraint_count = 0;
+  size_t main_w = 0, pre_w = 0, s2_w = 0;
+};
+struct QuotientArgs {
+  const u64 *pre = nullptr, *s1 = nullptr, *s2 = nullptr;  // column-major LDEs (bit-reversed rows)
+  size_t pre_h = 0, s1_h = 0, s2_h = 0;                    // LDE heights (column strides)
+  unsigned log_n = 0, log_q = 0;
+  u64 publics[8];
+  E2 alpha;
+};
+// writes quotient values in storage order: out[c * nq + t] for c in {0,1}
+void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* out);
+
+// ---------------------------------------------------------------- open.hip
+// 1/(z - x_i) for i < H over the bit-reversed coset x_i = 7 w_H^{bitrev(i)}; out: E2[H] (AoS)
+void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out);
+// opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i]
+void bary_eval(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* invden0, const E2* invden1,
+               E2 z0, E2 z1, int npoints, E2* out_host /* npoints * w */);
+struct DeepMat {
+  const u64* d;       // column-major LDE
+  uint32_t w;
+  uint32_t npoints;
+  E2 coeff[2];        // alpha^{offset_p}
+  E2 red_z[2];        // sum_c alpha^c y_p[c]
+  uint32_t inv_idx[2];  // which inverse-denominator vector each point uses
+  uint32_t pad[2];
+};
+// ro[i] += sum over matrices/points of coeff_p * (red_z_p - sum_c alpha^c m[i][c]) * invden_{idx_p}[i]
+void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, size_t height, const E2* alpha_pows_dev, size_t n_alpha,
+                 const E2* const* invden_dev /* device array of pointers */, E2* ro, bool accumulate);
+// FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
+void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out);
+// Merkle tree of one FRI layer: leaf i = BLAKE3 of the 32-byte row (cur[2i], cur[2i+1]) (ExtensionMmcs flattening)
+void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows);
+// gather: rows of column-major matrices and digest siblings for the query phase
+struct GatherReq {
+  const void* base;   // matrix (u64) or digest layer
+  uint64_t stride;    // column stride (elements) for matrices
+  uint64_t index;     // row index / digest index
+  uint32_t count;     // number of columns (matrices) or 1 (digests)
+  uint32_t kind;      // 0 = matrix row (u64 x count), 1 = digest (32 bytes)
+  uint64_t out_off;   // byte offset in the output buffer
+};
+void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes);
+
+}  // namespace msamd

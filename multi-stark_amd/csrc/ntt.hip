@@ -1,0 +1,330 @@
+// Batched radix-2 Goldilocks NTT / coset LDE for gfx950.
+// Replaces p3 Radix2DitParallel::dft_batch and the coset_lde_batch inside TwoAdicFriPcs::commit as reached from
+// /root/reference/src/prover.rs:350,419,650,716 and src/system.rs:193.
+//
+// Layout: column-major (one polynomial = one contiguous column); committed LDEs keep the reference's
+// bit-reversed row order (src/prover.rs:685-692) so no permutation pass is ever run:
+//   * ntt_dif = in-place Gentleman-Sande: natural in -> bit-reversed out
+//   * ntt_dit = in-place Cooley-Tukey:   bit-reversed in -> natural out
+// A size-2^L transform is a recursive four-step: strided passes of <= 8 bits over LDS tiles of 4096 elements
+// (tile = M sub-transform points x T consecutive columns of the implicit M x S matrix, so every global access is
+// a run of T*8 >= 128 contiguous bytes), an inter-pass twiddle w_B^{l * bitrev(h)} from a two-level table, and a
+// final contiguous pass of <= 11 bits. The coset LDE is B independent size-n transforms of the coefficient
+// vector scaled by (g w_N^k0)^j / n (the first log2(B) stages of the zero-padded size-Bn transform are trivial),
+// with the scaling fused into the first pass' loads.
+#include "msamd.h"
+
+namespace msamd {
+
+namespace {
+
+__device__ __forceinline__ u64 tw_lookup(const u64* __restrict__ t0, const u64* __restrict__ t1, u32 e26) {
+  return gl_mul(t1[e26 >> TW_HALF], t0[e26 & ((1u << TW_HALF) - 1)]);
+}
+
+// radix-2 stages over `k` bits of an LDS array whose transform axis has stride `T` (T = 1 for contiguous)
+template <int DIT>
+__device__ __forceinline__ void lds_stages(u64* sm, unsigned k, unsigned logT, const u64* __restrict__ t1) {
+  if (k == 0) return;
+  const unsigned T = 1u << logT;
+  const unsigned nb = (1u << (k - 1)) << logT;  // butterflies
+  for (unsigned s = 0; s < k; s++) {
+    const unsigned loghalf = DIT ? s : (k - 1 - s);
+    const unsigned half = 1u << loghalf;
+    // twiddle w_{2 half}^j = W^(j << (26 - loghalf - 1)) = T1[j << (13 - loghalf - 1)]
+    const unsigned tsh = TW_HALF - loghalf - 1;
+    for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) {
+      unsigned l = b & (T - 1), bb = b >> logT;
+      unsigned j = bb & (half - 1), grp = bb >> loghalf;
+      unsigned i0 = (((grp << (loghalf + 1)) + j) << logT) + l;
+      unsigned i1 = i0 + (half << logT);
+      u64 w = t1[j << tsh];
+      u64 x = sm[i0], y = sm[i1];
+      if (DIT) {
+        u64 t = gl_mul(w, y);
+        sm[i0] = gl_add(x, t);
+        sm[i1] = gl_sub(x, t);
+      } else {
+        sm[i0] = gl_add(x, y);
+        sm[i1] = gl_mul(gl_sub(x, y), w);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int DIT>
+__global__ __launch_bounds__(256) void ntt_contig_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned K,
+                                                     unsigned logn, const u64* __restrict__ t1, unsigned src_div,
+                                                     const u64* __restrict__ scale, u64 out_mul) {
+  extern __shared__ u64 sm[];
+  const size_t n = size_t(1) << logn;
+  const size_t col = blockIdx.y, off = size_t(blockIdx.x) << K;
+  const u64* s = src + (col / src_div) * n + off;
+  const u64* sc = scale ? scale + (col % src_div) * n + off : nullptr;
+  u64* d = dst + col * n + off;
+  const unsigned m = 1u << K;
+  for (unsigned i = threadIdx.x; i < m; i += blockDim.x) {
+    u64 v = s[i];
+    if (sc) v = gl_mul(v, sc[i]);
+    sm[i] = v;
+  }
+  __syncthreads();
+  lds_stages<DIT>(sm, K, 0, t1);
+  for (unsigned i = threadIdx.x; i < m; i += blockDim.x) {
+    u64 v = sm[i];
+    if (out_mul != 1) v = gl_mul(v, out_mul);
+    d[i] = v;
+  }
+}
+
+template <int DIT>
+__global__ __launch_bounds__(256) void ntt_strided_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned k,
+                                                      unsigned logS, unsigned logT, unsigned logn,
+                                                      const u64* __restrict__ t0, const u64* __restrict__ t1,
+                                                      unsigned src_div, const u64* __restrict__ scale, u64 out_mul) {
+  extern __shared__ u64 sm[];
+  const size_t n = size_t(1) << logn;
+  const unsigned logB = k + logS;
+  const unsigned tiles = 1u << (logS - logT);
+  const size_t col = blockIdx.y;
+  const unsigned tile = blockIdx.x & (tiles - 1);
+  const size_t blk = blockIdx.x >> (logS - logT);
+  const u32 l0 = tile << logT;
+  const size_t base = blk << logB;
+  const u64* s = src + (col / src_div) * n + base;
+  const u64* sc = scale ? scale + (col % src_div) * n + base : nullptr;
+  u64* d = dst + col * n + base;
+  const unsigned total = 1u << (k + logT);
+  const unsigned T = 1u << logT;
+  const unsigned esh = TW_LOG - logB;
+  for (unsigned idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    unsigned h = idx >> logT, l = idx & (T - 1);
+    size_t pos = (size_t(h) << logS) + l0 + l;
+    u64 v = s[pos];
+    if (sc) v = gl_mul(v, sc[pos]);
+    if (DIT) {
+      u32 e = (l0 + l) * bitrev32(h, k);
+      v = gl_mul(v, tw_lookup(t0, t1, e << esh));
+    }
+    sm[idx] = v;
+  }
+  __syncthreads();
+  lds_stages<DIT>(sm, k, logT, t1);
+  for (unsigned idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    unsigned h = idx >> logT, l = idx & (T - 1);
+    size_t pos = (size_t(h) << logS) + l0 + l;
+    u64 v = sm[idx];
+    if (!DIT) {
+      u32 e = (l0 + l) * bitrev32(h, k);
+      v = gl_mul(v, tw_lookup(t0, t1, e << esh));
+    }
+    if (out_mul != 1) v = gl_mul(v, out_mul);
+    d[pos] = v;
+  }
+}
+
+struct Plan {
+  unsigned K;
+  std::vector<unsigned> bits;  // strided passes, top first
+};
+Plan make_plan(unsigned logn) {
+  Plan p;
+  p.K = logn < 11 ? logn : 11;
+  unsigned R = logn - p.K;
+  unsigned m = (R + 7) / 8;
+  for (unsigned i = 0; i < m; i++) p.bits.push_back(R / m + (i < R % m ? 1 : 0));
+  return p;
+}
+
+template <int DIT>
+void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned logB, unsigned logn, size_t ncols,
+                    bool inverse, unsigned src_div, const u64* scale, u64 out_mul) {
+  unsigned logS = logB - k;
+  unsigned logT = 12 - k;
+  if (logT > logS) logT = logS;
+  size_t gx = (size_t(1) << (logS - logT)) << (logn - logB);
+  dim3 grid((unsigned)gx, (unsigned)ncols);
+  size_t shmem = (size_t(8) << (k + logT));
+  hipEvent_t ev = ctx.prof_begin(K_NTT_STRIDED);
+  hipLaunchKernelGGL(ntt_strided_k<DIT>, grid, dim3(256), shmem, ctx.stream, src, dst, k, logS, logT, logn,
+                     inverse ? ctx.tw0i : ctx.tw0, inverse ? ctx.tw1i : ctx.tw1, src_div, scale, out_mul);
+  ctx.prof_end(K_NTT_STRIDED, ev, 16.0 * double(ncols) * double(size_t(1) << logn));
+}
+
+template <int DIT>
+void launch_contig(Ctx& ctx, const u64* src, u64* dst, unsigned K, unsigned logn, size_t ncols, bool inverse,
+                   unsigned src_div, const u64* scale, u64 out_mul) {
+  dim3 grid((unsigned)(size_t(1) << (logn - K)), (unsigned)ncols);
+  unsigned threads = K >= 9 ? 256 : 64;
+  hipEvent_t ev = ctx.prof_begin(K_NTT_CONTIG);
+  hipLaunchKernelGGL(ntt_contig_k<DIT>, grid, dim3(threads), size_t(8) << K, ctx.stream, src, dst, K, logn,
+                     inverse ? ctx.tw1i : ctx.tw1, src_div, scale, out_mul);
+  ctx.prof_end(K_NTT_CONTIG, ev, 16.0 * double(ncols) * double(size_t(1) << logn));
+}
+
+void check_dims(unsigned logn, size_t ncols) {
+  if (logn > NTT_MAX_LOG) throw std::runtime_error("ntt: transform larger than 2^26 is not supported");
+  if (ncols > 65535) throw std::runtime_error("ntt: more than 65535 columns in one batch");
+}
+
+// scale[b][j] = (g * w_N^{bitrev_B(b)})^j / n
+__global__ void lde_scale_k(u64* out, unsigned logn, unsigned lb) {
+  size_t n = size_t(1) << logn;
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= (n << lb)) return;
+  size_t b = i >> logn, j = i & (n - 1);
+  u64 wN = gl_two_adic_generator(logn + lb);
+  u64 s = gl_mul(GL_GEN, gl_pow(wN, bitrev32((u32)b, lb)));
+  u64 ninv = gl_inv((u64)n);
+  out[i] = gl_mul(gl_pow(s, j), ninv);
+}
+
+__global__ void transpose_in_k(const u64* __restrict__ in, u64* __restrict__ out, size_t h, size_t w, unsigned logh,
+                               int bitrev_rows) {
+  // block: 64 output rows rr0.. x all columns, staged through LDS in chunks of 64 columns
+  __shared__ u64 tile[64][65];
+  const size_t rr0 = size_t(blockIdx.x) * 64;
+  const unsigned rows = (unsigned)((h - rr0) < 64 ? (h - rr0) : 64);
+  for (size_t c0 = 0; c0 < w; c0 += 64) {
+    unsigned cols = (unsigned)((w - c0) < 64 ? (w - c0) : 64);
+    for (unsigned idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) {
+      unsigned rr = idx / cols, c = idx % cols;
+      size_t r = bitrev_rows ? bitrev64(rr0 + rr, logh) : (rr0 + rr);
+      tile[rr][c] = in[r * w + c0 + c];
+    }
+    __syncthreads();
+    for (unsigned idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) {
+      unsigned c = idx / rows, rr = idx % rows;
+      out[(c0 + c) * h + rr0 + rr] = tile[rr][c];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void transpose_out_k(const u64* __restrict__ in, u64* __restrict__ out, size_t h, size_t w, unsigned logh,
+                                int bitrev_rows) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= h * w) return;
+  size_t r = i / w, c = i % w;
+  size_t rs = bitrev_rows ? bitrev64(r, logh) : r;
+  out[i] = in[c * h + rs];
+}
+
+// quotient: DFT output S (natural order, nq x D) -> per coset block b, slice k: pre-scaled coefficients
+//   lde[(k*D + c) * Bn + b*n + r] = S[c][(N - (k n + r)) mod N] * w_k * w_{Bn}^{bitrev_B(b) * r}
+__global__ void quotient_slice_k(const u64* __restrict__ S, u64* __restrict__ lde, unsigned logn, unsigned logq,
+                                 unsigned lb, unsigned D, const u64* __restrict__ t0, const u64* __restrict__ t1,
+                                 const u64* __restrict__ wk /* q weights */) {
+  const size_t n = size_t(1) << logn, N = n << logq, Bn = n << lb;
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // over r + n*(b + B*k)
+  if (i >= (n << (lb + logq))) return;
+  size_t r = i & (n - 1);
+  unsigned b = (unsigned)((i >> logn) & ((1u << lb) - 1));
+  unsigned k = (unsigned)(i >> (logn + lb));
+  size_t j = (size_t(k) << logn) + r;
+  size_t srcrow = (N - j) & (N - 1);
+  u32 k0 = bitrev32(b, lb);
+  // w_{Bn}^{k0 r}: exponent modulo Bn, scaled to the order-2^26 table
+  u64 e = (u64(k0) * r) & (Bn - 1);
+  u64 f = gl_mul(wk[k], tw_lookup(t0, t1, (u32)(e << (TW_LOG - logn - lb))));
+  for (unsigned c = 0; c < D; c++) lde[(size_t(k) * D + c) * Bn + (size_t(b) << logn) + r] = gl_mul(S[c * N + srcrow], f);
+}
+
+}  // namespace
+
+void ntt_dif(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, const NttSrc* from, u64 out_mul) {
+  check_dims(logn, ncols);
+  if (ncols == 0) return;
+  Plan p = make_plan(logn);
+  const u64* src = from && from->src ? from->src : data;
+  unsigned src_div = from ? from->src_div : 1;
+  const u64* scale = from ? from->scale : nullptr;
+  unsigned logB = logn;
+  for (size_t i = 0; i < p.bits.size(); i++) {
+    launch_strided<0>(ctx, src, data, p.bits[i], logB, logn, ncols, inverse, src_div, scale, 1);
+    src = data;
+    src_div = 1;
+    scale = nullptr;
+    logB -= p.bits[i];
+  }
+  launch_contig<0>(ctx, src, data, p.K, logn, ncols, inverse, src_div, scale, out_mul);
+}
+
+void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64 out_mul) {
+  check_dims(logn, ncols);
+  if (ncols == 0) return;
+  Plan p = make_plan(logn);
+  launch_contig<1>(ctx, data, data, p.K, logn, ncols, inverse, 1, nullptr, p.bits.empty() ? out_mul : 1);
+  unsigned logB = p.K;
+  for (size_t i = p.bits.size(); i-- > 0;) {
+    logB += p.bits[i];
+    launch_strided<1>(ctx, data, data, p.bits[i], logB, logn, ncols, inverse, 1, nullptr, i == 0 ? out_mul : 1);
+  }
+}
+
+const u64* Ctx::lde_scale(unsigned log_n, unsigned log_blowup) {
+  auto key = std::make_pair(log_n, log_blowup);
+  auto it = lde_scales.find(key);
+  if (it != lde_scales.end()) return it->second;
+  size_t cnt = size_t(1) << (log_n + log_blowup);
+  u64* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, cnt * 8));
+  hipLaunchKernelGGL(lde_scale_k, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, p, log_n, log_blowup);
+  HIP_CHECK(hipGetLastError());
+  lde_scales[key] = p;
+  return p;
+}
+
+void lde_from_coeffs(Ctx& ctx, const u64* coef, u64* lde, unsigned logn, unsigned log_blowup, size_t w) {
+  NttSrc from;
+  from.src = coef;
+  from.src_div = 1u << log_blowup;
+  from.scale = ctx.lde_scale(logn, log_blowup);
+  ntt_dif(ctx, lde, logn, w << log_blowup, false, &from, 1);
+}
+
+void coset_lde(Ctx& ctx, u64* evals_bitrev, u64* lde, unsigned logn, unsigned log_blowup, size_t w) {
+  ntt_dit(ctx, evals_bitrev, logn, w, true, 1);  // unscaled inverse DFT: n * coefficients, natural order
+  lde_from_coeffs(ctx, evals_bitrev, lde, logn, log_blowup, w);
+}
+
+void quotient_lde(Ctx& ctx, u64* qvals_bitrev, u64* lde, unsigned logn, unsigned logq, unsigned log_blowup, size_t D) {
+  // forward DFT of the quotient evaluations (bit-reversed in -> natural out), src/prover.rs:650
+  unsigned logN = logn + logq;
+  ntt_dit(ctx, qvals_bitrev, logN, D, false, 1);
+  size_t q = size_t(1) << logq, n = size_t(1) << logn;
+  // w_k = N^-1 * GENERATOR^(-k n), src/prover.rs:651-657
+  std::vector<u64> wk(q);
+  u64 n_inv = gl_inv((u64)(n << logq));
+  u64 step = gl_inv(gl_pow(GL_GEN, (u64)n)), cur = 1;
+  for (size_t k = 0; k < q; k++) {
+    wk[k] = gl_mul(cur, n_inv);
+    cur = gl_mul(cur, step);
+  }
+  DBuf<u64> dwk(ctx, q);
+  ctx.h2d(dwk.p, wk.data(), q * 8);
+  size_t total = n << (log_blowup + logq);
+  hipLaunchKernelGGL(quotient_slice_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx.stream, qvals_bitrev, lde,
+                     logn, logq, log_blowup, (unsigned)D, ctx.tw0, ctx.tw1, dwk.p);
+  HIP_CHECK(hipGetLastError());
+  // B independent size-n transforms per output column (q*D columns), src/prover.rs:716
+  ntt_dif(ctx, lde, logn, (q * D) << log_blowup, false, nullptr, 1);
+}
+
+void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, bool bitrev_rows) {
+  if (h * w == 0) return;
+  hipEvent_t ev = ctx.prof_begin(K_TRANSPOSE);
+  hipLaunchKernelGGL(transpose_in_k, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w,
+                     log2_strict(h), bitrev_rows ? 1 : 0);
+  ctx.prof_end(K_TRANSPOSE, ev, 16.0 * double(h) * double(w));
+}
+
+void transpose_out(Ctx& ctx, const u64* colmajor, u64* rowmajor, size_t h, size_t w, bool bitrev_rows) {
+  if (h * w == 0) return;
+  hipLaunchKernelGGL(transpose_out_k, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, ctx.stream, colmajor, rowmajor, h,
+                     w, log2_strict(h), bitrev_rows ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace msamd

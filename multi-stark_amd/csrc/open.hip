@@ -1,0 +1,285 @@
+// PCS opening on device: inverse denominators, barycentric evaluation, DEEP reduced openings, FRI folding,
+// FRI leaf hashing and the query-phase gathers.
+// Replaces the device-side work of p3 TwoAdicFriPcs::open as called from /root/reference/src/prover.rs:580
+// (rounds built at :540-579): interpolate_coset, the reduced-opening pass, prover::commit_phase fold_matrix,
+// and mmcs.open_batch for the queries. The transcript itself stays on the host (prover.hip).
+#include "b3_dev.h"
+#include "msamd.h"
+
+namespace msamd {
+
+namespace {
+
+__device__ __forceinline__ u64 coset_point(const u64* __restrict__ t0, const u64* __restrict__ t1, u32 i, unsigned log_h) {
+  // x_i = 7 * w_H^{bitrev(i)}
+  u32 e = bitrev32(i, log_h) << (TW_LOG - log_h);
+  return gl_mul_small(gl_mul(t1[e >> TW_HALF], t0[e & ((1u << TW_HALF) - 1)]), 7);
+}
+
+constexpr int DEN_CHUNK = 8;
+__global__ __launch_bounds__(256) void inv_denoms_k(E2 z, unsigned log_h, const u64* __restrict__ t0, const u64* __restrict__ t1,
+                                                    E2* __restrict__ out) {
+  const size_t H = size_t(1) << log_h;
+  size_t base = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * DEN_CHUNK;
+  if (base >= H) return;
+  E2 d[DEN_CHUNK], pre[DEN_CHUNK];
+  E2 acc = e2(1);
+#pragma unroll
+  for (int k = 0; k < DEN_CHUNK; k++) {
+    if (base + k < H) {
+      d[k] = e2(gl_sub(z.c0, coset_point(t0, t1, (u32)(base + k), log_h)), z.c1);
+      pre[k] = acc;
+      acc = e2_mul(acc, d[k]);
+    }
+  }
+  E2 inv = e2_inv(acc);
+#pragma unroll
+  for (int k = DEN_CHUNK - 1; k >= 0; k--) {
+    if (base + k < H) {
+      out[base + k] = e2_mul(inv, pre[k]);
+      inv = e2_mul(inv, d[k]);
+    }
+  }
+}
+
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    u64 o = (u64)__shfl_xor((unsigned long long)v, m, 64);
+    v = gl_add(v, o);
+  }
+  return v;
+}
+
+constexpr int BARY_ROWS = 8;  // rows per thread
+// partial[(blk * w + c) * np + p] = sum over the block's rows of col_c[i] * x_i * invden_p[i]
+template <int NP>
+__global__ __launch_bounds__(256) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
+                                                      const E2* __restrict__ den0, const E2* __restrict__ den1,
+                                                      const u64* __restrict__ t0, const u64* __restrict__ t1, E2* __restrict__ partial) {
+  __shared__ u64 sh[4][NP * 2];
+  const size_t h = size_t(1) << log_h;
+  const size_t base = blockIdx.x * size_t(256 * BARY_ROWS);
+  E2 cs[BARY_ROWS][NP];
+#pragma unroll
+  for (int k = 0; k < BARY_ROWS; k++) {
+    size_t i = base + size_t(k) * 256 + threadIdx.x;
+    if (i < h) {
+      u64 x = coset_point(t0, t1, (u32)i, log_h);
+      cs[k][0] = e2_mul_base(den0[i], x);
+      if (NP == 2) cs[k][1] = e2_mul_base(den1[i], x);
+    } else {
+      cs[k][0] = e2(0);
+      if (NP == 2) cs[k][1] = e2(0);
+    }
+  }
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (u32 c = 0; c < w; c++) {
+    const u64* col = mat + size_t(c) * mat_h;
+    u64 a[NP * 2];
+#pragma unroll
+    for (int j = 0; j < NP * 2; j++) a[j] = 0;
+#pragma unroll
+    for (int k = 0; k < BARY_ROWS; k++) {
+      size_t i = base + size_t(k) * 256 + threadIdx.x;
+      u64 v = i < h ? col[i] : 0;
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        a[2 * p] = gl_add(a[2 * p], gl_mul(cs[k][p].c0, v));
+        a[2 * p + 1] = gl_add(a[2 * p + 1], gl_mul(cs[k][p].c1, v));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NP * 2; j++) a[j] = wave_sum(a[j]);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NP * 2; j++) sh[wave][j] = a[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < NP * 2) {
+      u64 s = gl_add(gl_add(sh[0][threadIdx.x], sh[1][threadIdx.x]), gl_add(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+      u64* dst = reinterpret_cast<u64*>(partial + (size_t(blockIdx.x) * w + c) * NP);
+      dst[threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ void bary_final_k(const E2* __restrict__ partial, size_t nblk, u32 w, int np, E2* __restrict__ out) {
+  size_t id = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // over c * np + p
+  if (id >= size_t(w) * np) return;
+  E2 s = e2(0);
+  for (size_t b = 0; b < nblk; b++) s = e2_add(s, partial[b * w * np + id]);
+  out[id] = s;
+}
+
+struct DeepParams {
+  const DeepMat* mats;
+  u32 nmats;
+  const E2* apow;
+  const E2* const* den;
+  E2* ro;
+  size_t height;
+  int accumulate;
+};
+__global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= p.height) return;
+  E2 acc = p.accumulate ? p.ro[i] : e2(0);
+  for (u32 m = 0; m < p.nmats; m++) {
+    const DeepMat dm = p.mats[m];
+    u64 s0 = 0, s1 = 0;
+    for (u32 c = 0; c < dm.w; c++) {
+      u64 v = dm.d[size_t(c) * p.height + i];
+      E2 a = p.apow[c];
+      s0 = gl_add(s0, gl_mul(a.c0, v));
+      s1 = gl_add(s1, gl_mul(a.c1, v));
+    }
+    for (u32 q = 0; q < dm.npoints; q++) {
+      E2 diff = e2(gl_sub(dm.red_z[q].c0, s0), gl_sub(dm.red_z[q].c1, s1));
+      E2 t = e2_mul(e2_mul(dm.coeff[q], diff), p.den[dm.inv_idx[q]][i]);
+      acc = e2_add(acc, t);
+    }
+  }
+  p.ro[i] = acc;
+}
+
+// out[i] = (1/2 + pw) lo + (1/2 - pw) hi, pw = (beta/2) w_{2R}^{-bitrev(i)}; optional roll-in out[i] += f * in[i]
+__global__ __launch_bounds__(256) void fri_fold_k(const E2* __restrict__ cur, size_t rows, unsigned log_rows, E2 half_beta, u64 half,
+                                                  const E2* __restrict__ roll, E2 roll_f, const u64* __restrict__ t0i,
+                                                  const u64* __restrict__ t1i, E2* __restrict__ out) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= rows) return;
+  u32 e = bitrev32((u32)i, log_rows) << (TW_LOG - log_rows - 1);
+  u64 gp = gl_mul(t1i[e >> TW_HALF], t0i[e & ((1u << TW_HALF) - 1)]);
+  E2 pw = e2_mul_base(half_beta, gp);
+  E2 lo = cur[2 * i], hi = cur[2 * i + 1];
+  E2 r = e2_add(e2_mul(e2(gl_add(half, pw.c0), pw.c1), lo), e2_mul(e2(gl_sub(half, pw.c0), gl_neg(pw.c1)), hi));
+  if (roll) r = e2_add(r, e2_mul(roll_f, roll[i]));
+  out[i] = r;
+}
+
+// leaf digest of FRI row i = BLAKE3 of the 32 bytes (lo.c0, lo.c1, hi.c0, hi.c1) (ExtensionMmcs flattening)
+__global__ __launch_bounds__(256) void fri_leaf_hash_k(const E2* __restrict__ cur, size_t rows, Digest* __restrict__ out) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= rows) return;
+  E2 lo = cur[2 * i], hi = cur[2 * i + 1];
+  u32 m[16];
+  m[0] = (u32)lo.c0;
+  m[1] = (u32)(lo.c0 >> 32);
+  m[2] = (u32)lo.c1;
+  m[3] = (u32)(lo.c1 >> 32);
+  m[4] = (u32)hi.c0;
+  m[5] = (u32)(hi.c0 >> 32);
+  m[6] = (u32)hi.c1;
+  m[7] = (u32)(hi.c1 >> 32);
+#pragma unroll
+  for (int k = 8; k < 16; k++) m[k] = 0;
+  u32 cv[8];
+  b3_iv(cv);
+  b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+  uint4* q = reinterpret_cast<uint4*>(out + i);
+  q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+  q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+__global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* __restrict__ out) {
+  size_t r = blockIdx.x;
+  if (r >= n) return;
+  const GatherReq q = reqs[r];
+  if (q.kind == 0) {
+    const u64* m = (const u64*)q.base;
+    u64* o = (u64*)(out + q.out_off);
+    for (u32 c = threadIdx.x; c < q.count; c += blockDim.x) o[c] = m[size_t(c) * q.stride + q.index];
+  } else {
+    const u32* d = (const u32*)((const Digest*)q.base + q.index);
+    u32* o = (u32*)(out + q.out_off);
+    for (u32 c = threadIdx.x; c < 8 * q.count; c += blockDim.x) o[c] = d[c];
+  }
+}
+
+}  // namespace
+
+void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out) {
+  if (log_h > TW_LOG) throw std::runtime_error("LDE height above 2^28 is not supported");
+  size_t H = size_t(1) << log_h;
+  size_t threads = (H + DEN_CHUNK - 1) / DEN_CHUNK;
+  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, z, log_h, ctx.tw0, ctx.tw1, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+void bary_eval(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* den0, const E2* den1, E2 z0, E2 z1,
+               int npoints, E2* out_host) {
+  if (npoints == 0) return;
+  size_t h = size_t(1) << log_h;
+  size_t nblk = (h + 256 * BARY_ROWS - 1) / (256 * BARY_ROWS);
+  DBuf<E2> partial(ctx, nblk * w * npoints), fin(ctx, w * npoints);
+  hipEvent_t ev = ctx.prof_begin(K_BARY);
+  if (npoints == 1)
+    hipLaunchKernelGGL(bary_partial_k<1>, dim3((unsigned)nblk), dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, den0, den0, ctx.tw0,
+                       ctx.tw1, partial.p);
+  else
+    hipLaunchKernelGGL(bary_partial_k<2>, dim3((unsigned)nblk), dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, den0, den1, ctx.tw0,
+                       ctx.tw1, partial.p);
+  ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
+  size_t tot = w * npoints;
+  hipLaunchKernelGGL(bary_final_k, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, fin.p);
+  HIP_CHECK(hipGetLastError());
+  std::vector<E2> sums(tot);
+  ctx.d2h(sums.data(), fin.p, tot * sizeof(E2));
+  // y = sum * (z^h - s^h) / (h s^h), s = GENERATOR (p3 interpolate_coset)
+  u64 s_pow = gl_exp_pow2(GL_GEN, log_h);
+  u64 dinv = gl_inv(gl_mul(s_pow, (u64)h % GL_P));
+  E2 zs[2] = {z0, z1};
+  for (int p = 0; p < npoints; p++) {
+    E2 scale = e2_mul_base(e2_sub(e2_exp_pow2(zs[p], log_h), e2(s_pow)), dinv);
+    for (size_t c = 0; c < w; c++) out_host[p * w + c] = e2_mul(sums[c * npoints + p], scale);
+  }
+}
+
+void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, size_t height, const E2* apow_dev, size_t n_alpha,
+                 const E2* const* den_dev, E2* ro, bool accumulate) {
+  (void)n_alpha;
+  DBuf<DeepMat> dm(ctx, mats.size());
+  ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
+  DeepParams p{dm.p, (u32)mats.size(), apow_dev, den_dev, ro, height, accumulate ? 1 : 0};
+  double bytes = 16.0 * height;
+  for (auto& m : mats) bytes += 8.0 * m.w * height;
+  hipEvent_t ev = ctx.prof_begin(K_DEEP);
+  hipLaunchKernelGGL(deep_reduce_k, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, ctx.stream, p);
+  ctx.prof_end(K_DEEP, ev, bytes);
+  HIP_CHECK(hipGetLastError());
+}
+
+void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in, E2* out) {
+  unsigned lr = log2_strict(rows);
+  if (lr + 1 > TW_LOG) throw std::runtime_error("FRI layer above 2^28 is not supported");
+  u64 half = gl_inv(2);
+  E2 hb = e2_mul_base(beta, half);
+  E2 rf = e2_sqr(beta);  // roll-in factor beta^2
+  hipEvent_t ev = ctx.prof_begin(K_FRI_FOLD);
+  hipLaunchKernelGGL(fri_fold_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, hb, half, roll_in, rf,
+                     ctx.tw0i, ctx.tw1i, out);
+  ctx.prof_end(K_FRI_FOLD, ev, 48.0 * rows);
+  HIP_CHECK(hipGetLastError());
+}
+
+void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows) {
+  merkle_alloc(ctx, t, rows);
+  hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
+  hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.digests.p);
+  ctx.prof_end(K_LEAF_HASH, ev, 64.0 * rows);
+  HIP_CHECK(hipGetLastError());
+  merkle_compress_plain(ctx, t);
+}
+
+void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes) {
+  if (reqs.empty()) return;
+  DBuf<GatherReq> dr(ctx, reqs.size());
+  DBuf<uint8_t> dout(ctx, out_bytes);
+  ctx.h2d(dr.p, reqs.data(), reqs.size() * sizeof(GatherReq));
+  hipLaunchKernelGGL(gather_k, dim3((unsigned)reqs.size()), dim3(64), 0, ctx.stream, dr.p, reqs.size(), dout.p);
+  HIP_CHECK(hipGetLastError());
+  ctx.d2h(host_out, dout.p, out_bytes);
+}
+
+}  // namespace msamd

@@ -1,0 +1,915 @@
+// Host orchestration of the MI355X prover: System::new, SystemWitness, prove_multiple_claims, PCS open / FRI.
+// Stage order, transcript order and proof container layout follow /root/reference/src/prover.rs:290-603
+// (observe/sample sequence :297-431,527,539; rounds :540-579; Proof fields :213-238) and src/system.rs:115-222.
+// Plonky3-side behaviour (TwoAdicFriPcs::open, prove_fri, challenger, MMCS) follows the published p3 0.5.1
+// algorithms; the LDE matrices never leave the device — only caps, opened values, the final polynomial and the
+// query openings cross PCIe.
+#include <algorithm>
+#include <chrono>
+
+#include "host.h"
+
+namespace msamd {
+
+// ------------------------------------------------------------------ host BLAKE3 + challenger
+namespace {
+void load_block(const uint8_t* p, size_t len, u32 w[16]) {
+  uint8_t buf[64];
+  memset(buf, 0, 64);
+  if (len) memcpy(buf, p, len);
+  for (int i = 0; i < 16; i++)
+    w[i] = (u32)buf[4 * i] | ((u32)buf[4 * i + 1] << 8) | ((u32)buf[4 * i + 2] << 16) | ((u32)buf[4 * i + 3] << 24);
+}
+void subtree_cv(const uint8_t* in, size_t len, u64 chunk_index, u32 root_flag, u32 out[8]) {
+  if (len <= 1024) {
+    b3_iv(out);
+    size_t nblocks = len == 0 ? 1 : (len + 63) / 64;
+    for (size_t b = 0; b < nblocks; b++) {
+      size_t off = b * 64, bl = len - off < 64 ? len - off : 64;
+      u32 m[16];
+      load_block(in + off, bl, m);
+      u32 flags = (b == 0 ? B3_CHUNK_START : 0) | (b == nblocks - 1 ? (B3_CHUNK_END | root_flag) : 0);
+      b3_compress(out, m, chunk_index, (u32)bl, flags);
+    }
+    return;
+  }
+  size_t full = (len - 1) / 1024, lc = 1;
+  while (lc * 2 <= full) lc *= 2;
+  u32 m[16];
+  subtree_cv(in, lc * 1024, chunk_index, 0, m);
+  subtree_cv(in + lc * 1024, len - lc * 1024, chunk_index + lc, 0, m + 8);
+  b3_iv(out);
+  b3_compress(out, m, 0, 64, B3_PARENT | root_flag);
+}
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+void blake3_host(const uint8_t* in, size_t len, uint8_t out[32]) {
+  u32 cv[8];
+  subtree_cv(in, len, 0, B3_ROOT, cv);
+  for (int i = 0; i < 8; i++)
+    for (int k = 0; k < 4; k++) out[4 * i + k] = (uint8_t)(cv[i] >> (8 * k));
+}
+
+uint8_t Challenger::sample_byte() {
+  if (output.empty()) {
+    uint8_t d[32];
+    blake3_host(input.data(), input.size(), d);
+    input.assign(d, d + 32);
+    output.assign(d, d + 32);
+  }
+  uint8_t b = output.back();
+  output.pop_back();
+  return b;
+}
+u64 Challenger::sample_u64() {
+  u64 v = 0;
+  for (int k = 0; k < 8; k++) v |= (u64)sample_byte() << (8 * k);
+  return v;
+}
+u64 Challenger::sample_base() {
+  for (;;) {
+    u64 v = sample_u64();
+    if (v < GL_P) return v;
+  }
+}
+E2 Challenger::sample_ext() {
+  u64 a = sample_base();
+  u64 b = sample_base();
+  return e2(a, b);
+}
+size_t Challenger::sample_bits(unsigned bits) { return (size_t)(sample_u64() & ((u64(1) << bits) - 1)); }
+
+// smallest witness w such that observing w then sampling `bits` bits gives zero (SURVEY finding 7);
+// ZERO at 0 bits (DeterministicPow, src/types.rs:75-80). The candidate transcript is input || w (8 bytes).
+u64 Challenger::grind(unsigned bits) {
+  if (bits == 0) return 0;
+  std::vector<uint8_t> buf(input);
+  size_t base = buf.size();
+  buf.resize(base + 8);
+  const u64 mask = (u64(1) << bits) - 1;
+  for (u64 w = 0;; w++) {
+    for (int k = 0; k < 8; k++) buf[base + k] = (uint8_t)(w >> (8 * k));
+    uint8_t d[32];
+    blake3_host(buf.data(), buf.size(), d);
+    // sample_bits pops 8 bytes from the back of the digest: byte k of the u64 is d[31 - k]
+    u64 v = 0;
+    for (int k = 0; k < 8; k++) v |= (u64)d[31 - k] << (8 * k);
+    if ((v & mask) == 0) {
+      observe(w);
+      size_t s = sample_bits(bits);
+      if (s != 0) throw std::runtime_error("grind: internal inconsistency");
+      return w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ System::new
+namespace {
+struct Reader {
+  const uint8_t* p;
+  size_t n, off = 0;
+  u64 word() {
+    if (off + 8 > n) throw std::runtime_error("system blob truncated");
+    u64 v;
+    memcpy(&v, p + off, 8);
+    off += 8;
+    return v;
+  }
+};
+const u64 BLOB_MAGIC = 0x31305359534D0000ULL;
+}  // namespace
+
+void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out) {
+  out.ldes = std::move(ldes);
+  out.tree = DTree();
+  out.tree.cap_height = cap_height;
+  for (auto& m : out.ldes) {
+    out.tree.mat_d.push_back(m.d());
+    out.tree.mat_h.push_back(m.h);
+    out.tree.mat_w.push_back(m.w);
+  }
+  merkle_build(ctx, out.tree);
+}
+
+// host row-major evaluations -> device bit-reversed coset LDE
+static DMat lde_of_host_matrix(Ctx& ctx, const u64* rowmajor_dev, size_t h, size_t w, unsigned lb) {
+  unsigned logn = log2_strict(h);
+  DBuf<u64> ev(ctx, h * w);
+  transpose_in(ctx, rowmajor_dev, ev.p, h, w, true);
+  DMat lde;
+  lde.h = h << lb;
+  lde.w = w;
+  lde.buf = DBuf<u64>(ctx, lde.h * w);
+  coset_lde(ctx, ev.p, lde.d(), logn, lb, w);
+  return lde;
+}
+
+std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t len) {
+  Reader rd{blob, len};
+  if (rd.word() != BLOB_MAGIC) throw std::runtime_error("bad system blob magic");
+  std::unique_ptr<HSystem> sys(new HSystem());
+  sys->ctx = &ctx;
+  Params& p = sys->params;
+  p.log_blowup = rd.word();
+  p.cap_height = rd.word();
+  p.log_final_poly_len = rd.word();
+  p.max_log_arity = rd.word();
+  p.num_queries = rd.word();
+  p.commit_pow_bits = rd.word();
+  p.query_pow_bits = rd.word();
+  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 (binary folding) is supported");
+  if (p.log_blowup < 1 || p.log_blowup > 8) throw std::runtime_error("log_blowup out of range");
+  if (p.commit_pow_bits > 40 || p.query_pow_bits > 40) throw std::runtime_error("proof-of-work bits out of range");
+  {
+    const char* tag = "multi-stark/v0";  // src/types.rs:118-130
+    sys->seed.assign(tag, tag + 14);
+    const u64 ps[7] = {p.log_blowup, p.cap_height, p.log_final_poly_len, p.max_log_arity, p.num_queries, p.commit_pow_bits,
+                       p.query_pow_bits};
+    for (u64 x : ps)
+      for (int k = 0; k < 8; k++) sys->seed.push_back((uint8_t)(x >> (8 * k)));
+  }
+  const size_t D = 2;
+  size_t nc = rd.word();
+  std::vector<DMat> pre_ldes;
+  for (size_t ci = 0; ci < nc; ci++) {
+    sys->circuits.emplace_back();
+    HCircuit& c = sys->circuits.back();
+    c.main_width = rd.word();
+    c.pre_width = rd.word();
+    c.pre_height = rd.word();
+    size_t nn = rd.word(), nz = rd.word(), nl = rd.word();
+    c.num_lookups = nl;
+    c.stage2_width = std::max<size_t>(nl, 1) * D;
+    c.nodes.resize(nn);
+    c.degrees.resize(nn);
+    for (size_t i = 0; i < nn; i++) {
+      u64 w0 = rd.word();
+      PNode& nd = c.nodes[i];
+      nd.kind = (uint32_t)(w0 & 0xff);
+      nd.source = (uint32_t)((w0 >> 8) & 0xff);
+      nd.offset = (uint32_t)((w0 >> 16) & 0xff);
+      nd.a = rd.word();
+      nd.b = rd.word();
+      auto child = [&](u64 id) -> uint32_t {
+        if (id >= i) throw std::runtime_error("node program is not topologically ordered");
+        return c.degrees[id];
+      };
+      uint32_t deg = 0;
+      switch (nd.kind) {  // src/graph.rs:242-252
+        case OP_CONST:
+          if (nd.a >= GL_P) throw std::runtime_error("non-canonical constant in node program");
+          break;
+        case OP_PUBLIC:
+          if (nd.a >= 4 * D) throw std::runtime_error("public index out of range");
+          break;
+        case OP_IS_TRANS: break;
+        case OP_VAR: {
+          size_t width = nd.source == 0 ? c.pre_width : nd.source == 1 ? c.main_width : c.stage2_width;
+          if (nd.source > 2 || nd.offset > 1 || nd.a >= width) throw std::runtime_error("column reference out of range");
+          deg = 1;
+          break;
+        }
+        case OP_IS_FIRST:
+        case OP_IS_LAST: deg = 1; break;
+        case OP_ADD:
+        case OP_SUB: deg = std::max(child(nd.a), child(nd.b)); break;
+        case OP_MUL: deg = child(nd.a) + child(nd.b); break;
+        case OP_NEG: deg = child(nd.a); break;
+        default: throw std::runtime_error("bad node kind");
+      }
+      c.degrees[i] = deg;
+    }
+    uint32_t graph_deg = 0;
+    for (size_t i = 0; i < nz; i++) {
+      u64 z = rd.word();
+      if (z >= nn) throw std::runtime_error("constraint root out of range");
+      c.zeros.push_back((uint32_t)z);
+      graph_deg = std::max(graph_deg, c.degrees[z]);
+    }
+    uint32_t logup_deg = nl ? 0 : 1;  // src/lookup.rs:262-278
+    for (size_t j = 0; j < nl; j++) {
+      u64 m = rd.word();
+      if (m >= nn) throw std::runtime_error("lookup node out of range");
+      size_t na = rd.word();
+      std::vector<uint32_t> args;
+      uint32_t msg = 0;
+      c.lookup_prefix_len = std::max<size_t>(c.lookup_prefix_len, m + 1);
+      for (size_t k = 0; k < na; k++) {
+        u64 a = rd.word();
+        if (a >= nn) throw std::runtime_error("lookup node out of range");
+        args.push_back((uint32_t)a);
+        msg = std::max(msg, c.degrees[a]);
+        c.lookup_prefix_len = std::max<size_t>(c.lookup_prefix_len, a + 1);
+      }
+      c.args_width += na;
+      logup_deg = std::max(logup_deg, std::max(msg + 1, c.degrees[m]));
+      c.lookups.emplace_back((uint32_t)m, std::move(args));
+    }
+    c.constraint_count = nz + std::max<size_t>(nl, 1) * D;  // src/system.rs:151
+    c.max_constraint_degree = std::max(graph_deg, logup_deg);
+    if (c.quotient_degree() > (size_t(1) << p.log_blowup))  // src/system.rs:171-178
+      throw std::runtime_error("circuit " + std::to_string(ci) + ": constraint degree needs a quotient degree beyond the blowup");
+    build_program(ctx, c.nodes, c.zeros, c.lookups, c.prog);
+    c.prog.constraint_count = c.constraint_count;
+    c.prog.main_w = c.main_width;
+    c.prog.pre_w = c.pre_width;
+    c.prog.s2_w = c.stage2_width;
+    if (c.pre_width) {
+      if (c.pre_height == 0 || (c.pre_height & (c.pre_height - 1))) throw std::runtime_error("preprocessed height must be a power of two");
+      if (log2_strict(c.pre_height) > NTT_MAX_LOG) throw std::runtime_error("preprocessed trace too tall");
+      size_t cnt = c.pre_height * c.pre_width;
+      c.preprocessed.resize(cnt);
+      for (auto& x : c.preprocessed) {
+        x = rd.word();
+        if (x >= GL_P) throw std::runtime_error("non-canonical preprocessed value");
+      }
+      DBuf<u64> up(ctx, cnt);
+      ctx.h2d(up.p, c.preprocessed.data(), cnt * 8);
+      sys->pre_indices.push_back((int)pre_ldes.size());
+      pre_ldes.push_back(lde_of_host_matrix(ctx, up.p, c.pre_height, c.pre_width, (unsigned)p.log_blowup));
+      ctx.sync();
+    } else {
+      c.pre_height = 0;
+      sys->pre_indices.push_back(-1);
+    }
+  }
+  if (rd.off != len) throw std::runtime_error("trailing bytes in system blob");
+  if (!pre_ldes.empty()) {
+    sys->has_pre = true;
+    commit_matrices(ctx, std::move(pre_ldes), (unsigned)p.cap_height, sys->pre_data);
+    sys->pre_commit = merkle_cap(ctx, sys->pre_data.tree);
+  }
+  ctx.sync();
+  return sys;
+}
+
+// ------------------------------------------------------------------ SystemWitness
+namespace {
+// host sweep of the lookup prefix for one row (src/eval.rs:59-106 in the base field)
+void sweep_prefix(const HCircuit& c, const u64* pre_cur, const u64* pre_next, const u64* cur, const u64* next, bool first,
+                  bool last, std::vector<u64>& buf) {
+  size_t len = c.lookup_prefix_len;
+  buf.resize(len);
+  for (size_t i = 0; i < len; i++) {
+    const PNode& n = c.nodes[i];
+    u64 v = 0;
+    switch (n.kind) {
+      case OP_CONST: v = n.a; break;
+      case OP_VAR:
+        if (n.source == 0)
+          v = (n.offset ? pre_next : pre_cur)[n.a];
+        else if (n.source == 1)
+          v = (n.offset ? next : cur)[n.a];
+        else
+          throw std::runtime_error("stage-2 column in a lookup expression");
+        break;
+      case OP_PUBLIC: throw std::runtime_error("public input in a lookup expression");
+      case OP_IS_FIRST: v = first; break;
+      case OP_IS_LAST: v = last; break;
+      case OP_IS_TRANS: v = !last; break;
+      case OP_ADD: v = gl_add(buf[n.a], buf[n.b]); break;
+      case OP_SUB: v = gl_sub(buf[n.a], buf[n.b]); break;
+      case OP_MUL: v = gl_mul(buf[n.a], buf[n.b]); break;
+      default: v = gl_neg(buf[n.a]); break;
+    }
+    buf[i] = v;
+  }
+}
+}  // namespace
+
+std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces, const u64* heights, const u64* const* mult,
+                                         const u64* const* args, size_t n_claims, const u64* claim_offsets, const u64* claim_data) {
+  Ctx& ctx = *sys.ctx;
+  std::unique_ptr<HWitness> w(new HWitness());
+  w->sys = &sys;
+  size_t C = sys.circuits.size();
+  w->traces.resize(C);
+  w->lookups.resize(C);
+  for (size_t ci = 0; ci < C; ci++) {
+    const HCircuit& c = sys.circuits[ci];
+    size_t h = heights[ci];
+    w->heights.push_back(h);
+    if (h == 0) continue;
+    if (h & (h - 1)) throw std::runtime_error("trace height must be a power of two");
+    if (log2_strict(h) > NTT_MAX_LOG || log2_strict(h) + sys.params.log_blowup > TW_LOG)
+      throw std::runtime_error("trace height exceeds the supported maximum");
+    if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    size_t cnt = h * c.main_width;
+    for (size_t i = 0; i < cnt; i++)
+      if (traces[ci][i] >= GL_P) throw std::runtime_error("non-canonical trace value");
+    w->traces[ci] = DBuf<u64>(ctx, cnt);
+    ctx.h2d(w->traces[ci].p, traces[ci], cnt * 8);
+    DLookups& lk = w->lookups[ci];
+    lk.height = h;
+    lk.num_lookups = c.num_lookups;
+    lk.args_width = c.args_width;
+    if (c.num_lookups == 0) continue;
+    std::vector<uint32_t> offs(1, 0);
+    for (auto& l : c.lookups) offs.push_back(offs.back() + (uint32_t)l.second.size());
+    lk.arg_offsets = DBuf<uint32_t>(ctx, offs.size());
+    ctx.h2d(lk.arg_offsets.p, offs.data(), offs.size() * 4);
+    lk.mult = DBuf<u64>(ctx, h * c.num_lookups);
+    lk.args = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
+    if (mult && mult[ci]) {
+      ctx.h2d(lk.mult.p, mult[ci], h * c.num_lookups * 8);
+      if (c.args_width) ctx.h2d(lk.args.p, args[ci], h * c.args_width * 8);
+      ctx.sync();
+    } else {
+      // SystemWitness::from_stage_1, src/system.rs:275-328
+      std::vector<u64> hm(h * c.num_lookups), ha(h * c.args_width), buf;
+      const u64* tr = traces[ci];
+      for (size_t r = 0; r < h; r++) {
+        size_t rn = (r + 1) % h;
+        const u64* pc = c.pre_width ? &c.preprocessed[r * c.pre_width] : nullptr;
+        const u64* pn = c.pre_width ? &c.preprocessed[rn * c.pre_width] : nullptr;
+        sweep_prefix(c, pc, pn, tr + r * c.main_width, tr + rn * c.main_width, r == 0, r == h - 1, buf);
+        for (size_t j = 0; j < c.num_lookups; j++) {
+          hm[r * c.num_lookups + j] = buf[c.lookups[j].first];
+          for (size_t k = 0; k < c.lookups[j].second.size(); k++) ha[r * c.args_width + offs[j] + k] = buf[c.lookups[j].second[k]];
+        }
+      }
+      ctx.h2d(lk.mult.p, hm.data(), hm.size() * 8);
+      if (!ha.empty()) ctx.h2d(lk.args.p, ha.data(), ha.size() * 8);
+      ctx.sync();
+    }
+  }
+  w->claim_offsets.assign(claim_offsets, claim_offsets + n_claims + 1);
+  size_t tot = n_claims ? (size_t)claim_offsets[n_claims] : 0;
+  if (claim_offsets[0] != 0) throw std::runtime_error("claim offsets must start at 0");
+  for (size_t i = 0; i < n_claims; i++)
+    if (claim_offsets[i + 1] < claim_offsets[i]) throw std::runtime_error("claim offsets must be non-decreasing");
+  w->claim_data.assign(claim_data, claim_data + tot);
+  for (u64 x : w->claim_data)
+    if (x >= GL_P) throw std::runtime_error("non-canonical claim value");
+  w->d_claim_offsets = DBuf<u64>(ctx, n_claims + 1);
+  w->d_claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
+  ctx.h2d(w->d_claim_offsets.p, w->claim_offsets.data(), (n_claims + 1) * 8);
+  if (tot) ctx.h2d(w->d_claim_data.p, w->claim_data.data(), tot * 8);
+  ctx.sync();
+  return w;
+}
+
+// ------------------------------------------------------------------ proof bytes (Proof::to_bytes, src/prover.rs:241-248)
+namespace {
+struct PW {
+  std::vector<uint8_t> b;
+  void u8(uint8_t x) { b.push_back(x); }
+  void u64_(u64 x) {
+    size_t o = b.size();
+    b.resize(o + 8);
+    memcpy(&b[o], &x, 8);
+  }
+  void ext(E2 e) {
+    u64_(e.c0);
+    u64_(e.c1);
+  }
+  void raw(const void* p, size_t n) {
+    const uint8_t* q = (const uint8_t*)p;
+    b.insert(b.end(), q, q + n);
+  }
+  void cap(const std::vector<Digest>& c) {
+    u64_(c.size());
+    for (auto& d : c) raw(d.b, 32);
+  }
+};
+typedef std::vector<std::vector<std::vector<E2>>> OpenedRound;
+void write_round(PW& w, const OpenedRound& r) {
+  w.u64_(r.size());
+  for (auto& m : r) {
+    w.u64_(m.size());
+    for (auto& pt : m) {
+      w.u64_(pt.size());
+      for (auto& e : pt) w.ext(e);
+    }
+  }
+}
+
+struct OpenRound {
+  PcsData* data;
+  std::vector<std::vector<E2>> points;
+};
+
+bool e2_same(E2 a, E2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+
+// TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
+void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes) {
+  Ctx& ctx = *sys.ctx;
+  const Params& prm = sys.params;
+  const unsigned lb = (unsigned)prm.log_blowup;
+  size_t gmax = 0, gw = 0;
+  for (auto& r : rounds)
+    for (auto& m : r.data->ldes) {
+      gmax = std::max(gmax, m.h);
+      gw = std::max(gw, m.w);
+    }
+  if (!gmax) throw std::runtime_error("pcs_open: no matrices");
+  const unsigned log_gmax = log2_strict(gmax);
+
+  // unique opening points and the tallest matrix opened at each
+  std::vector<E2> upts;
+  std::vector<size_t> uh;
+  auto point_index = [&](E2 z) -> size_t {
+    for (size_t i = 0; i < upts.size(); i++)
+      if (e2_same(upts[i], z)) return i;
+    upts.push_back(z);
+    uh.push_back(0);
+    return upts.size() - 1;
+  };
+  for (auto& r : rounds)
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++)
+      for (auto& z : r.points[mi]) {
+        size_t k = point_index(z);
+        uh[k] = std::max(uh[k], r.data->ldes[mi].h);
+      }
+  std::vector<DBuf<E2>> dens(upts.size());
+  for (size_t k = 0; k < upts.size(); k++) {
+    dens[k] = DBuf<E2>(ctx, uh[k]);
+    inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p);
+  }
+
+  // opened values (barycentric over the first h = height / B storage rows), observed as produced
+  opened.clear();
+  for (auto& r : rounds) {
+    OpenedRound orr;
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+      const DMat& m = r.data->ldes[mi];
+      auto& pts = r.points[mi];
+      std::vector<std::vector<E2>> per_point;
+      if (!pts.empty()) {
+        if (pts.size() > 2) throw std::runtime_error("pcs_open: more than two points per matrix");
+        int np = (int)pts.size();
+        std::vector<E2> ys(np * m.w);
+        const E2* d0 = dens[point_index(pts[0])].p;
+        const E2* d1 = np == 2 ? dens[point_index(pts[1])].p : d0;
+        bary_eval(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, pts[0], np == 2 ? pts[1] : pts[0], np, ys.data());
+        for (int p = 0; p < np; p++) {
+          per_point.emplace_back(ys.begin() + p * m.w, ys.begin() + (p + 1) * m.w);
+          for (auto& y : per_point.back()) ch.observe_ext(y);
+        }
+      }
+      orr.push_back(std::move(per_point));
+    }
+    opened.push_back(std::move(orr));
+  }
+
+  const E2 alpha = ch.sample_ext();
+  std::vector<E2> apow(gw + 1);
+  apow[0] = e2(1);
+  for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
+  DBuf<E2> d_apow(ctx, gw + 1);
+  ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
+  std::vector<const E2*> denp(dens.size());
+  for (size_t k = 0; k < dens.size(); k++) denp[k] = dens[k].p;
+  DBuf<const E2*> d_denp(ctx, std::max<size_t>(dens.size(), 1));
+  ctx.h2d(d_denp.p, denp.data(), denp.size() * sizeof(E2*));
+
+  // reduced openings per LDE height
+  std::vector<size_t> num_reduced(33, 0);
+  std::vector<std::vector<DeepMat>> lists(33);
+  std::vector<char> present(33, 0);
+  for (size_t ri = 0; ri < rounds.size(); ri++) {
+    auto& r = rounds[ri];
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+      const DMat& m = r.data->ldes[mi];
+      unsigned lh = log2_strict(m.h);
+      present[lh] = 1;
+      auto& pts = r.points[mi];
+      if (pts.empty()) continue;
+      DeepMat dm;
+      memset(&dm, 0, sizeof(dm));
+      dm.d = m.d();
+      dm.w = (uint32_t)m.w;
+      dm.npoints = (uint32_t)pts.size();
+      for (size_t pi = 0; pi < pts.size(); pi++) {
+        dm.coeff[pi] = e2_pow(alpha, num_reduced[lh]);
+        E2 rz = e2(0);
+        const std::vector<E2>& ys = opened[ri][mi][pi];
+        for (size_t c = 0; c < m.w; c++) rz = e2_add(rz, e2_mul(apow[c], ys[c]));
+        dm.red_z[pi] = rz;
+        dm.inv_idx[pi] = (uint32_t)point_index(pts[pi]);
+        num_reduced[lh] += m.w;
+      }
+      lists[lh].push_back(dm);
+    }
+  }
+  std::vector<DBuf<E2>> inputs;  // descending height
+  for (int lh = 32; lh >= 0; lh--) {
+    if (!present[lh]) continue;
+    size_t h = size_t(1) << lh;
+    DBuf<E2> ro(ctx, h);
+    if (lists[lh].empty())
+      HIP_CHECK(hipMemsetAsync(ro.p, 0, h * sizeof(E2), ctx.stream));
+    else
+      deep_reduce(ctx, lists[lh], h, d_apow.p, gw + 1, d_denp.p, ro.p, false);
+    inputs.push_back(std::move(ro));
+  }
+  for (auto& d : dens) d.reset();
+
+  // ---- FRI commit phase (prove_fri / commit_phase)
+  const size_t final_len = size_t(1) << prm.log_final_poly_len;
+  const size_t stop = (size_t(1) << lb) * final_len;
+  std::vector<DBuf<E2>> layers;  // folded vectors kept for the query phase
+  std::vector<DTree> trees;
+  std::vector<std::vector<Digest>> commits;
+  std::vector<u64> pow_w;
+  DBuf<E2> folded = std::move(inputs[0]);
+  size_t next_in = 1;
+  const unsigned log_max_height = log2_strict(folded.n);
+  while (folded.n > stop) {
+    size_t rows = folded.n / 2;
+    trees.emplace_back();
+    DTree& t = trees.back();
+    t.cap_height = (unsigned)prm.cap_height;
+    fri_tree_build(ctx, t, folded.p, rows);
+    std::vector<Digest> cap = merkle_cap(ctx, t);
+    ch.observe_cap(cap);
+    commits.push_back(cap);
+    pow_w.push_back(ch.grind((unsigned)prm.commit_pow_bits));
+    E2 beta = ch.sample_ext();
+    DBuf<E2> nxt(ctx, rows);
+    const E2* roll = nullptr;
+    if (next_in < inputs.size() && inputs[next_in].n == rows) roll = inputs[next_in].p;
+    fri_fold(ctx, folded.p, rows, beta, roll, nxt.p);
+    if (roll) inputs[next_in++].reset();
+    layers.push_back(std::move(folded));
+    folded = std::move(nxt);
+  }
+  if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
+  // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
+  std::vector<E2> fin(folded.n);
+  ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
+  std::vector<E2> final_poly(final_len);
+  {
+    unsigned lf = (unsigned)prm.log_final_poly_len;
+    std::vector<E2> ev(final_len);
+    for (size_t i = 0; i < final_len; i++) ev[bitrev64(i, lf)] = fin[i];
+    u64 winv = gl_inv(gl_two_adic_generator(lf)), ninv = gl_inv((u64)final_len);
+    for (size_t k = 0; k < final_len; k++) {
+      E2 s = e2(0);
+      u64 wk = gl_pow(winv, k), cur = 1;
+      for (size_t j = 0; j < final_len; j++) {
+        s = e2_add(s, e2_mul_base(ev[j], cur));
+        cur = gl_mul(cur, wk);
+      }
+      final_poly[k] = e2_mul_base(s, ninv);
+      ch.observe_ext(final_poly[k]);
+    }
+  }
+  const u64 query_pow = ch.grind((unsigned)prm.query_pow_bits);
+
+  // ---- query phase: sample every index, one gather for all openings
+  std::vector<size_t> indices(prm.num_queries);
+  for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
+  std::vector<GatherReq> reqs;
+  size_t out_off = 0;
+  auto add_req = [&](const void* base, u64 stride, u64 index, uint32_t count, uint32_t kind) {
+    GatherReq q;
+    q.base = base;
+    q.stride = stride;
+    q.index = index;
+    q.count = count;
+    q.kind = kind;
+    q.out_off = out_off;
+    reqs.push_back(q);
+    out_off += kind == 0 ? size_t(count) * 8 : size_t(count) * 32;
+  };
+  auto n_siblings = [](const DTree& t) { return t.cap_layer(); };
+  for (size_t index : indices) {
+    for (auto& r : rounds) {
+      const DTree& t = r.data->tree;
+      unsigned lmh = log2_strict(t.max_height());
+      size_t ridx = index >> (log_gmax - lmh);
+      for (auto& m : r.data->ldes) add_req(m.d(), m.h, ridx >> (lmh - log2_strict(m.h)), (uint32_t)m.w, 0);
+      for (size_t i = 0; i < n_siblings(t); i++) add_req(t.digests.p + t.layer_off[i], 0, (ridx >> i) ^ 1, 1, 1);
+    }
+    for (size_t i = 0; i < trees.size(); i++) {
+      size_t index_i = index >> i, sib = index_i ^ 1, pair = index_i >> 1;
+      add_req((const u64*)(layers[i].p + 2 * pair + (sib & 1)), 1, 0, 2, 0);
+      const DTree& t = trees[i];
+      for (size_t l = 0; l < n_siblings(t); l++) add_req(t.digests.p + t.layer_off[l], 0, (pair >> l) ^ 1, 1, 1);
+    }
+  }
+  std::vector<uint8_t> g(out_off);
+  gather_rows(ctx, reqs, g.data(), out_off);
+
+  // ---- FriProof bytes
+  PW& w = fri_bytes;
+  w.u64_(commits.size());
+  for (auto& c : commits) w.cap(c);
+  w.u64_(pow_w.size());
+  for (u64 x : pow_w) w.u64_(x);
+  w.u64_(indices.size());
+  size_t pos = 0;
+  for (size_t qi = 0; qi < indices.size(); qi++) {
+    w.u64_(rounds.size());
+    for (auto& r : rounds) {
+      const DTree& t = r.data->tree;
+      w.u64_(r.data->ldes.size());
+      for (auto& m : r.data->ldes) {
+        w.u64_(m.w);
+        w.raw(&g[pos], m.w * 8);
+        pos += m.w * 8;
+      }
+      size_t ns = n_siblings(t);
+      w.u64_(ns);
+      w.raw(&g[pos], ns * 32);
+      pos += ns * 32;
+    }
+    w.u64_(trees.size());
+    for (size_t i = 0; i < trees.size(); i++) {
+      w.u8(1);  // log_arity
+      w.u64_(1);
+      w.raw(&g[pos], 16);
+      pos += 16;
+      size_t ns = n_siblings(trees[i]);
+      w.u64_(ns);
+      w.raw(&g[pos], ns * 32);
+      pos += ns * 32;
+    }
+  }
+  w.u64_(final_poly.size());
+  for (auto& e : final_poly) w.ext(e);
+  w.u64_(query_pow);
+}
+}  // namespace
+
+// ------------------------------------------------------------------ prove
+std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  const Params& prm = sys.params;
+  const unsigned lb = (unsigned)prm.log_blowup;
+  const size_t C = sys.circuits.size();
+  if (wit.sys != &sys || wit.heights.size() != C) throw std::runtime_error("witness does not belong to this system");
+  double t_begin = now_ms(), t0;
+  auto lap = [&](int slot) {
+    if (times) {
+      ctx.sync();
+      times->v[slot] = now_ms() - t0;
+    }
+  };
+
+  Challenger ch(sys.seed);
+  // src/system.rs:211-222
+  ch.observe((u64)C);
+  for (auto& c : sys.circuits) {
+    ch.observe((u64)c.constraint_count);
+    ch.observe((u64)c.max_constraint_degree);
+    ch.observe((u64)c.pre_height);
+    ch.observe((u64)c.pre_width);
+    ch.observe((u64)c.main_width);
+    ch.observe((u64)c.stage2_width);
+  }
+  std::vector<uint8_t> active(C);
+  std::vector<size_t> aidx;
+  std::vector<int> apos(C, -1);
+  for (size_t i = 0; i < C; i++) {
+    active[i] = wit.heights[i] > 0;
+    ch.observe(active[i] ? 1 : 0);
+    if (active[i]) {
+      apos[i] = (int)aidx.size();
+      aidx.push_back(i);
+    }
+  }
+  if (aidx.empty()) throw std::runtime_error("cannot prove with every circuit deactivated (all traces empty)");
+  const size_t NA = aidx.size();
+
+  // ---- stage 1 commit (src/prover.rs:336-351)
+  t0 = now_ms();
+  std::vector<unsigned> log_degrees;
+  PcsData s1;
+  {
+    std::vector<DMat> ldes;
+    for (size_t ci : aidx) {
+      size_t h = wit.heights[ci];
+      log_degrees.push_back(log2_strict(h));
+      ldes.push_back(lde_of_host_matrix(ctx, wit.traces[ci].p, h, sys.circuits[ci].main_width, lb));
+    }
+    commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
+  }
+  std::vector<Digest> s1_cap = merkle_cap(ctx, s1.tree);
+  lap(0);
+
+  if (sys.has_pre) ch.observe_cap(sys.pre_commit);
+  ch.observe_cap(s1_cap);
+  for (unsigned ld : log_degrees) ch.observe(ld);
+  // claims, length-prefixed (src/prover.rs:369-373). Large claim sets are hashed on the device: the transcript
+  // since the last sample is `ch.input || words`, and the next operation is a sample, so the digest is all
+  // the challenger needs.
+  const size_t n_claims = wit.claim_offsets.size() - 1;
+  const size_t claim_elems = wit.claim_data.size();
+  const size_t claim_words = 1 + n_claims + claim_elems;
+  const bool device_claims = claim_words > 8192;
+  if (!device_claims) {
+    ch.observe((u64)n_claims);
+    for (size_t i = 0; i < n_claims; i++) {
+      size_t a = wit.claim_offsets[i], b = wit.claim_offsets[i + 1];
+      ch.observe((u64)(b - a));
+      for (size_t k = a; k < b; k++) ch.observe(wit.claim_data[k]);
+    }
+  } else {
+    DBuf<uint8_t> d_prefix(ctx, ch.input.size());
+    ctx.h2d(d_prefix.p, ch.input.data(), ch.input.size());
+    DBuf<u64> d_words(ctx, claim_words);
+    claims_transcript_words(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, claim_elems, d_words.p);
+    Digest d = blake3_device(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words);
+    ch.flush_with(d);
+  }
+  const E2 beta = ch.sample_ext();
+  ch.observe_ext(beta);
+  const E2 gamma = ch.sample_ext();
+  ch.observe_ext(gamma);
+  // initial accumulator from the claims (src/prover.rs:382-387)
+  E2 acc;
+  if (n_claims > 256) {
+    acc = claims_accumulator(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, beta, gamma);
+  } else {
+    acc = e2(0);
+    for (size_t i = 0; i < n_claims; i++) {
+      E2 f = e2(0);
+      for (size_t k = wit.claim_offsets[i + 1]; k-- > wit.claim_offsets[i];) f = e2_add(e2_mul(f, gamma), e2(wit.claim_data[k]));
+      acc = e2_add(acc, e2_inv(e2_add(beta, f)));
+    }
+  }
+  const E2 acc_initial = acc;
+
+  // ---- lookup construction (src/prover.rs:391-409) + stage 2 commit (:413-421)
+  t0 = now_ms();
+  std::vector<E2> accs;
+  std::vector<DBuf<u64>> s2_evals(NA);
+  for (size_t pos = 0; pos < NA; pos++) {
+    size_t ci = aidx[pos];
+    const HCircuit& c = sys.circuits[ci];
+    size_t n = wit.heights[ci];
+    s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
+    E2 total = stage2_build(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p);
+    acc = e2_add(acc, total);
+    accs.push_back(acc);
+  }
+  lap(1);
+  t0 = now_ms();
+  PcsData s2;
+  {
+    std::vector<DMat> ldes;
+    for (size_t pos = 0; pos < NA; pos++) {
+      const HCircuit& c = sys.circuits[aidx[pos]];
+      size_t n = wit.heights[aidx[pos]];
+      DMat lde;
+      lde.h = n << lb;
+      lde.w = c.stage2_width;
+      lde.buf = DBuf<u64>(ctx, lde.h * lde.w);
+      coset_lde(ctx, s2_evals[pos].p, lde.d(), log_degrees[pos], lb, lde.w);
+      s2_evals[pos].reset();
+      ldes.push_back(std::move(lde));
+    }
+    commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s2);
+  }
+  std::vector<Digest> s2_cap = merkle_cap(ctx, s2.tree);
+  lap(2);
+  ch.observe_cap(s2_cap);
+  for (auto& a : accs) ch.observe_ext(a);
+  const E2 alpha = ch.sample_ext();
+
+  // ---- quotient (src/prover.rs:437-528)
+  t0 = now_ms();
+  PcsData qd;
+  {
+    std::vector<DMat> qldes;
+    E2 acc_in = acc_initial;
+    for (size_t pos = 0; pos < NA; pos++) {
+      size_t ci = aidx[pos];
+      const HCircuit& c = sys.circuits[ci];
+      unsigned log_n = log_degrees[pos], log_q = log2_strict(c.quotient_degree());
+      size_t n = size_t(1) << log_n, nq = n << log_q;
+      QuotientArgs qa;
+      if (sys.has_pre && sys.pre_indices[ci] >= 0) {
+        const DMat& pm = sys.pre_data.ldes[sys.pre_indices[ci]];
+        qa.pre = pm.d();
+        qa.pre_h = pm.h;
+      }
+      qa.s1 = s1.ldes[pos].d();
+      qa.s1_h = s1.ldes[pos].h;
+      qa.s2 = s2.ldes[pos].d();
+      qa.s2_h = s2.ldes[pos].h;
+      qa.log_n = log_n;
+      qa.log_q = log_q;
+      const E2 four[4] = {beta, gamma, acc_in, accs[pos]};
+      for (int k = 0; k < 4; k++) {
+        qa.publics[2 * k] = four[k].c0;
+        qa.publics[2 * k + 1] = four[k].c1;
+      }
+      qa.alpha = alpha;
+      DBuf<u64> qv(ctx, nq * 2);
+      quotient_eval(ctx, c.prog, qa, qv.p);
+      acc_in = accs[pos];
+      DMat lde;
+      lde.h = n << lb;
+      lde.w = 2 << log_q;
+      lde.buf = DBuf<u64>(ctx, lde.h * lde.w);
+      quotient_lde(ctx, qv.p, lde.d(), log_n, log_q, lb, 2);
+      qldes.push_back(std::move(lde));
+    }
+    commit_matrices(ctx, std::move(qldes), (unsigned)prm.cap_height, qd);
+  }
+  std::vector<Digest> q_cap = merkle_cap(ctx, qd.tree);
+  ch.observe_cap(q_cap);
+  lap(3);
+
+  // ---- opening (src/prover.rs:538-581)
+  t0 = now_ms();
+  const E2 zeta = ch.sample_ext();
+  std::vector<OpenRound> rounds(3);
+  rounds[0].data = &s1;
+  rounds[1].data = &s2;
+  rounds[2].data = &qd;
+  for (unsigned ld : log_degrees) {
+    E2 zn = e2_mul_base(zeta, gl_two_adic_generator(ld));
+    rounds[0].points.push_back({zeta, zn});
+    rounds[1].points.push_back({zeta, zn});
+    rounds[2].points.push_back({zeta});
+  }
+  if (sys.has_pre) {
+    OpenRound r0;
+    r0.data = &sys.pre_data;
+    for (size_t ci = 0; ci < C; ci++) {
+      if (sys.pre_indices[ci] < 0) continue;
+      if (apos[ci] >= 0) {
+        E2 zn = e2_mul_base(zeta, gl_two_adic_generator(log_degrees[apos[ci]]));
+        r0.points.push_back({zeta, zn});
+      } else {
+        r0.points.push_back({});
+      }
+    }
+    rounds.push_back(std::move(r0));
+  }
+  std::vector<OpenedRound> opened;
+  PW fri;
+  pcs_open(sys, rounds, ch, opened, fri);
+  lap(4);
+
+  // ---- Proof bytes, field order of src/prover.rs:213-238
+  PW w;
+  w.u64_(C);
+  for (auto a : active) w.u8(a);
+  w.cap(s1_cap);
+  w.cap(s2_cap);
+  w.cap(q_cap);
+  w.u64_(accs.size());
+  for (auto& a : accs) w.ext(a);
+  w.u64_(log_degrees.size());
+  for (unsigned ld : log_degrees) w.u8((uint8_t)ld);
+  w.raw(fri.b.data(), fri.b.size());
+  write_round(w, opened[2]);
+  w.u8(sys.has_pre ? 1 : 0);
+  if (sys.has_pre) write_round(w, opened[3]);
+  write_round(w, opened[0]);
+  write_round(w, opened[1]);
+  ctx.prof_collect();
+  if (times) times->v[5] = now_ms() - t_begin;
+  return std::move(w.b);
+}
+
+}  // namespace msamd

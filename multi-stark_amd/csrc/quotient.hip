@@ -1,0 +1,353 @@
+// Per-row constraint / quotient evaluation on the quotient domain.
+// Replaces quotient_values + quotient_values_inner (/root/reference/src/prover.rs:756-962), the node sweep
+// ConstraintGraph::sweep_range (src/eval.rs:67-106) and logup_constraint_values (src/lookup.rs:152-208, D = 2).
+//
+// One thread = one storage row t of the committed LDEs (natural quotient-domain index i = bitrev(t)), so the
+// "current row" loads are perfectly coalesced and the "next row" (i + q) maps to another contiguous run. The
+// compiled node vector is lowered on the host into a register-allocated straight-line program (slots reused
+// after a node's last use); slots live in LDS as [slot][lane] (bank-conflict free) or, for very large
+// circuits, in a global scratch with the same layout. Selectors are computed from x = 7 w^i in-kernel.
+#include <algorithm>
+
+#include "msamd.h"
+#include "program.h"
+
+namespace msamd {
+
+namespace {
+
+struct QParams {
+  const u64 *pre, *s1, *s2;
+  size_t pre_h, s1_h, s2_h;
+  unsigned log_n, log_q;
+  u64 publics[8];
+  u64 delta_scaled[2];
+  u64 g_inv;          // inverse of the trace-domain generator
+  const u64* zh;      // q entries: Z_H on the coset, x^n - 1
+  const u64* zh_inv;  // q entries
+  const E2* alpha_rev;  // constraint_count reversed powers
+  const uint32_t* code;
+  const u64* consts;
+  const uint32_t* zero_slots;
+  const uint32_t* lookup_slots;
+  uint32_t n_instr, n_zeros, n_lookups, n_slots;
+  const u64* t0;
+  const u64* t1;
+  u64* out;
+  u64* scratch;       // global slot storage (when !LDS)
+  size_t row0, rows;  // batch of storage rows handled by this launch
+};
+
+__device__ __forceinline__ void mul2(u64 a0, u64 a1, u64 b0, u64 b1, u64& c0, u64& c1) {
+  u64 v0 = gl_mul(a0, b0), v1 = gl_mul(a1, b1);
+  u64 cross = gl_sub(gl_sub(gl_mul(gl_add(a0, a1), gl_add(b0, b1)), v0), v1);
+  c0 = gl_add(v0, gl_mul_small(v1, (u32)GL_EXT_W));
+  c1 = cross;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void quotient_k(QParams p) {
+  extern __shared__ u64 sm[];
+  const size_t lt = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (lt >= p.rows) return;  // no barriers below
+  const size_t t = p.row0 + lt;
+  const unsigned lognq = p.log_n + p.log_q;
+  const size_t nq = size_t(1) << lognq;
+  const u32 i = bitrev32((u32)t, lognq);
+  const u32 inext = (i + (1u << p.log_q)) & (u32)(nq - 1);
+  const size_t tn = bitrev32(inext, lognq);
+  u64* slots = LDS ? (sm + threadIdx.x) : (p.scratch + lt);
+  const size_t stride = LDS ? blockDim.x : p.rows;
+
+  // x = 7 * w_{nq}^i and the Lagrange selectors (p3 selectors_on_coset, unnormalised)
+  u64 x = gl_mul_small(gl_mul(p.t1[(i << (TW_LOG - lognq)) >> TW_HALF], p.t0[(i << (TW_LOG - lognq)) & ((1u << TW_HALF) - 1)]), 7);
+  const u32 qi = i & ((1u << p.log_q) - 1);
+  const u64 zh = p.zh[qi];
+  u64 d_first = gl_sub(x, 1), d_last = gl_sub(x, p.g_inv);
+  u64 inv_both = gl_inv(gl_mul(d_first, d_last));
+  u64 is_first = gl_mul(zh, gl_mul(inv_both, d_last));
+  u64 is_last = gl_mul(zh, gl_mul(inv_both, d_first));
+  u64 is_trans = d_last;
+
+  for (u32 pc = 0; pc < p.n_instr; pc++) {
+    const uint4 ins = reinterpret_cast<const uint4*>(p.code)[pc];
+    u64 v;
+    switch (ins.x) {
+      case OP_CONST: v = p.consts[ins.z]; break;
+      case OP_VAR: {
+        u32 src = ins.z & 0xff, off = ins.z >> 8;
+        size_t row = off ? tn : t;
+        if (src == 1)
+          v = p.s1[size_t(ins.w) * p.s1_h + row];
+        else if (src == 0)
+          v = p.pre[size_t(ins.w) * p.pre_h + row];
+        else
+          v = p.s2[size_t(ins.w) * p.s2_h + row];
+        break;
+      }
+      case OP_PUBLIC: v = p.publics[ins.z]; break;
+      case OP_IS_FIRST: v = is_first; break;
+      case OP_IS_LAST: v = is_last; break;
+      case OP_IS_TRANS: v = is_trans; break;
+      case OP_ADD: v = gl_add(slots[ins.z * stride], slots[ins.w * stride]); break;
+      case OP_SUB: v = gl_sub(slots[ins.z * stride], slots[ins.w * stride]); break;
+      case OP_MUL: v = gl_mul(slots[ins.z * stride], slots[ins.w * stride]); break;
+      default: v = gl_neg(slots[ins.z * stride]); break;
+    }
+    slots[ins.y * stride] = v;
+  }
+
+  // fold: user roots first, then the logUp values, constraint i weighted by alpha^{k-1-i}
+  u64 acc0 = 0, acc1 = 0;
+  u32 ci = 0;
+  for (u32 z = 0; z < p.n_zeros; z++, ci++) {
+    u64 cv = slots[p.zero_slots[z] * stride];
+    E2 a = p.alpha_rev[ci];
+    acc0 = gl_add(acc0, gl_mul(cv, a.c0));
+    acc1 = gl_add(acc1, gl_mul(cv, a.c1));
+  }
+  const u64 beta0 = p.publics[0], beta1 = p.publics[1], gamma0 = p.publics[2], gamma1 = p.publics[3];
+  const u64 inj0 = gl_mul(is_last, p.delta_scaled[0]), inj1 = gl_mul(is_last, p.delta_scaled[1]);
+  auto fold2 = [&](u64 c0, u64 c1) {
+    E2 a = p.alpha_rev[ci], b = p.alpha_rev[ci + 1];
+    acc0 = gl_add(acc0, gl_add(gl_mul(c0, a.c0), gl_mul(c1, b.c0)));
+    acc1 = gl_add(acc1, gl_add(gl_mul(c0, a.c1), gl_mul(c1, b.c1)));
+    ci += 2;
+  };
+  if (p.n_lookups == 0) {
+    u64 c0 = gl_add(gl_sub(p.s2[tn], p.s2[t]), inj0);
+    u64 c1 = gl_add(gl_sub(p.s2[p.s2_h + tn], p.s2[p.s2_h + t]), inj1);
+    fold2(c0, c1);
+  } else {
+    const uint32_t* ls = p.lookup_slots;
+    u64 src0 = p.s2[t], src1 = p.s2[p.s2_h + t];
+    for (u32 j = 0; j < p.n_lookups; j++) {
+      u32 mslot = ls[0], na = ls[1];
+      u64 tgt0, tgt1;
+      if (j + 1 < p.n_lookups) {
+        tgt0 = p.s2[size_t(2 * j + 2) * p.s2_h + t];
+        tgt1 = p.s2[size_t(2 * j + 3) * p.s2_h + t];
+      } else {
+        tgt0 = gl_add(p.s2[tn], inj0);
+        tgt1 = gl_add(p.s2[p.s2_h + tn], inj1);
+      }
+      u64 f0 = 0, f1 = 0;
+      for (u32 k = na; k-- > 0;) {
+        u64 g0, g1;
+        mul2(f0, f1, gamma0, gamma1, g0, g1);
+        f0 = gl_add(g0, slots[ls[2 + k] * stride]);
+        f1 = g1;
+      }
+      u64 c0, c1;
+      mul2(gl_add(f0, beta0), gl_add(f1, beta1), gl_sub(tgt0, src0), gl_sub(tgt1, src1), c0, c1);
+      fold2(gl_sub(c0, slots[mslot * stride]), c1);
+      if (j + 1 < p.n_lookups) {
+        src0 = tgt0;
+        src1 = tgt1;
+      }
+      ls += 2 + na;
+    }
+  }
+  const u64 iv = p.zh_inv[qi];
+  p.out[t] = gl_mul(acc0, iv);
+  p.out[nq + t] = gl_mul(acc1, iv);
+}
+
+}  // namespace
+
+// ---- host: lower the compiled node vector to a slot-allocated program
+void build_program(Ctx& ctx, const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                   const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, DProgram& out) {
+  const size_t nn = nodes.size();
+  const uint32_t INF = 0xFFFFFFFFu;
+  std::vector<uint32_t> last_use(nn, 0);
+  std::vector<char> needed(nn, 0);
+  for (auto z : zeros) {
+    needed[z] = 1;
+    last_use[z] = INF;
+  }
+  for (auto& l : lookups) {
+    needed[l.first] = 1;
+    last_use[l.first] = INF;
+    for (auto a : l.second) {
+      needed[a] = 1;
+      last_use[a] = INF;
+    }
+  }
+  for (size_t i = nn; i-- > 0;) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    auto use = [&](uint64_t c) {
+      needed[c] = 1;
+      if (last_use[c] != INF && last_use[c] < i) last_use[c] = (uint32_t)i;
+    };
+    if (n.kind == OP_ADD || n.kind == OP_SUB || n.kind == OP_MUL) {
+      use(n.a);
+      use(n.b);
+    } else if (n.kind == OP_NEG) {
+      use(n.a);
+    }
+  }
+  std::vector<uint32_t> slot_of(nn, INF), free_slots, code;
+  std::vector<u64> consts;
+  uint32_t n_slots = 0;
+  for (size_t i = 0; i < nn; i++) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    uint32_t a = 0, b = 0;
+    switch (n.kind) {
+      case OP_CONST:
+        a = (uint32_t)consts.size();
+        consts.push_back(n.a);
+        break;
+      case OP_VAR:
+        a = n.source | (n.offset << 8);
+        b = (uint32_t)n.a;
+        break;
+      case OP_PUBLIC: a = (uint32_t)n.a; break;
+      case OP_ADD:
+      case OP_SUB:
+      case OP_MUL:
+        a = slot_of[n.a];
+        b = slot_of[n.b];
+        break;
+      case OP_NEG: a = slot_of[n.a]; break;
+      default: break;
+    }
+    // operands whose last use is this node free their slots (the destination may reuse them: reads precede the write)
+    auto maybe_free = [&](uint64_t c) {
+      if (last_use[c] == i && slot_of[c] != INF) {
+        free_slots.push_back(slot_of[c]);
+        slot_of[c] = INF;
+      }
+    };
+    if (n.kind == OP_ADD || n.kind == OP_SUB || n.kind == OP_MUL) {
+      maybe_free(n.a);
+      if (n.b != n.a) maybe_free(n.b);
+    } else if (n.kind == OP_NEG) {
+      maybe_free(n.a);
+    }
+    uint32_t dst;
+    if (!free_slots.empty()) {
+      dst = free_slots.back();
+      free_slots.pop_back();
+    } else {
+      dst = n_slots++;
+    }
+    slot_of[i] = dst;
+    code.push_back(n.kind);
+    code.push_back(dst);
+    code.push_back(a);
+    code.push_back(b);
+    if (last_use[i] == 0 && !(last_use[i] == INF)) {
+      // never used (can only happen for a root-less needed node): keep the slot, harmless
+    }
+  }
+  if (n_slots == 0) n_slots = 1;
+  std::vector<uint32_t> zslots, lslots;
+  for (auto z : zeros) zslots.push_back(slot_of[z]);
+  for (auto& l : lookups) {
+    lslots.push_back(slot_of[l.first]);
+    lslots.push_back((uint32_t)l.second.size());
+    for (auto a : l.second) lslots.push_back(slot_of[a]);
+  }
+  out.n_instr = code.size() / 4;
+  out.n_slots = n_slots;
+  out.n_zeros = zeros.size();
+  out.n_lookups = lookups.size();
+  out.code = DBuf<uint32_t>(ctx, std::max<size_t>(code.size(), 4));
+  out.consts = DBuf<u64>(ctx, std::max<size_t>(consts.size(), 1));
+  out.zero_slots = DBuf<uint32_t>(ctx, std::max<size_t>(zslots.size(), 1));
+  out.lookup_slots = DBuf<uint32_t>(ctx, std::max<size_t>(lslots.size(), 1));
+  if (!code.empty()) ctx.h2d(out.code.p, code.data(), code.size() * 4);
+  if (!consts.empty()) ctx.h2d(out.consts.p, consts.data(), consts.size() * 8);
+  if (!zslots.empty()) ctx.h2d(out.zero_slots.p, zslots.data(), zslots.size() * 4);
+  if (!lslots.empty()) ctx.h2d(out.lookup_slots.p, lslots.data(), lslots.size() * 4);
+  ctx.sync();
+}
+
+void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* out) {
+  const unsigned lognq = a.log_n + a.log_q;
+  if (lognq > 26) throw std::runtime_error("quotient domain larger than 2^26 is not supported");
+  const size_t n = size_t(1) << a.log_n, q = size_t(1) << a.log_q, nq = n * q;
+  // Z_H on the coset: x^n - 1 = 7^n w_q^j - 1, period q (src/prover.rs:775 -> p3 selectors_on_coset)
+  std::vector<u64> zh(q), zhi(q);
+  u64 s_pow_n = gl_exp_pow2(GL_GEN, a.log_n), wq = gl_two_adic_generator(a.log_q), xx = 1;
+  for (size_t j = 0; j < q; j++) {
+    zh[j] = gl_sub(gl_mul(s_pow_n, xx), 1);
+    zhi[j] = gl_inv(zh[j]);
+    xx = gl_mul(xx, wq);
+  }
+  const size_t k = prog.constraint_count;
+  std::vector<E2> arev(k);
+  E2 ap = e2(1);
+  for (size_t i = 0; i < k; i++) {
+    arev[k - 1 - i] = ap;
+    ap = e2_mul(ap, a.alpha);
+  }
+  DBuf<u64> dzh(ctx, 2 * q);
+  DBuf<E2> darev(ctx, k);
+  ctx.h2d(dzh.p, zh.data(), q * 8);
+  ctx.h2d(dzh.p + q, zhi.data(), q * 8);
+  ctx.h2d(darev.p, arev.data(), k * sizeof(E2));
+
+  QParams p;
+  p.pre = a.pre;
+  p.s1 = a.s1;
+  p.s2 = a.s2;
+  p.pre_h = a.pre_h;
+  p.s1_h = a.s1_h;
+  p.s2_h = a.s2_h;
+  p.log_n = a.log_n;
+  p.log_q = a.log_q;
+  memcpy(p.publics, a.publics, sizeof(p.publics));
+  u64 g = gl_two_adic_generator(a.log_n);
+  u64 inj_norm = gl_inv(gl_mul((u64)n % GL_P, g));  // src/prover.rs:782-784
+  p.delta_scaled[0] = gl_mul(gl_sub(a.publics[6], a.publics[4]), inj_norm);
+  p.delta_scaled[1] = gl_mul(gl_sub(a.publics[7], a.publics[5]), inj_norm);
+  p.g_inv = gl_inv(g);
+  p.zh = dzh.p;
+  p.zh_inv = dzh.p + q;
+  p.alpha_rev = darev.p;
+  p.code = prog.code.p;
+  p.consts = prog.consts.p;
+  p.zero_slots = prog.zero_slots.p;
+  p.lookup_slots = prog.lookup_slots.p;
+  p.n_instr = (uint32_t)prog.n_instr;
+  p.n_zeros = (uint32_t)prog.n_zeros;
+  p.n_lookups = (uint32_t)prog.n_lookups;
+  p.n_slots = (uint32_t)prog.n_slots;
+  p.t0 = ctx.tw0;
+  p.t1 = ctx.tw1;
+  p.out = out;
+  p.scratch = nullptr;
+
+  const double bytes = double(nq) * 8.0 * (2.0 * (prog.main_w + prog.s2_w + prog.pre_w) + 2.0);
+  unsigned threads = 256;
+  while (threads > 64 && prog.n_slots * threads * 8 > 64 * 1024) threads >>= 1;
+  if (prog.n_slots * threads * 8 <= 64 * 1024) {
+    p.row0 = 0;
+    p.rows = nq;
+    hipEvent_t ev = ctx.prof_begin(K_QUOTIENT);
+    hipLaunchKernelGGL(quotient_k<true>, dim3((unsigned)((nq + threads - 1) / threads)), dim3(threads), prog.n_slots * threads * 8,
+                       ctx.stream, p);
+    ctx.prof_end(K_QUOTIENT, ev, bytes);
+  } else {
+    // global scratch in batches of rows so that it stays below ~1 GiB
+    size_t batch = (size_t(1) << 30) / (prog.n_slots * 8);
+    batch = std::max<size_t>(256, batch & ~size_t(255));
+    batch = std::min(batch, nq);
+    DBuf<u64> scratch(ctx, batch * prog.n_slots);
+    p.scratch = scratch.p;
+    for (size_t r0 = 0; r0 < nq; r0 += batch) {
+      p.row0 = r0;
+      p.rows = std::min(batch, nq - r0);
+      hipEvent_t ev = ctx.prof_begin(K_QUOTIENT);
+      hipLaunchKernelGGL(quotient_k<false>, dim3((unsigned)((p.rows + 255) / 256)), dim3(256), 0, ctx.stream, p);
+      ctx.prof_end(K_QUOTIENT, ev, bytes * double(p.rows) / double(nq));
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace msamd

@@ -1,0 +1,149 @@
+"""GPU parity tests, kernel level: every HIP entry point of include/mstark.h against the oracle on the same
+seeded inputs (bit-exact: all arithmetic is integer). Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+def test_field_ops(ctx, oracle):
+    rng = np.random.default_rng(1)
+    a = rand_field(rng, 4096)
+    b = rand_field(rng, 4096)
+    ai, bi = [int(x) for x in a], [int(x) for x in b]
+    assert [int(x) for x in ctx.field_op(0, a, b)] == [(x + y) % P for x, y in zip(ai, bi)]
+    assert [int(x) for x in ctx.field_op(1, a, b)] == [(x - y) % P for x, y in zip(ai, bi)]
+    assert [int(x) for x in ctx.field_op(2, a, b)] == [(x * y) % P for x, y in zip(ai, bi)]
+    nz = np.where(a == 0, np.uint64(5), a)
+    assert [int(x) for x in ctx.field_op(3, nz)] == [pow(int(x), P - 2, P) for x in nz]
+    # Ext2: (a0 + a1 X)(b0 + b1 X) mod X^2 - 7
+    e = ctx.field_op(4, a, b).reshape(-1, 2)
+    for k in range(0, 2048, 97):
+        a0, a1, b0, b1 = ai[2 * k], ai[2 * k + 1], bi[2 * k], bi[2 * k + 1]
+        assert (int(e[k, 0]), int(e[k, 1])) == ((a0 * b0 + 7 * a1 * b1) % P, (a0 * b1 + a1 * b0) % P)
+    inv = ctx.field_op(5, nz).reshape(-1, 2)
+    prod = ctx.field_op(4, nz, inv.reshape(-1)).reshape(-1, 2)
+    assert np.all(prod[:, 0] == 1) and np.all(prod[:, 1] == 0)
+
+
+@pytest.mark.parametrize("log_h", [0, 1, 2, 5, 8, 11, 12, 13, 16, 20])
+@pytest.mark.parametrize("w", [1, 3])
+def test_dft_batch(ctx, oracle, log_h, w):
+    rng = np.random.default_rng(100 + log_h)
+    m = rand_field(rng, (1 << log_h, w))
+    got = ctx.dft_batch(m)
+    assert np.array_equal(got, oracle.dft_batch(m))
+    back = ctx.dft_batch(got, inverse=True)
+    assert np.array_equal(back, m)
+
+
+# the reference's layout pin: src/prover.rs:975-999 (h in {1,2,4,32,256}, B in {2,4,8}, w in {1,2,7})
+@pytest.mark.parametrize("log_h", [0, 1, 2, 5, 8, 12, 14])
+@pytest.mark.parametrize("log_blowup", [1, 2, 3])
+@pytest.mark.parametrize("w", [1, 2, 7])
+def test_coset_lde_matches_commit_transform(ctx, oracle, log_h, log_blowup, w):
+    rng = np.random.default_rng(1000 * log_h + 10 * log_blowup + w)
+    m = rand_field(rng, (1 << log_h, w))
+    assert np.array_equal(ctx.coset_lde_batch(m, log_blowup), oracle.coset_lde_bitrev(m, log_blowup))
+
+
+# src/prover.rs:1006-1041 scenario grid (n in {1,2,4,32,128}, q in {1,2,4}, D in {1,2}) + larger sizes
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 7, 12])
+@pytest.mark.parametrize("log_q", [0, 1, 2])
+@pytest.mark.parametrize("D", [1, 2])
+def test_quotient_lde(ctx, oracle, log_n, log_q, D):
+    rng = np.random.default_rng(7 + log_n * 31 + log_q * 5 + D)
+    q = rand_field(rng, (1 << (log_n + log_q), D))
+    for lb in (1, 2):
+        if lb < log_q:
+            continue
+        want = oracle.lde_from_shifted_coefficients(oracle.shifted_quotient_slices(q, 1 << log_q), lb)
+        assert np.array_equal(ctx.quotient_lde(q, log_n, log_q, lb), want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 63, 64, 65, 1023, 1024, 1025, 2048, 2049, 3072, 5000, 7 * 1024 + 1, 100003])
+def test_blake3_stream(ctx, oracle, n):
+    data = bytes((i * 7 + 3) % 251 for i in range(n))
+    assert ctx.blake3(data) == oracle.hash_bytes(data)
+
+
+@pytest.mark.parametrize("shapes", [
+    [(8, 2), (4, 3), (2, 1)],              # the reference's gen_pcs_refs scenario (src/types.rs:260-275)
+    [(1, 1)],
+    [(64, 5)],
+    [(1024, 14), (1024, 2), (16, 1)],
+    [(256, 130)],                          # rows longer than one BLAKE3 chunk
+    [(64, 300), (64, 1), (8, 129)],
+    [(4096, 26), (1024, 2)],
+])
+@pytest.mark.parametrize("cap_height", [0, 2])
+def test_mmcs_commit_open(pkg, ctx, oracle, shapes, cap_height):
+    rng = np.random.default_rng(len(shapes) * 17 + cap_height)
+    mats = [rand_field(rng, s) for s in shapes]
+    g = pkg.Mmcs(ctx, mats, cap_height)
+    o = oracle.Mmcs(mats, cap_height)
+    assert g.cap == o.cap
+    maxh = max(s[0] for s in shapes)
+    for index in sorted({0, 1 % maxh, maxh // 2, maxh - 1, 5 % maxh}):
+        gv, gp = g.open(index)
+        ov, op = o.open(index)
+        assert np.array_equal(gv, ov) and gp == op
+        assert o.verify(index, gv, gp, g.cap) == 1
+
+
+@pytest.mark.parametrize("h,L,widths", [(1, 1, [2]), (4, 2, [3, 3]), (256, 1, [2]), (64, 13, [4] + [2] * 12),
+                                        (4096, 13, [4] + [2] * 12), (32, 3, [0, 5, 1]), (8192, 9, [1] * 9)])
+def test_stage2_trace(ctx, oracle, h, L, widths):
+    rng = np.random.default_rng(h + L)
+    offs = np.concatenate([[0], np.cumsum(widths)]).astype(np.uint64)
+    mult = rand_field(rng, (h, L))
+    args = rand_field(rng, (h, max(int(offs[-1]), 1)))[:, : int(offs[-1])]
+    beta, gamma, acc = [int(x) for x in rand_field(rng, 2)], [int(x) for x in rand_field(rng, 2)], [3, 9]
+    gt, ga = ctx.stage2_trace(mult, offs, args, beta, gamma, acc)
+    ot, oa = oracle.stage2_trace(mult, offs, args, beta, gamma, acc)
+    assert ga == oa
+    assert np.array_equal(gt, ot)
+
+
+def test_stage2_no_lookups(ctx, oracle):
+    mult = np.zeros((16, 0), dtype=np.uint64)
+    gt, ga = ctx.stage2_trace(mult, np.zeros(1, dtype=np.uint64), np.zeros((16, 0), dtype=np.uint64), [1, 2], [3, 4], [5, 6])
+    assert ga == (5, 6) and gt.shape == (16, 2) and not gt.any()
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 256, 257, 5000, 70000])
+def test_claims_accumulator(ctx, oracle, fe, n):
+    rng = np.random.default_rng(n)
+    claims = [list(map(int, rand_field(rng, int(rng.integers(0, 6))))) for _ in range(n)]
+    packed = fe.pack_claims(claims)
+    beta, gamma = [11, 12], [13, 14]
+    assert ctx.claims_accumulator(packed, beta, gamma) == oracle.claims_accumulator(packed, beta, gamma)
+
+
+def _systems(pkg, ctx, oracle, fe, inputs, params):
+    g = pkg.System.new(ctx, params, inputs)
+    return g, oracle.System(g.blob)
+
+
+@pytest.mark.parametrize("which,log_n", [("pyth", 2), ("pyth", 6), ("evenodd", 2), ("evenodd", 5), ("u32", 3), ("u32", 8), ("u32", 12)])
+def test_quotient_values(pkg, ctx, oracle, fe, which, log_n):
+    rng = np.random.default_rng(log_n)
+    inputs = {"pyth": fe.pythagorean_inputs, "evenodd": fe.even_odd_inputs, "u32": fe.u32_add_system_inputs}[which]()
+    params = fe.bench_params()
+    g, o = _systems(pkg, ctx, oracle, fe, inputs, params)
+    for ci in range(len(inputs)):
+        info = g.circuit_info(ci)
+        assert info == o.circuit_info(ci)
+        ln = 8 if info["pre_height"] else log_n   # byte table is fixed at 256 rows
+        lq = info["quotient_degree"].bit_length() - 1
+        N = 1 << (ln + lq)
+        pre = rand_field(rng, (N, info["pre_width"])) if info["pre_width"] else None
+        s1 = rand_field(rng, (N, info["main_width"]))
+        s2 = rand_field(rng, (N, info["stage2_width"]))
+        publics = rand_field(rng, 8)
+        alpha = rand_field(rng, 2)
+        want = oracle.quotient_values(o, ci, publics, ln, lq, pre, s1, s2, alpha)
+        got = g.quotient_values(ci, publics, ln, lq, pre, s1, s2, alpha)
+        assert np.array_equal(got, want)
