@@ -118,7 +118,7 @@ def main():
     # ---- warmup (untimed); the first warmup step is profiled per kernel class to pick the dominant kernel
     names = ctx.kernel_names()
     proof = None
-    dominant = "ntt_strided"
+    dominant = "ntt8s_dif"
     table = {}
     for i in range(max(args.warmup, 1)):
         if i == 0:
@@ -211,31 +211,35 @@ def main():
 def cpu_baseline(fe, blob, log_adds):
     """The oracle (multi-threaded C++ restatement, kind "port") timed on this box's host cores over a bounded
     sample of the same workload; it is a reported baseline, not the thing measured or shipped."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     oracle = load_oracle()
     osys = oracle.System(blob)
     traces, claims = fe.u32_add_bench_witness(1 << log_adds)
     packed = fe.pack_claims(claims)
     rows = sum(t.shape[0] for t in traces)
-    osys.prove(traces, packed)  # warm-up (twiddle tables, thread pool)
-    best = None
+    # the restatement's parallel loops stop scaling well before the box's full thread count: try a few pool sizes
+    # and report the best one (a baseline should be as fast as this code can be made to run here)
+    best, best_cores, runs = None, 1, 0
     t_all = time.time()
-    runs = 0
-    while runs < 3 and time.time() - t_all < 25:
-        t = time.time()
-        _, tm = osys.prove(traces, packed, want_times=True)
-        dt = tm["total"]
-        best = dt if best is None else min(best, dt)
-        runs += 1
+    for cores in sorted({c for c in (16, 32, 64, avail) if c <= avail}):
+        oracle.set_threads(cores)
+        osys.prove(traces, packed)  # warm-up (twiddle tables, thread pool)
+        for _ in range(2):
+            if time.time() - t_all > 28:
+                break
+            _, tm = osys.prove(traces, packed, want_times=True)
+            runs += 1
+            if best is None or tm["total"] < best:
+                best, best_cores = tm["total"], cores
     return {
         "value": rows / best,
         "unit": "rows/s",
-        "cores": cores,
+        "cores": best_cores,
         "kind": "port",
-        "sample": "oracle C++ restatement (OpenMP, %d threads), same circuit/params, 2^%d additions per proof, "
-                  "best of %d proofs, %.3f s/proof (witness prep excluded)" % (cores, log_adds, runs, best),
+        "sample": "oracle C++ restatement (OpenMP, best of 16/32/64/%d threads = %d), same circuit/params, 2^%d "
+                  "additions per proof, best of %d proofs, %.3f s/proof (witness prep excluded)" % (
+                      avail, best_cores, log_adds, runs, best),
     }
 
 

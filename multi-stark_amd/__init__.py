@@ -213,9 +213,10 @@ class Proof:
 class SystemWitness:
     """Device-resident SystemWitness + claims (ms_witness). Built by `System.witness`."""
 
-    def __init__(self, handle, rows):
+    def __init__(self, handle, rows, system):
         self.h = handle
         self.rows = rows  # sum of active trace heights
+        self.system = system  # keeps System (and its Context) alive: device buffers return to that context's pool
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -280,7 +281,7 @@ class System:
         data = data if data.size else np.zeros(1, dtype=np.uint64)
         h = C.c_void_p()
         _check(lib().ms_witness_create(self.h, tptr, _p(hs), mptr, aptr, C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(h)))
-        return SystemWitness(h, int(hs.sum()))
+        return SystemWitness(h, int(hs.sum()), self)
 
     def prove_multiple_claims(self, witness, want_times=False):
         cap = getattr(self, "_proof_cap", 1 << 21)

@@ -3,7 +3,7 @@
 
 namespace msamd {
 
-static const char* KNAMES[K_COUNT] = {"ntt_strided", "ntt_contig", "leaf_hash", "compress_layer", "stage2", "quotient",
+static const char* KNAMES[K_COUNT] = {"ntt_lds_strided", "ntt_lds_contig", "ntt12_dif", "ntt12_dit", "ntt8s_dif", "ntt8s_dit", "leaf_hash", "compress_layer", "stage2", "quotient",
                                       "bary_eval",   "deep_reduce", "fri_fold", "transpose",      "other"};
 const char* kernel_name(int id) { return id >= 0 && id < K_COUNT ? KNAMES[id] : "?"; }
 
@@ -65,6 +65,24 @@ Ctx::Ctx(int dev) : device(dev) {
   tw1 = t + T;
   tw0i = t + 2 * T;
   tw1i = t + 3 * T;
+  // compact tables for roots of order 2^1 .. 2^12
+  std::vector<u64> cf(4096, 0), ci(4096, 0);
+  for (unsigned r = 1; r <= 12; r++) {
+    u64 w = gl_two_adic_generator(r), wi = gl_inv(w), x = 1, y = 1;
+    size_t off = (size_t(1) << (r - 1)) - 1;
+    for (size_t i = 0; i < (size_t(1) << (r - 1)); i++) {
+      cf[off + i] = x;
+      ci[off + i] = y;
+      x = gl_mul(x, w);
+      y = gl_mul(y, wi);
+    }
+  }
+  u64* tc = nullptr;
+  HIP_CHECK(hipMalloc(&tc, 2 * 4096 * sizeof(u64)));
+  HIP_CHECK(hipMemcpy(tc, cf.data(), 4096 * sizeof(u64), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(tc + 4096, ci.data(), 4096 * sizeof(u64), hipMemcpyHostToDevice));
+  twc = tc;
+  twci = tc + 4096;
 }
 
 Ctx::~Ctx() {
@@ -79,6 +97,7 @@ Ctx::~Ctx() {
   for (auto& kv : pool_live) (void)hipFree(kv.first);
   for (auto& kv : lde_scales) (void)hipFree(kv.second);
   if (tw0) (void)hipFree(tw0);
+  if (twc) (void)hipFree(twc);
   (void)hipStreamDestroy(stream);
 }
 

@@ -50,13 +50,28 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
 
 GL_HD u64 gl_mul(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u64 lo = a * b;
-  u64 hi = __umul64hi(a, b);
+  // 64x64 -> 128 as four 32x32+64 multiply-adds (v_mad_u64_u32), then x = hi*2^64 + lo with hi = h1:h0 reduces as
+  // lo - h1 + (h0 << 32) - h0; every step is a 64-bit add/sub whose carry/borrow is folded back as -/+ (2^32 - 1).
+  // Written limb-wise so that the compiler does not turn (h0 << 32) - h0 back into a fifth multiply.
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p00 = (u64)a0 * b0;
+  u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+  u64 p10 = (u64)a1 * b0 + (u32)p01;
+  u64 hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  u64 lo = (p10 << 32) | (u32)p00;
+  u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+  u64 A = lo - h1;
+  A -= (u64)(0u - (u32)(lo < (u64)h1));
+  u64 B = A + ((u64)h0 << 32);
+  B += (u64)(0u - (u32)(B < A));
+  u64 C = B - h0;
+  C -= (u64)(0u - (u32)(B < (u64)h0));
+  u64 s = C + GL_EPS;  // C >= p  <=>  C + (2^32 - 1) overflows
+  return s < C ? s : C;
 #else
   unsigned __int128 x = (unsigned __int128)a * b;
-  u64 lo = (u64)x, hi = (u64)(x >> 64);
+  return gl_reduce128((u64)x, (u64)(x >> 64));
 #endif
-  return gl_reduce128(lo, hi);
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // multiply by a small constant c < 2^32: the high word is < 2^32 so only the 2^64 = 2^32 - 1 fold is needed

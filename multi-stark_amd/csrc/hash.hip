@@ -155,6 +155,105 @@ __global__ __launch_bounds__(256) void compress_layer_k(const Digest* __restrict
   }
 }
 
+
+// ---- fused upper levels. Layers are stored back to back (leaf layer first), so the parents of a layer of
+// `len` digests start right after it.
+__device__ __forceinline__ void lds_store_digest(u32* sh, u32 idx, const u32 cv[8]) {
+  uint4* q = reinterpret_cast<uint4*>(sh + idx * 8);
+  q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+  q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+__device__ __forceinline__ void lds_load_digest(const u32* sh, u32 idx, u32 cv[8]) {
+  const uint4* q = reinterpret_cast<const uint4*>(sh + idx * 8);
+  uint4 a = q[0], b = q[1];
+  cv[0] = a.x;
+  cv[1] = a.y;
+  cv[2] = a.z;
+  cv[3] = a.w;
+  cv[4] = b.x;
+  cv[5] = b.y;
+  cv[6] = b.z;
+  cv[7] = b.w;
+}
+
+// three levels per launch: a workgroup turns 2048 children into 1024 + 512 + 256 ancestors (no injection)
+__global__ __launch_bounds__(256) void compress3_k(const Digest* __restrict__ child, Digest* __restrict__ l1, Digest* __restrict__ l2,
+                                                   Digest* __restrict__ l3) {
+  __shared__ __attribute__((aligned(16))) u32 sh1[1024 * 8];
+  __shared__ __attribute__((aligned(16))) u32 sh2[512 * 8];
+  const u32 t = threadIdx.x;
+  const size_t b = blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    u32 i = t + 256 * k;
+    u32 l[8], r[8], d[8];
+    load_digest(child + b * 2048 + 2 * i, l);
+    load_digest(child + b * 2048 + 2 * i + 1, r);
+    b3_compress_pair_root(l, r, d);
+    store_digest(l1 + b * 1024 + i, d);
+    lds_store_digest(sh1, i, d);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    u32 i = t + 256 * k;
+    u32 l[8], r[8], d[8];
+    lds_load_digest(sh1, 2 * i, l);
+    lds_load_digest(sh1, 2 * i + 1, r);
+    b3_compress_pair_root(l, r, d);
+    store_digest(l2 + b * 512 + i, d);
+    lds_store_digest(sh2, i, d);
+  }
+  __syncthreads();
+  {
+    u32 l[8], r[8], d[8];
+    lds_load_digest(sh2, 2 * t, l);
+    lds_load_digest(sh2, 2 * t + 1, r);
+    b3_compress_pair_root(l, r, d);
+    store_digest(l3 + b * 256 + t, d);
+  }
+}
+
+// every remaining level of a tree whose current layer has len <= 1024 digests (no injection), one workgroup
+__global__ __launch_bounds__(256) void tree_tail_k(Digest* __restrict__ layer, u32 len) {
+  __shared__ __attribute__((aligned(16))) u32 sh[1024 * 8];
+  const u32 t = threadIdx.x;
+  for (u32 i = t; i < len; i += 256) {
+    u32 d[8];
+    load_digest(layer + i, d);
+    lds_store_digest(sh, i, d);
+  }
+  __syncthreads();
+  Digest* out = layer + len;
+  for (u32 n = len >> 1; n >= 1; n >>= 1) {
+    u32 d0[8], d1[8];
+    const bool h0 = t < n, h1 = t + 256 < n;
+    if (h0) {
+      u32 l[8], r[8];
+      lds_load_digest(sh, 2 * t, l);
+      lds_load_digest(sh, 2 * t + 1, r);
+      b3_compress_pair_root(l, r, d0);
+    }
+    if (h1) {
+      u32 l[8], r[8];
+      lds_load_digest(sh, 2 * (t + 256), l);
+      lds_load_digest(sh, 2 * (t + 256) + 1, r);
+      b3_compress_pair_root(l, r, d1);
+    }
+    __syncthreads();
+    if (h0) {
+      lds_store_digest(sh, t, d0);
+      store_digest(out + t, d0);
+    }
+    if (h1) {
+      lds_store_digest(sh, t + 256, d1);
+      store_digest(out + t + 256, d1);
+    }
+    __syncthreads();
+    out += n;
+  }
+}
+
 // ---- whole-stream BLAKE3. The stream is `prefix` (prefix_len bytes, any alignment) followed by `nwords`
 // little-endian u64 words (8-byte aligned), which is how the transcript up to the claims is shaped: a short
 // host-built prefix, then the length-prefixed claims as field elements.
@@ -248,15 +347,57 @@ void merkle_alloc(Ctx& ctx, DTree& t, size_t maxh) {
   t.digests = DBuf<Digest>(ctx, tot);
 }
 
-void merkle_compress_plain(Ctx& ctx, DTree& t) {
-  for (size_t li = 1; li < t.layer_len.size(); li++) {
-    size_t n = t.layer_len[li];
+// levels li_begin.. of tree t, given which layers receive an injected group (inject[li] = (first, total_w, count))
+struct InjectAt {
+  size_t first = 0;
+  u32 total_w = 0;
+  size_t count = 0;
+};
+static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, const MatRef* drefs) {
+  const size_t L = t.layer_len.size();
+  size_t last_inject = 0;
+  for (size_t li = 1; li < L; li++)
+    if (inj[li].count) last_inject = li;
+  size_t li = 1;
+  while (li < L) {
+    const size_t child_len = t.layer_len[li - 1];
+    Digest* child = t.digests.p + t.layer_off[li - 1];
+    if (child_len <= 1024 && li > last_inject) {
+      hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
+      hipLaunchKernelGGL(tree_tail_k, dim3(1), dim3(256), 0, ctx.stream, child, (u32)child_len);
+      ctx.prof_end(K_COMPRESS, ev, 96.0 * double(child_len));
+      break;
+    }
+    if (child_len >= 2048 && li + 2 < L && !inj[li].count && !inj[li + 1].count && !inj[li + 2].count) {
+      hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
+      hipLaunchKernelGGL(compress3_k, dim3((unsigned)(child_len / 2048)), dim3(256), 0, ctx.stream, (const Digest*)child,
+                         t.digests.p + t.layer_off[li], t.digests.p + t.layer_off[li + 1], t.digests.p + t.layer_off[li + 2]);
+      ctx.prof_end(K_COMPRESS, ev, 32.0 * double(child_len) * 1.875);
+      li += 3;
+      continue;
+    }
+    const size_t n = t.layer_len[li];
+    Digest* next = t.digests.p + t.layer_off[li];
+    dim3 grid((unsigned)((n + 255) / 256));
     hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
-    hipLaunchKernelGGL((compress_layer_k<false, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream,
-                       t.digests.p + t.layer_off[li - 1], t.digests.p + t.layer_off[li], n, (const MatRef*)nullptr, 0u);
-    ctx.prof_end(K_COMPRESS, ev, double(n) * 96.0);
+    if (inj[li].count == 0)
+      hipLaunchKernelGGL((compress_layer_k<false, false>), grid, dim3(256), 0, ctx.stream, (const Digest*)child, next, n,
+                         (const MatRef*)nullptr, 0u);
+    else if (inj[li].total_w <= 128)
+      hipLaunchKernelGGL((compress_layer_k<true, false>), grid, dim3(256), 0, ctx.stream, (const Digest*)child, next, n,
+                         drefs + inj[li].first, inj[li].total_w);
+    else
+      hipLaunchKernelGGL((compress_layer_k<true, true>), grid, dim3(256), 0, ctx.stream, (const Digest*)child, next, n,
+                         drefs + inj[li].first, inj[li].total_w);
+    ctx.prof_end(K_COMPRESS, ev, double(n) * (96.0 + 8.0 * inj[li].total_w));
+    li++;
   }
   HIP_CHECK(hipGetLastError());
+}
+
+void merkle_compress_plain(Ctx& ctx, DTree& t) {
+  std::vector<InjectAt> inj(t.layer_len.size());
+  build_levels(ctx, t, inj, nullptr);
 }
 
 void merkle_build(Ctx& ctx, DTree& t) {
@@ -300,21 +441,14 @@ void merkle_build(Ctx& ctx, DTree& t) {
       hipLaunchKernelGGL(leaf_hash_k<true>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.digests.p);
     ctx.prof_end(K_LEAF_HASH, ev, double(maxh) * (8.0 * tw + 32.0));
   }
+  std::vector<InjectAt> inj(t.layer_len.size());
   for (size_t li = 1; li < t.layer_len.size(); li++) {
-    size_t n = t.layer_len[li];
-    take_group(n, first, tw, count);
-    const Digest* prev = t.digests.p + t.layer_off[li - 1];
-    Digest* next = t.digests.p + t.layer_off[li];
-    dim3 grid((unsigned)((n + 255) / 256));
-    hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
-    if (count == 0)
-      hipLaunchKernelGGL((compress_layer_k<false, false>), grid, dim3(256), 0, ctx.stream, prev, next, n, (const MatRef*)nullptr, 0u);
-    else if (tw <= 128)
-      hipLaunchKernelGGL((compress_layer_k<true, false>), grid, dim3(256), 0, ctx.stream, prev, next, n, drefs.p + first, tw);
-    else
-      hipLaunchKernelGGL((compress_layer_k<true, true>), grid, dim3(256), 0, ctx.stream, prev, next, n, drefs.p + first, tw);
-    ctx.prof_end(K_COMPRESS, ev, double(n) * (96.0 + 8.0 * tw));
+    take_group(t.layer_len[li], first, tw, count);
+    inj[li].first = first;
+    inj[li].total_w = tw;
+    inj[li].count = count;
   }
+  build_levels(ctx, t, inj, drefs.p);
   if (pos != nm) throw std::runtime_error("merkle_build: matrix height not reached");
   HIP_CHECK(hipGetLastError());
 }

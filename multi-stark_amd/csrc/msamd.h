@@ -32,8 +32,12 @@ struct Digest {
 
 // kernel classes for which launch durations can be sampled with HIP events (bench.py roofline leg)
 enum KernelId : int {
-  K_NTT_STRIDED = 0,
+  K_NTT_STRIDED = 0,  // generic LDS radix-2 passes (sizes the register kernels do not cover)
   K_NTT_CONTIG,
+  K_NTT12_DIF,        // register radix-16 kernels: 12-bit contiguous pass, 8-bit strided pass
+  K_NTT12_DIT,
+  K_NTT8S_DIF,
+  K_NTT8S_DIT,
   K_LEAF_HASH,
   K_COMPRESS,
   K_STAGE2,
@@ -57,6 +61,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   u64 *tw0 = nullptr, *tw1 = nullptr, *tw0i = nullptr, *tw1i = nullptr;
+  // compact per-order tables: table r (root of order 2^r, r = 1..12) holds w^i for i < 2^(r-1) at offset 2^(r-1) - 1
+  u64 *twc = nullptr, *twci = nullptr;
   // pooled device memory: exact-size buckets, reused across proofs
   std::multimap<size_t, void*> pool_free;
   std::map<void*, size_t> pool_live;
@@ -248,5 +254,7 @@ struct GatherReq {
   uint64_t out_off;   // byte offset in the output buffer
 };
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes);
+// proof-of-work search on the device (single-chunk transcripts); false = not applicable, use the host loop
+bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out);
 
 }  // namespace msamd

@@ -124,16 +124,206 @@ __global__ __launch_bounds__(256) void ntt_strided_k(const u64* __restrict__ src
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Register radix-16 kernels. A thread owns 16 elements whose positions differ in 4 index bits, runs those 4
+// radix-2 stages in registers (32 butterflies, 15 twiddle loads from the compact per-order tables) and trades
+// elements with the rest of the 256-thread workgroup through LDS between rounds. A 4096-element tile therefore
+// needs 3 rounds for a 12-bit contiguous pass and 2 rounds for an 8-bit strided pass, instead of 12 / 8
+// LDS round trips with a barrier each. All global accesses are coalesced runs of >= 128 bytes.
+
+// x[j] sits at position lo + (j << shift) of a block of 16 << shift positions; runs the stages over bits
+// [shift, shift + 4). Root of the stage with half-size `half` (in j units) has order 2 * half << shift.
+template <bool DIT>
+__device__ __forceinline__ void reg_stages16(u64 (&x)[16], u32 lo, unsigned shift, const u64* __restrict__ twc) {
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int loghalf = DIT ? s : 3 - s;
+    const int half = 1 << loghalf;
+    const unsigned r = loghalf + 1 + shift;                  // root order 2^r
+    const u64* tab = twc + ((1u << (r - 1)) - 1) + lo;        // table r, entry (jl << shift) + lo
+#pragma unroll
+    for (int jl = 0; jl < half; jl++) {
+      const u64 w = tab[jl << shift];
+#pragma unroll
+      for (int g = 0; g < 8 / half; g++) {
+        const int j0 = g * 2 * half + jl, j1 = j0 + half;
+        u64 a = x[j0], b = x[j1];
+        if (DIT) {
+          u64 t = gl_mul(w, b);
+          x[j0] = gl_add(a, t);
+          x[j1] = gl_sub(a, t);
+        } else {
+          x[j0] = gl_add(a, b);
+          x[j1] = gl_mul(gl_sub(a, b), w);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ u32 pad_hi(u32 e) { return e + ((e >> 8) << 4); }  // 16 spare slots per 256
+__device__ __forceinline__ u32 pad_lo(u32 e) { return e + (e >> 4); }         // 1 spare slot per 16
+constexpr int NTT12_LDS = 4096 + 256 + 16;
+
+// 12-bit contiguous pass over one 4096-element tile (bits 11..0 of the position inside the tile).
+template <bool DIT>
+__global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logn,
+                                               const u64* __restrict__ twc, unsigned src_div, const u64* __restrict__ scale,
+                                               u64 out_mul) {
+  __shared__ u64 sm[NTT12_LDS];
+  const size_t n = size_t(1) << logn;
+  const size_t col = blockIdx.y, off = size_t(blockIdx.x) << 12;
+  const u64* s = src + (col / src_div) * n + off;
+  const u64* sc = scale ? scale + (col % src_div) * n + off : nullptr;
+  u64* d = dst + col * n + off;
+  const u32 t = threadIdx.x, a = t >> 4, b = t & 15;
+  u64 x[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    u64 v = s[t + 256 * j];
+    if (sc) v = gl_mul(v, sc[t + 256 * j]);
+    x[j] = v;
+  }
+  if (!DIT) {
+    reg_stages16<false>(x, t, 8, twc);  // bits 11..8
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_hi(t + 256 * j)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_hi(a * 256 + 16 * j + b)];
+    reg_stages16<false>(x, b, 4, twc);  // bits 7..4
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_lo(a * 256 + 16 * j + b)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(16 * t + j)];
+    reg_stages16<false>(x, 0, 0, twc);  // bits 3..0
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_lo(16 * t + j)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(t + 256 * j)];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_lo(t + 256 * j)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(16 * t + j)];
+    reg_stages16<true>(x, 0, 0, twc);  // bits 0..3
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_lo(16 * t + j)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(a * 256 + 16 * j + b)];
+    reg_stages16<true>(x, b, 4, twc);  // bits 4..7
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_hi(a * 256 + 16 * j + b)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_hi(t + 256 * j)];
+    reg_stages16<true>(x, t, 8, twc);  // bits 8..11
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    u64 v = x[j];
+    if (out_mul != 1) v = gl_mul(v, out_mul);
+    d[t + 256 * j] = v;
+  }
+}
+
+// 8-bit strided pass: sub-transforms of 256 points at stride S = 2^logS inside blocks of 2^(8 + logS); a tile is
+// 256 (h) x 16 (l) with l contiguous in memory. Includes the four-step inter-pass twiddle w_B^{l * bitrev8(h)}.
+template <bool DIT>
+__global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
+                                               const u64* __restrict__ twc, const u64* __restrict__ t0,
+                                               const u64* __restrict__ t1, unsigned src_div, const u64* __restrict__ scale,
+                                               u64 out_mul) {
+  __shared__ u64 sm[NTT12_LDS];
+  const size_t n = size_t(1) << logn;
+  const unsigned logB = 8 + logS;
+  const unsigned tiles = 1u << (logS - 4);
+  const size_t col = blockIdx.y;
+  const u32 tile = blockIdx.x & (tiles - 1);
+  const size_t blk = blockIdx.x >> (logS - 4);
+  const u32 l0 = tile << 4;
+  const size_t base = blk << logB;
+  const u64* s = src + (col / src_div) * n + base;
+  const u64* sc = scale ? scale + (col % src_div) * n + base : nullptr;
+  u64* d = dst + col * n + base;
+  const u32 t = threadIdx.x, hq = t >> 4, l = t & 15;  // hq: low 4 bits of h in the strided round, high 4 in the other
+  const u32 lg = l0 + l;
+  const unsigned esh = TW_LOG - logB;
+  const u32 rev_hq = bitrev32(hq, 4);
+  u64 x[16];
+  if (!DIT) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      size_t pos = (size_t(hq + 16 * j) << logS) + lg;
+      u64 v = s[pos];
+      if (sc) v = gl_mul(v, sc[pos]);
+      x[j] = v;
+    }
+    reg_stages16<false>(x, hq, 4, twc);  // h bits 7..4
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_hi((hq + 16 * j) * 16 + l)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq * 16 + j) * 16 + l)];
+    reg_stages16<false>(x, 0, 0, twc);  // h bits 3..0
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      // h = hq * 16 + j, bitrev8(h) = bitrev4(j) * 16 + bitrev4(hq)
+      const u32 rev = (u32)(((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) << 4) + rev_hq;
+      u64 v = gl_mul(x[j], tw_lookup(t0, t1, (lg * rev) << esh));
+      if (out_mul != 1) v = gl_mul(v, out_mul);
+      d[(size_t(hq * 16 + j) << logS) + lg] = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const u32 rev = (u32)(((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) << 4) + rev_hq;
+      u64 v = s[(size_t(hq * 16 + j) << logS) + lg];
+      x[j] = gl_mul(v, tw_lookup(t0, t1, (lg * rev) << esh));
+    }
+    reg_stages16<true>(x, 0, 0, twc);  // h bits 0..3
+#pragma unroll
+    for (int j = 0; j < 16; j++) sm[pad_hi((hq * 16 + j) * 16 + l)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq + 16 * j) * 16 + l)];
+    reg_stages16<true>(x, hq, 4, twc);  // h bits 4..7
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      u64 v = x[j];
+      if (out_mul != 1) v = gl_mul(v, out_mul);
+      d[(size_t(hq + 16 * j) << logS) + lg] = v;
+    }
+  }
+}
+
 struct Plan {
   unsigned K;
   std::vector<unsigned> bits;  // strided passes, top first
 };
 Plan make_plan(unsigned logn) {
   Plan p;
-  p.K = logn < 11 ? logn : 11;
-  unsigned R = logn - p.K;
-  unsigned m = (R + 7) / 8;
-  for (unsigned i = 0; i < m; i++) p.bits.push_back(R / m + (i < R % m ? 1 : 0));
+  if (logn >= 12) {
+    // register kernels: 12-bit contiguous pass, 8-bit strided passes first, the remainder on the generic kernel
+    p.K = 12;
+    unsigned R = logn - 12;
+    while (R > 8) {
+      p.bits.push_back(8);
+      R -= 8;
+    }
+    if (R) p.bits.push_back(R);
+    return p;
+  }
+  p.K = logn;
   return p;
 }
 
@@ -141,6 +331,16 @@ template <int DIT>
 void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned logB, unsigned logn, size_t ncols,
                     bool inverse, unsigned src_div, const u64* scale, u64 out_mul) {
   unsigned logS = logB - k;
+  if (k == 8 && logS >= 4) {
+    size_t gx8 = (size_t(1) << (logS - 4)) << (logn - logB);
+    const int id = DIT ? K_NTT8S_DIT : K_NTT8S_DIF;
+    hipEvent_t ev8 = ctx.prof_begin(id);
+    hipLaunchKernelGGL(ntt8s_k<(DIT != 0)>, dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS, logn,
+                       inverse ? ctx.twci : ctx.twc, inverse ? ctx.tw0i : ctx.tw0, inverse ? ctx.tw1i : ctx.tw1, src_div, scale,
+                       out_mul);
+    ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
+    return;
+  }
   unsigned logT = 12 - k;
   if (logT > logS) logT = logS;
   size_t gx = (size_t(1) << (logS - logT)) << (logn - logB);
@@ -156,6 +356,14 @@ template <int DIT>
 void launch_contig(Ctx& ctx, const u64* src, u64* dst, unsigned K, unsigned logn, size_t ncols, bool inverse,
                    unsigned src_div, const u64* scale, u64 out_mul) {
   dim3 grid((unsigned)(size_t(1) << (logn - K)), (unsigned)ncols);
+  if (K == 12) {
+    const int id = DIT ? K_NTT12_DIT : K_NTT12_DIF;
+    hipEvent_t ev12 = ctx.prof_begin(id);
+    hipLaunchKernelGGL(ntt12_k<(DIT != 0)>, grid, dim3(256), 0, ctx.stream, src, dst, logn, inverse ? ctx.twci : ctx.twc, src_div,
+                       scale, out_mul);
+    ctx.prof_end(id, ev12, 16.0 * double(ncols) * double(size_t(1) << logn));
+    return;
+  }
   unsigned threads = K >= 9 ? 256 : 64;
   hipEvent_t ev = ctx.prof_begin(K_NTT_CONTIG);
   hipLaunchKernelGGL(ntt_contig_k<DIT>, grid, dim3(threads), size_t(8) << K, ctx.stream, src, dst, K, logn,

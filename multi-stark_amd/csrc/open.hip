@@ -104,12 +104,18 @@ __global__ __launch_bounds__(256) void bary_partial_k(const u64* __restrict__ ma
     __syncthreads();
   }
 }
-__global__ void bary_final_k(const E2* __restrict__ partial, size_t nblk, u32 w, int np, E2* __restrict__ out) {
-  size_t id = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // over c * np + p
-  if (id >= size_t(w) * np) return;
-  E2 s = e2(0);
-  for (size_t b = 0; b < nblk; b++) s = e2_add(s, partial[b * w * np + id]);
-  out[id] = s;
+// one wave per output (c, p): strided sum over the blocks' partials, then a wave reduction
+__global__ __launch_bounds__(64) void bary_final_k(const E2* __restrict__ partial, size_t nblk, u32 w, int np, E2* __restrict__ out) {
+  const size_t id = blockIdx.x;  // over c * np + p
+  u64 s0 = 0, s1 = 0;
+  for (size_t b = threadIdx.x; b < nblk; b += 64) {
+    E2 v = partial[b * w * np + id];
+    s0 = gl_add(s0, v.c0);
+    s1 = gl_add(s1, v.c1);
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (threadIdx.x == 0) out[id] = e2(s0, s1);
 }
 
 struct DeepParams {
@@ -182,6 +188,43 @@ __global__ __launch_bounds__(256) void fri_leaf_hash_k(const E2* __restrict__ cu
   q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+
+// proof-of-work search: smallest w in [w0, w0 + n) such that BLAKE3(prefix || w as 8 LE bytes), read as the
+// challenger's sample_bits (u64 from the LAST 8 digest bytes, reversed), has its low `bits` bits clear.
+// cv_mid = chaining value after the prefix blocks that cannot contain witness bytes; tail = remaining prefix bytes.
+struct GrindParams {
+  u32 cv_mid[8];
+  u32 tail[32];     // tail bytes as LE words, zero padded (tail_len < 120)
+  u32 tail_len;     // bytes of prefix in the tail
+  u32 first_block;  // 1 if the tail's first block is the chunk's first block
+  u64 w0;
+  u64 mask;
+};
+__global__ __launch_bounds__(256) void grind_k(GrindParams p, unsigned long long* __restrict__ best) {
+  const u64 w = p.w0 + blockIdx.x * u64(blockDim.x) + threadIdx.x;
+  u32 m[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) m[i] = p.tail[i];
+  for (int k = 0; k < 8; k++) {
+    u32 pos = p.tail_len + k;
+    m[pos >> 2] |= (u32)((w >> (8 * k)) & 0xff) << (8 * (pos & 3));
+  }
+  const u32 total = p.tail_len + 8;
+  u32 cv[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) cv[i] = p.cv_mid[i];
+  if (total <= 64) {
+    b3_compress(cv, m, 0, total, (p.first_block ? B3_CHUNK_START : 0) | B3_CHUNK_END | B3_ROOT);
+  } else {
+    b3_compress(cv, m, 0, 64, p.first_block ? B3_CHUNK_START : 0);
+    b3_compress(cv, m + 16, 0, total - 64, B3_CHUNK_END | B3_ROOT);
+  }
+  // digest bytes 31..24 form the sampled u64 little-endian: byte k = d[31 - k]
+  const u32 hi = cv[7], lo = cv[6];
+  const u64 v = ((u64)__builtin_bswap32(lo) << 32) | (u64)__builtin_bswap32(hi);
+  if ((v & p.mask) == 0) atomicMin(best, (unsigned long long)w);
+}
+
 __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* __restrict__ out) {
   size_t r = blockIdx.x;
   if (r >= n) return;
@@ -222,7 +265,7 @@ void bary_eval(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h,
                        ctx.tw1, partial.p);
   ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
   size_t tot = w * npoints;
-  hipLaunchKernelGGL(bary_final_k, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, fin.p);
+  hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, fin.p);
   HIP_CHECK(hipGetLastError());
   std::vector<E2> sums(tot);
   ctx.d2h(sums.data(), fin.p, tot * sizeof(E2));
@@ -270,6 +313,48 @@ void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows) {
   ctx.prof_end(K_LEAF_HASH, ev, 64.0 * rows);
   HIP_CHECK(hipGetLastError());
   merkle_compress_plain(ctx, t);
+}
+
+
+// Device grinding. `input` is the challenger's pending input buffer; returns the minimal witness.
+bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out) {
+  const size_t L = input.size();
+  if (L + 8 > 1024 || bits == 0 || bits > 40) return false;  // single-chunk transcripts only
+  const size_t nblocks = (L + 8 + 63) / 64;
+  size_t nb_pre = L / 64;
+  if (nb_pre > nblocks - 1) nb_pre = nblocks - 1;
+  GrindParams p;
+  memset(&p, 0, sizeof(p));
+  b3_iv(p.cv_mid);
+  for (size_t b = 0; b < nb_pre; b++) {
+    u32 m[16];
+    for (int i = 0; i < 16; i++) {
+      const uint8_t* q = &input[b * 64 + 4 * i];
+      m[i] = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+    }
+    b3_compress(p.cv_mid, m, 0, 64, b == 0 ? B3_CHUNK_START : 0);
+  }
+  p.tail_len = (u32)(L - nb_pre * 64);
+  if (p.tail_len + 8 > 128) return false;
+  for (u32 i = 0; i < p.tail_len; i++) p.tail[i >> 2] |= (u32)input[nb_pre * 64 + i] << (8 * (i & 3));
+  p.first_block = nb_pre == 0 ? 1 : 0;
+  p.mask = (u64(1) << bits) - 1;
+  DBuf<unsigned long long> best(ctx, 1);
+  const u64 batch = u64(1) << (bits + 6 < 16 ? 16 : bits + 6 > 24 ? 24 : bits + 6);
+  for (u64 w0 = 0;; w0 += batch) {
+    unsigned long long init = ~0ull;
+    ctx.h2d(best.p, &init, 8);
+    p.w0 = w0;
+    hipLaunchKernelGGL(grind_k, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx.stream, p, best.p);
+    HIP_CHECK(hipGetLastError());
+    unsigned long long r = 0;
+    ctx.d2h(&r, best.p, 8);
+    if (r != ~0ull) {
+      *witness_out = r;
+      return true;
+    }
+    if (w0 + batch >= GL_P - batch) throw std::runtime_error("grind: witness space exhausted");
+  }
 }
 
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes) {

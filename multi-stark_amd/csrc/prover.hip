@@ -434,6 +434,18 @@ struct OpenRound {
 
 bool e2_same(E2 a, E2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
 
+// challenger.grind(bits): the search runs on the device when the pending transcript is a single BLAKE3 chunk
+u64 grind(Ctx& ctx, Challenger& ch, unsigned bits) {
+  if (bits == 0) return 0;
+  u64 w = 0;
+  if (bits >= 4 && grind_device(ctx, ch.input, bits, &w)) {
+    ch.observe(w);
+    if (ch.sample_bits(bits) != 0) throw std::runtime_error("grind: device witness rejected by the host challenger");
+    return w;
+  }
+  return ch.grind(bits);
+}
+
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
 void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes) {
   Ctx& ctx = *sys.ctx;
@@ -567,7 +579,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     std::vector<Digest> cap = merkle_cap(ctx, t);
     ch.observe_cap(cap);
     commits.push_back(cap);
-    pow_w.push_back(ch.grind((unsigned)prm.commit_pow_bits));
+    pow_w.push_back(grind(ctx, ch, (unsigned)prm.commit_pow_bits));
     E2 beta = ch.sample_ext();
     DBuf<E2> nxt(ctx, rows);
     const E2* roll = nullptr;
@@ -598,7 +610,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       ch.observe_ext(final_poly[k]);
     }
   }
-  const u64 query_pow = ch.grind((unsigned)prm.query_pow_bits);
+  const u64 query_pow = grind(ctx, ch, (unsigned)prm.query_pow_bits);
 
   // ---- query phase: sample every index, one gather for all openings
   std::vector<size_t> indices(prm.num_queries);

@@ -34,6 +34,16 @@ static Mat mat_from(const u64* p, size_t h, size_t w) {
 extern "C" {
 
 const char* mso_last_error() { return g_err.c_str(); }
+#ifdef _OPENMP
+}
+#include <omp.h>
+extern "C" {
+void mso_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int mso_max_threads() { return omp_get_max_threads(); }
+#else
+void mso_set_threads(int) {}
+int mso_max_threads() { return 1; }
+#endif
 
 // ---- field / hash primitives (KAT pinning)
 u64 mso_gl_mul(u64 a, u64 b) { return gl_mul(a, b); }

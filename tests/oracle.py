@@ -49,6 +49,14 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    lib().mso_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().mso_max_threads())
+
+
 def _err():
     return lib().mso_last_error().decode()
 
