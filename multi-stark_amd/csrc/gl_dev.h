@@ -48,18 +48,9 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   return r;
 }
 
-GL_HD u64 gl_mul(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // 64x64 -> 128 as four 32x32+64 multiply-adds (v_mad_u64_u32), then x = hi*2^64 + lo with hi = h1:h0 reduces as
-  // lo - h1 + (h0 << 32) - h0; every step is a 64-bit add/sub whose carry/borrow is folded back as -/+ (2^32 - 1).
-  // Written limb-wise so that the compiler does not turn (h0 << 32) - h0 back into a fifth multiply.
-  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  u64 p00 = (u64)a0 * b0;
-  u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-  u64 p10 = (u64)a1 * b0 + (u32)p01;
-  u64 hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-  u64 lo = (p10 << 32) | (u32)p00;
-  u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+// x = (h1:h0) * 2^64 + lo  ->  canonical x mod p. Limb-wise: lo - h1 + (h0 << 32) - h0, each 64-bit add/sub folds
+// its carry/borrow back as -/+ (2^32 - 1). Written so that the compiler does not turn (h0 << 32) - h0 into a multiply.
+GL_HD u64 gl_reduce_limbs(u64 lo, u32 h0, u32 h1) {
   u64 A = lo - h1;
   A -= (u64)(0u - (u32)(lo < (u64)h1));
   u64 B = A + ((u64)h0 << 32);
@@ -68,10 +59,41 @@ GL_HD u64 gl_mul(u64 a, u64 b) {
   C -= (u64)(0u - (u32)(B < (u64)h0));
   u64 s = C + GL_EPS;  // C >= p  <=>  C + (2^32 - 1) overflows
   return s < C ? s : C;
+}
+
+GL_HD u64 gl_mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // 64x64 -> 128 as four 32x32+64 multiply-adds (v_mad_u64_u32)
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p00 = (u64)a0 * b0;
+  u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+  u64 p10 = (u64)a1 * b0 + (u32)p01;
+  u64 hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  u64 lo = (p10 << 32) | (u32)p00;
+  return gl_reduce_limbs(lo, (u32)hi, (u32)(hi >> 32));
 #else
   unsigned __int128 x = (unsigned __int128)a * b;
   return gl_reduce128((u64)x, (u64)(x >> 64));
 #endif
+}
+
+// x * 2^k mod p for 0 <= k < 96 by shifts (2 has order 192 and 2^96 = -1: every root of unity of order <= 64 is a
+// signed power of two, so the innermost NTT stages need no multiplier). Meant for k known at compile time.
+GL_HD u64 gl_mul_2exp(u64 x, unsigned k) {
+  if (k == 0) return x;
+  if (k < 64) {
+    u64 lo = x << k, hi = x >> (64 - k);
+    return gl_reduce_limbs(lo, (u32)hi, (u32)(hi >> 32));
+  }
+  // 64 <= k < 96: (hi * 2^64 + lo) * 2^64 with (hi:lo) = x << (k - 64), hi < 2^32:
+  //   hi * 2^128 + l1 * 2^96 + l0 * 2^64 = -(hi << 32) - l1 + (l0 << 32) - l0
+  unsigned s = k - 64;
+  u64 lo = x << s;
+  u64 hi = s ? (x >> (64 - s)) : 0;
+  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32);
+  u64 t = gl_sub(((u64)l0 << 32), (u64)l0);   // (l0 << 32) - l0, both canonical
+  t = gl_sub(t, (u64)l1);
+  return gl_sub(t, hi << 32);
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // multiply by a small constant c < 2^32: the high word is < 2^32 so only the 2^64 = 2^32 - 1 fold is needed

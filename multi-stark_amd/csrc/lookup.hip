@@ -68,11 +68,13 @@ __global__ __launch_bounds__(256) void stage2_rowsum_k(const u64* __restrict__ m
 __global__ __launch_bounds__(256) void stage2_write_k(const u64* __restrict__ mult, const u64* __restrict__ args,
                                                       const u32* __restrict__ offs, size_t n, unsigned logn, u32 L, u32 aw, E2 beta,
                                                       E2 gamma, const E2* __restrict__ rowprefix, u64* __restrict__ out) {
-  size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (r >= n) return;
+  // thread t owns storage row t = natural row bitrev(t): row reads are scattered 8(L + aw)-byte runs, but the
+  // 2L column stores are coalesced (the other way round costs 2L scattered 8-byte stores per row)
+  size_t rr = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (rr >= n) return;
+  const size_t r = bitrev64(rr, logn);
   E2 run = rowprefix[r];
   const u64* mrow = mult + r * L;
-  const size_t rr = bitrev64(r, logn);
   for_each_inverse(args + r * aw, offs, L, beta, gamma, [&](u32 j, E2 inv) {
     out[size_t(2 * j) * n + rr] = run.c0;
     out[size_t(2 * j + 1) * n + rr] = run.c1;

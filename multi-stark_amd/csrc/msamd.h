@@ -225,9 +225,11 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
 // ---------------------------------------------------------------- open.hip
 // 1/(z - x_i) for i < H over the bit-reversed coset x_i = 7 w_H^{bitrev(i)}; out: E2[H] (AoS)
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out);
-// opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i]
-void bary_eval(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* invden0, const E2* invden1,
-               E2 z0, E2 z1, int npoints, E2* out_host /* npoints * w */);
+// opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i].
+// bary_sums_async only launches (raw sums to device memory, index c * np + p); bary_finish applies scale_p on the host.
+void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* invden0, const E2* invden1,
+                     int npoints, E2* out_dev);
+void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npoints, E2* out /* p * w + c */);
 struct DeepMat {
   const u64* d;       // column-major LDE
   uint32_t w;
@@ -256,5 +258,8 @@ struct GatherReq {
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes);
 // proof-of-work search on the device (single-chunk transcripts); false = not applicable, use the host loop
 bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out);
+// cap of a tree + (when it fits) the PoW witness for transcript prefix || cap, in one host synchronisation
+std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<uint8_t>& prefix, unsigned bits, bool* found,
+                                  u64* witness);
 
 }  // namespace msamd

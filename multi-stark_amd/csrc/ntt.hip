@@ -162,12 +162,45 @@ __device__ __forceinline__ void reg_stages16(u64 (&x)[16], u32 lo, unsigned shif
   }
 }
 
+
+// The round over the lowest 4 position bits (lo = 0, shift = 0): all its twiddles are powers of w_16 = 2^156
+// (inverse: 2^36), i.e. signed powers of two — 15 of the 32 butterflies have twiddle 1 and the other 17 are shifts.
+template <bool DIT, bool INV>
+__device__ __forceinline__ void reg_stages16_uniform(u64 (&x)[16]) {
+  constexpr unsigned E16 = INV ? 36u : 156u;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int loghalf = DIT ? s : 3 - s;
+    const int half = 1 << loghalf;
+#pragma unroll
+    for (int jl = 0; jl < half; jl++) {
+      // twiddle w_{2 half}^jl = w_16^(jl * 8 / half) = 2^k (mod 192), sign folded into the butterfly
+      const unsigned kk = (E16 * (unsigned)(jl * (8 / half))) % 192u;
+      const bool neg = kk >= 96;
+      const unsigned k = neg ? kk - 96 : kk;
+#pragma unroll
+      for (int g = 0; g < 8 / half; g++) {
+        const int j0 = g * 2 * half + jl, j1 = j0 + half;
+        u64 a = x[j0], b = x[j1];
+        if (DIT) {
+          u64 t = gl_mul_2exp(b, k);
+          x[j0] = neg ? gl_sub(a, t) : gl_add(a, t);
+          x[j1] = neg ? gl_add(a, t) : gl_sub(a, t);
+        } else {
+          x[j0] = gl_add(a, b);
+          x[j1] = gl_mul_2exp(neg ? gl_sub(b, a) : gl_sub(a, b), k);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ u32 pad_hi(u32 e) { return e + ((e >> 8) << 4); }  // 16 spare slots per 256
 __device__ __forceinline__ u32 pad_lo(u32 e) { return e + (e >> 4); }         // 1 spare slot per 16
 constexpr int NTT12_LDS = 4096 + 256 + 16;
 
 // 12-bit contiguous pass over one 4096-element tile (bits 11..0 of the position inside the tile).
-template <bool DIT>
+template <bool DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logn,
                                                const u64* __restrict__ twc, unsigned src_div, const u64* __restrict__ scale,
                                                u64 out_mul) {
@@ -199,7 +232,7 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(16 * t + j)];
-    reg_stages16<false>(x, 0, 0, twc);  // bits 3..0
+    reg_stages16_uniform<false, INV>(x);  // bits 3..0
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_lo(16 * t + j)] = x[j];
@@ -212,7 +245,7 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(16 * t + j)];
-    reg_stages16<true>(x, 0, 0, twc);  // bits 0..3
+    reg_stages16_uniform<true, INV>(x);  // bits 0..3
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_lo(16 * t + j)] = x[j];
@@ -238,7 +271,7 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
 
 // 8-bit strided pass: sub-transforms of 256 points at stride S = 2^logS inside blocks of 2^(8 + logS); a tile is
 // 256 (h) x 16 (l) with l contiguous in memory. Includes the four-step inter-pass twiddle w_B^{l * bitrev8(h)}.
-template <bool DIT>
+template <bool DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
                                                const u64* __restrict__ twc, const u64* __restrict__ t0,
                                                const u64* __restrict__ t1, unsigned src_div, const u64* __restrict__ scale,
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq * 16 + j) * 16 + l)];
-    reg_stages16<false>(x, 0, 0, twc);  // h bits 3..0
+    reg_stages16_uniform<false, INV>(x);  // h bits 3..0
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       // h = hq * 16 + j, bitrev8(h) = bitrev4(j) * 16 + bitrev4(hq)
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
       u64 v = s[(size_t(hq * 16 + j) << logS) + lg];
       x[j] = gl_mul(v, tw_lookup(t0, t1, (lg * rev) << esh));
     }
-    reg_stages16<true>(x, 0, 0, twc);  // h bits 0..3
+    reg_stages16_uniform<true, INV>(x);  // h bits 0..3
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi((hq * 16 + j) * 16 + l)] = x[j];
     __syncthreads();
@@ -335,9 +368,12 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
     size_t gx8 = (size_t(1) << (logS - 4)) << (logn - logB);
     const int id = DIT ? K_NTT8S_DIT : K_NTT8S_DIF;
     hipEvent_t ev8 = ctx.prof_begin(id);
-    hipLaunchKernelGGL(ntt8s_k<(DIT != 0)>, dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS, logn,
-                       inverse ? ctx.twci : ctx.twc, inverse ? ctx.tw0i : ctx.tw0, inverse ? ctx.tw1i : ctx.tw1, src_div, scale,
-                       out_mul);
+    if (inverse)
+      hipLaunchKernelGGL((ntt8s_k<(DIT != 0), true>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
+                         logn, ctx.twci, ctx.tw0i, ctx.tw1i, src_div, scale, out_mul);
+    else
+      hipLaunchKernelGGL((ntt8s_k<(DIT != 0), false>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
+                         logn, ctx.twc, ctx.tw0, ctx.tw1, src_div, scale, out_mul);
     ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
@@ -359,8 +395,10 @@ void launch_contig(Ctx& ctx, const u64* src, u64* dst, unsigned K, unsigned logn
   if (K == 12) {
     const int id = DIT ? K_NTT12_DIT : K_NTT12_DIF;
     hipEvent_t ev12 = ctx.prof_begin(id);
-    hipLaunchKernelGGL(ntt12_k<(DIT != 0)>, grid, dim3(256), 0, ctx.stream, src, dst, logn, inverse ? ctx.twci : ctx.twc, src_div,
-                       scale, out_mul);
+    if (inverse)
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, src_div, scale, out_mul);
+    else
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, src_div, scale, out_mul);
     ctx.prof_end(id, ev12, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }

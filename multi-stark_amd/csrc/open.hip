@@ -128,25 +128,35 @@ struct DeepParams {
   int accumulate;
 };
 __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
-  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  // two consecutive rows per thread: every column access is one 16-byte load
+  const size_t i = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * 2;
   if (i >= p.height) return;
-  E2 acc = p.accumulate ? p.ro[i] : e2(0);
+  E2 acc0 = e2(0), acc1 = e2(0);
+  if (p.accumulate) {
+    acc0 = p.ro[i];
+    acc1 = p.ro[i + 1];
+  }
   for (u32 m = 0; m < p.nmats; m++) {
     const DeepMat dm = p.mats[m];
-    u64 s0 = 0, s1 = 0;
+    u64 s00 = 0, s01 = 0, s10 = 0, s11 = 0;
     for (u32 c = 0; c < dm.w; c++) {
-      u64 v = dm.d[size_t(c) * p.height + i];
-      E2 a = p.apow[c];
-      s0 = gl_add(s0, gl_mul(a.c0, v));
-      s1 = gl_add(s1, gl_mul(a.c1, v));
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(dm.d + size_t(c) * p.height + i);
+      const E2 a = p.apow[c];
+      s00 = gl_add(s00, gl_mul(a.c0, v.x));
+      s01 = gl_add(s01, gl_mul(a.c1, v.x));
+      s10 = gl_add(s10, gl_mul(a.c0, v.y));
+      s11 = gl_add(s11, gl_mul(a.c1, v.y));
     }
     for (u32 q = 0; q < dm.npoints; q++) {
-      E2 diff = e2(gl_sub(dm.red_z[q].c0, s0), gl_sub(dm.red_z[q].c1, s1));
-      E2 t = e2_mul(e2_mul(dm.coeff[q], diff), p.den[dm.inv_idx[q]][i]);
-      acc = e2_add(acc, t);
+      const E2* den = p.den[dm.inv_idx[q]];
+      E2 d0 = e2(gl_sub(dm.red_z[q].c0, s00), gl_sub(dm.red_z[q].c1, s01));
+      E2 d1 = e2(gl_sub(dm.red_z[q].c0, s10), gl_sub(dm.red_z[q].c1, s11));
+      acc0 = e2_add(acc0, e2_mul(e2_mul(dm.coeff[q], d0), den[i]));
+      acc1 = e2_add(acc1, e2_mul(e2_mul(dm.coeff[q], d1), den[i + 1]));
     }
   }
-  p.ro[i] = acc;
+  p.ro[i] = acc0;
+  p.ro[i + 1] = acc1;
 }
 
 // out[i] = (1/2 + pw) lo + (1/2 - pw) hi, pw = (beta/2) w_{2R}^{-bitrev(i)}; optional roll-in out[i] += f * in[i]
@@ -225,6 +235,37 @@ __global__ __launch_bounds__(256) void grind_k(GrindParams p, unsigned long long
   if ((v & p.mask) == 0) atomicMin(best, (unsigned long long)w);
 }
 
+// Same search with the commitment still on the device: transcript = prefix (host bytes, 4-byte multiple) || cap
+// digests (device) || w, at most 128 bytes. Saves the host round trip between "read the cap" and "grind".
+struct GrindCapParams {
+  u32 prefix[32];
+  u32 prefix_words;
+  u32 cap_words;  // 8 per digest
+  u64 w0;
+  u64 mask;
+};
+__global__ __launch_bounds__(256) void grind_cap_k(GrindCapParams p, const u32* __restrict__ cap, unsigned long long* __restrict__ best) {
+  const u64 w = p.w0 + blockIdx.x * u64(blockDim.x) + threadIdx.x;
+  u32 m[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) m[i] = p.prefix[i];
+  const u32 q = p.prefix_words + p.cap_words;
+  for (u32 i = 0; i < p.cap_words; i++) m[p.prefix_words + i] = cap[i];
+  m[q] = (u32)w;
+  m[q + 1] = (u32)(w >> 32);
+  const u32 total = 4 * q + 8;
+  u32 cv[8];
+  b3_iv(cv);
+  if (total <= 64) {
+    b3_compress(cv, m, 0, total, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+  } else {
+    b3_compress(cv, m, 0, 64, B3_CHUNK_START);
+    b3_compress(cv, m + 16, 0, total - 64, B3_CHUNK_END | B3_ROOT);
+  }
+  const u64 v = ((u64)__builtin_bswap32(cv[6]) << 32) | (u64)__builtin_bswap32(cv[7]);
+  if ((v & p.mask) == 0) atomicMin(best, (unsigned long long)w);
+}
+
 __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* __restrict__ out) {
   size_t r = blockIdx.x;
   if (r >= n) return;
@@ -250,12 +291,13 @@ void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out) {
   HIP_CHECK(hipGetLastError());
 }
 
-void bary_eval(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* den0, const E2* den1, E2 z0, E2 z1,
-               int npoints, E2* out_host) {
+// launches only: raw sums sum_{i<h} col_c[i] x_i invden_p[i] into `out_dev` (w * npoints values, index c * np + p)
+void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* den0, const E2* den1, int npoints,
+                     E2* out_dev) {
   if (npoints == 0) return;
   size_t h = size_t(1) << log_h;
   size_t nblk = (h + 256 * BARY_ROWS - 1) / (256 * BARY_ROWS);
-  DBuf<E2> partial(ctx, nblk * w * npoints), fin(ctx, w * npoints);
+  DBuf<E2> partial(ctx, nblk * w * npoints);  // stream-ordered reuse keeps it valid until bary_final_k has run
   hipEvent_t ev = ctx.prof_begin(K_BARY);
   if (npoints == 1)
     hipLaunchKernelGGL(bary_partial_k<1>, dim3((unsigned)nblk), dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, den0, den0, ctx.tw0,
@@ -263,19 +305,20 @@ void bary_eval(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h,
   else
     hipLaunchKernelGGL(bary_partial_k<2>, dim3((unsigned)nblk), dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, den0, den1, ctx.tw0,
                        ctx.tw1, partial.p);
-  ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
   size_t tot = w * npoints;
-  hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, fin.p);
+  hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, out_dev);
+  ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
   HIP_CHECK(hipGetLastError());
-  std::vector<E2> sums(tot);
-  ctx.d2h(sums.data(), fin.p, tot * sizeof(E2));
-  // y = sum * (z^h - s^h) / (h s^h), s = GENERATOR (p3 interpolate_coset)
+}
+
+// y = sum * (z^h - s^h) / (h s^h), s = GENERATOR (p3 interpolate_coset); sums indexed c * np + p
+void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npoints, E2* out /* p * w + c */) {
+  size_t h = size_t(1) << log_h;
   u64 s_pow = gl_exp_pow2(GL_GEN, log_h);
   u64 dinv = gl_inv(gl_mul(s_pow, (u64)h % GL_P));
-  E2 zs[2] = {z0, z1};
   for (int p = 0; p < npoints; p++) {
     E2 scale = e2_mul_base(e2_sub(e2_exp_pow2(zs[p], log_h), e2(s_pow)), dinv);
-    for (size_t c = 0; c < w; c++) out_host[p * w + c] = e2_mul(sums[c * npoints + p], scale);
+    for (size_t c = 0; c < w; c++) out[p * w + c] = e2_mul(sums[c * npoints + p], scale);
   }
 }
 
@@ -288,7 +331,8 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, size_t height, cons
   double bytes = 16.0 * height;
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);
-  hipLaunchKernelGGL(deep_reduce_k, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, ctx.stream, p);
+  if (height < 2 || (height & 1)) throw std::runtime_error("deep_reduce: LDE height must be even");
+  hipLaunchKernelGGL(deep_reduce_k, dim3((unsigned)((height / 2 + 255) / 256)), dim3(256), 0, ctx.stream, p);
   ctx.prof_end(K_DEEP, ev, bytes);
   HIP_CHECK(hipGetLastError());
 }
@@ -355,6 +399,42 @@ bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u6
     }
     if (w0 + batch >= GL_P - batch) throw std::runtime_error("grind: witness space exhausted");
   }
+}
+
+// Reads the cap of tree t and, when `bits` > 0 and the transcript fits, searches the PoW witness in the same
+// submission (one host synchronisation). *found = false means the caller must grind the usual way.
+std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<uint8_t>& prefix, unsigned bits, bool* found,
+                                  u64* witness) {
+  const size_t cl = t.cap_layer();
+  const size_t ncap = t.layer_len[cl];
+  std::vector<Digest> cap(ncap);
+  *found = false;
+  const bool fits = bits > 0 && bits <= 40 && (prefix.size() % 4) == 0 && prefix.size() + 32 * ncap + 8 <= 128;
+  if (!fits) {
+    ctx.d2h(cap.data(), t.digests.p + t.layer_off[cl], ncap * sizeof(Digest));
+    return cap;
+  }
+  GrindCapParams p;
+  memset(&p, 0, sizeof(p));
+  memcpy(p.prefix, prefix.data(), prefix.size());
+  p.prefix_words = (u32)(prefix.size() / 4);
+  p.cap_words = (u32)(8 * ncap);
+  p.w0 = 0;
+  p.mask = (u64(1) << bits) - 1;
+  DBuf<unsigned long long> best(ctx, 1);
+  HIP_CHECK(hipMemsetAsync(best.p, 0xff, 8, ctx.stream));
+  const u64 batch = u64(1) << (bits + 6 < 16 ? 16 : bits + 6 > 24 ? 24 : bits + 6);
+  hipLaunchKernelGGL(grind_cap_k, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx.stream, p,
+                     (const u32*)(t.digests.p + t.layer_off[cl]), best.p);
+  HIP_CHECK(hipGetLastError());
+  unsigned long long r = 0;
+  HIP_CHECK(hipMemcpyAsync(cap.data(), t.digests.p + t.layer_off[cl], ncap * sizeof(Digest), hipMemcpyDeviceToHost, ctx.stream));
+  ctx.d2h(&r, best.p, 8);
+  if (r != ~0ull) {
+    *found = true;
+    *witness = r;
+  }
+  return cap;
 }
 
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes) {

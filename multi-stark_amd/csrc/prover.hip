@@ -6,6 +6,8 @@
 // query openings cross PCIe.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "host.h"
 
@@ -434,6 +436,26 @@ struct OpenRound {
 
 bool e2_same(E2 a, E2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
 
+// MSAMD_TRACE=1: synchronise and print the wall time of each phase of the opening (diagnostics only)
+struct PhaseTrace {
+  Ctx& ctx;
+  bool on;
+  double t;
+  explicit PhaseTrace(Ctx& c) : ctx(c), on(getenv("MSAMD_TRACE") != nullptr), t(0) {
+    if (on) {
+      ctx.sync();
+      t = now_ms();
+    }
+  }
+  void mark(const char* what) {
+    if (!on) return;
+    ctx.sync();
+    double n = now_ms();
+    fprintf(stderr, "[msamd] %-22s %8.3f ms\n", what, n - t);
+    t = n;
+  }
+};
+
 // challenger.grind(bits): the search runs on the device when the pending transcript is a single BLAKE3 chunk
 u64 grind(Ctx& ctx, Challenger& ch, unsigned bits) {
   if (bits == 0) return 0;
@@ -459,6 +481,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     }
   if (!gmax) throw std::runtime_error("pcs_open: no matrices");
   const unsigned log_gmax = log2_strict(gmax);
+  PhaseTrace tr(ctx);
 
   // unique opening points and the tallest matrix opened at each
   std::vector<E2> upts;
@@ -482,31 +505,57 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p);
   }
 
-  // opened values (barycentric over the first h = height / B storage rows), observed as produced
+  tr.mark("inv_denoms");
+  // opened values (barycentric over the first h = height / B storage rows): every matrix is launched first, one
+  // read-back serves them all, then they are observed in round -> matrix -> point order
   opened.clear();
-  for (auto& r : rounds) {
-    OpenedRound orr;
+  size_t total_vals = 0;
+  for (auto& r : rounds)
     for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
-      const DMat& m = r.data->ldes[mi];
-      auto& pts = r.points[mi];
-      std::vector<std::vector<E2>> per_point;
-      if (!pts.empty()) {
-        if (pts.size() > 2) throw std::runtime_error("pcs_open: more than two points per matrix");
+      if (r.points[mi].size() > 2) throw std::runtime_error("pcs_open: more than two points per matrix");
+      total_vals += r.points[mi].size() * r.data->ldes[mi].w;
+    }
+  DBuf<E2> d_sums(ctx, std::max<size_t>(total_vals, 1));
+  {
+    size_t off = 0;
+    for (auto& r : rounds)
+      for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+        const DMat& m = r.data->ldes[mi];
+        auto& pts = r.points[mi];
+        if (pts.empty()) continue;
         int np = (int)pts.size();
-        std::vector<E2> ys(np * m.w);
         const E2* d0 = dens[point_index(pts[0])].p;
         const E2* d1 = np == 2 ? dens[point_index(pts[1])].p : d0;
-        bary_eval(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, pts[0], np == 2 ? pts[1] : pts[0], np, ys.data());
-        for (int p = 0; p < np; p++) {
-          per_point.emplace_back(ys.begin() + p * m.w, ys.begin() + (p + 1) * m.w);
-          for (auto& y : per_point.back()) ch.observe_ext(y);
-        }
+        bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off);
+        off += np * m.w;
       }
-      orr.push_back(std::move(per_point));
-    }
-    opened.push_back(std::move(orr));
   }
-
+  std::vector<E2> h_sums(std::max<size_t>(total_vals, 1));
+  ctx.d2h(h_sums.data(), d_sums.p, total_vals * sizeof(E2));
+  {
+    size_t off = 0;
+    for (auto& r : rounds) {
+      OpenedRound orr;
+      for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+        const DMat& m = r.data->ldes[mi];
+        auto& pts = r.points[mi];
+        std::vector<std::vector<E2>> per_point;
+        if (!pts.empty()) {
+          int np = (int)pts.size();
+          std::vector<E2> ys(np * m.w);
+          bary_finish(&h_sums[off], m.w, log2_strict(m.h) - lb, pts.data(), np, ys.data());
+          off += np * m.w;
+          for (int p = 0; p < np; p++) {
+            per_point.emplace_back(ys.begin() + p * m.w, ys.begin() + (p + 1) * m.w);
+            for (auto& y : per_point.back()) ch.observe_ext(y);
+          }
+        }
+        orr.push_back(std::move(per_point));
+      }
+      opened.push_back(std::move(orr));
+    }
+  }
+  tr.mark("bary_eval");
   const E2 alpha = ch.sample_ext();
   std::vector<E2> apow(gw + 1);
   apow[0] = e2(1);
@@ -559,6 +608,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     inputs.push_back(std::move(ro));
   }
   for (auto& d : dens) d.reset();
+  tr.mark("deep_reduce");
 
   // ---- FRI commit phase (prove_fri / commit_phase)
   const size_t final_len = size_t(1) << prm.log_final_poly_len;
@@ -576,10 +626,18 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     DTree& t = trees.back();
     t.cap_height = (unsigned)prm.cap_height;
     fri_tree_build(ctx, t, folded.p, rows);
-    std::vector<Digest> cap = merkle_cap(ctx, t);
+    bool found = false;
+    u64 wit = 0;
+    std::vector<Digest> cap = cap_and_grind(ctx, t, ch.input, (unsigned)prm.commit_pow_bits, &found, &wit);
     ch.observe_cap(cap);
     commits.push_back(cap);
-    pow_w.push_back(grind(ctx, ch, (unsigned)prm.commit_pow_bits));
+    if (found) {
+      ch.observe(wit);
+      if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("grind: device witness rejected by the host challenger");
+      pow_w.push_back(wit);
+    } else {
+      pow_w.push_back(grind(ctx, ch, (unsigned)prm.commit_pow_bits));
+    }
     E2 beta = ch.sample_ext();
     DBuf<E2> nxt(ctx, rows);
     const E2* roll = nullptr;
@@ -589,6 +647,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     layers.push_back(std::move(folded));
     folded = std::move(nxt);
   }
+  tr.mark("fri_commit_phase");
   if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
   // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
   std::vector<E2> fin(folded.n);
@@ -644,8 +703,10 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       for (size_t l = 0; l < n_siblings(t); l++) add_req(t.digests.p + t.layer_off[l], 0, (pair >> l) ^ 1, 1, 1);
     }
   }
+  tr.mark("final_poly+grind");
   std::vector<uint8_t> g(out_off);
   gather_rows(ctx, reqs, g.data(), out_off);
+  tr.mark("query_gather");
 
   // ---- FriProof bytes
   PW& w = fri_bytes;
