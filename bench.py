@@ -43,17 +43,6 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def commitments_of(proof: bytes, n_circuits: int):
-    """stage_1 / stage_2 / quotient commitments from Proof::to_bytes (cap_height 0: one digest each)."""
-    off = 8 + n_circuits
-    out = []
-    for _ in range(3):
-        n = int.from_bytes(proof[off:off + 8], "little")
-        out.append(proof[off + 8: off + 8 + 32 * n])
-        off += 8 + 32 * n
-    return b"".join(out)
-
-
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,8 +77,13 @@ def main():
     system = pkg.System.new(ctx, params, inputs)
     num_adds = 1 << args.log_adds
     # per-rank seeds; rank 0 is exactly the reference's bench witness
-    a0 = 0xDEADBEEF ^ ((rank * 0x9E3779B9) & 0xFFFFFFFF)
-    b0 = 0xCAFEBABE ^ ((rank * 0x85EBCA6B) & 0xFFFFFFFF)
+    a0, b0 = (0xDEADBEEF, 0xCAFEBABE)
+    mgpu = None
+    if n_gpus > 1:
+        import importlib
+
+        mgpu = importlib.import_module("multi_stark_amd.distributed")
+        a0, b0 = mgpu.rank_seeds(rank)
     t = time.time()
     traces, claims = fe.u32_add_bench_witness(num_adds, a0, b0)
     packed = fe.pack_claims(claims)
@@ -108,11 +102,9 @@ def main():
     def step():
         proof = system.prove_multiple_claims(witness)
         if dist is not None:
-            mine = torch.frombuffer(bytearray(commitments_of(proof.to_bytes(), 2)), dtype=torch.uint8).cuda()
-            allc = [torch.empty_like(mine) for _ in range(n_gpus)]
-            dist.all_gather(allc, mine)
+            allc = mgpu.gather_commitments(mgpu.commitments_of(proof.to_bytes(), 2), torch.device("cuda", local_rank))
             if rank == 0:
-                hashlib.blake2s(b"".join(bytes(c.cpu().numpy()) for c in allc)).digest()
+                mgpu.joint_digest(allc)
         return proof
 
     # ---- warmup (untimed); the first warmup step is profiled per kernel class to pick the dominant kernel

@@ -18,7 +18,7 @@ import numpy as np
 
 P = (1 << 64) - (1 << 32) + 1
 
-# node kinds (shared with include/mstark.h and oracle/ms_oracle.hpp)
+# node kinds (the system-blob encoding, see include/mstark.h)
 N_CONST, N_VAR, N_PUBLIC, N_IS_FIRST, N_IS_LAST, N_IS_TRANS, N_ADD, N_SUB, N_MUL, N_NEG = range(10)
 SRC_PRE, SRC_MAIN, SRC_STAGE2 = 0, 1, 2
 BLOB_MAGIC = 0x31305359534D0000

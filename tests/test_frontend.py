@@ -1,0 +1,72 @@
+"""CPU tests: the circuit front-end mirrors src/expr.rs folding and src/graph.rs interning."""
+import numpy as np
+import pytest
+
+
+def test_expr_constant_folding(fe):
+    E = fe.Expr
+    x = E.main(0)
+    assert (E.const(2) + E.const(3)).a == 5
+    assert (x + 0) is x and (0 + x) is x and (x * 1) is x and (x - 0) is x
+    assert (x * 0).is_const(0)
+    assert (0 - x).kind == fe.N_NEG and (-(-x)) is x
+    assert (E.const(0) - E.const(1)).a == fe.P - 1
+
+
+def test_interning_and_canonical_zeros(fe):
+    E = fe.Expr
+    a, b = E.main(0), E.main(1)
+    ci = fe.CircuitInputs(2, None, [a + b, b + a, (a + b) - (a + b), a * b - b * a + a], [], [])
+    cc = fe.compile_circuit(ci)
+    # a+b and b+a intern to one node; x - x folds to the zero constant and is dropped; a*b - b*a folds to 0 so "+ a" is a
+    assert len(cc.zeros) == 2
+    kinds = [n[0] for n in cc.nodes]
+    assert kinds.count(fe.N_ADD) == 1
+    with pytest.raises(fe.CompileError):
+        fe.compile_circuit(fe.CircuitInputs(1, None, [E.const(5)], [], []))
+    with pytest.raises(fe.CompileError):
+        fe.compile_circuit(fe.CircuitInputs(1, None, [E.main(3)], [], []))
+
+
+def test_u32_add_program_shape(fe, oracle):
+    comp = [fe.compile_circuit(ci) for ci in fe.u32_add_system_inputs()]
+    byte, add = comp
+    assert len(byte.zeros) == 0 and len(byte.lookups) == 1
+    assert len(add.zeros) == 2 and len(add.lookups) == 13
+    assert [len(a) for _, a in add.lookups] == [4] + [2] * 12
+    # children precede parents
+    for i, (kind, _, _, a, b) in enumerate(add.nodes):
+        if kind in (fe.N_ADD, fe.N_SUB, fe.N_MUL):
+            assert a < i and b < i
+    s = oracle.System(fe.system_blob(fe.bench_params(), comp))
+    # benches/multi_stark.rs system: widths / constraint counts
+    assert s.circuit_info(0) == {"main_width": 1, "pre_width": 1, "pre_height": 256, "num_lookups": 1, "stage2_width": 2,
+                                 "constraint_count": 2, "max_constraint_degree": 2, "quotient_degree": 1, "args_width": 2}
+    assert s.circuit_info(1) == {"main_width": 14, "pre_width": 0, "pre_height": 0, "num_lookups": 13, "stage2_width": 26,
+                                 "constraint_count": 28, "max_constraint_degree": 2, "quotient_degree": 1, "args_width": 28}
+
+
+def test_ext_constraints_karatsuba(fe):
+    E, X = fe.Expr, fe.ExtExpr
+    a = X.coords([E.main(0), E.main(1)])
+    b = X.coords([E.main(2), E.main(3)])
+    cc = fe.compile_circuit(fe.CircuitInputs(4, None, [], [a * b - X.coords([E.main(0), E.main(1)])], []))
+    assert len(cc.zeros) == 2
+    assert [n[0] for n in cc.nodes].count(fe.N_MUL) == 4  # 3 Karatsuba products + W * p1
+    with pytest.raises(fe.CompileError):
+        fe.compile_circuit(fe.CircuitInputs(1, None, [], [X.base(E.main(0)) * X.base(E.main(0))], []))
+
+
+def test_bench_witness_matches_reference_generator(fe):
+    traces, claims = fe.u32_add_bench_witness(8)
+    # first xorshift32 outputs from 0xdeadbeef / 0xcafebabe (benches/multi_stark.rs:180-192)
+    a = 0xDEADBEEF
+    a ^= (a << 13) & 0xFFFFFFFF
+    a ^= a >> 17
+    a ^= (a << 5) & 0xFFFFFFFF
+    assert int(claims[0, 1]) == a
+    assert int(claims[0, 0]) == 1 and int(claims[0, 3]) == (int(claims[0, 1]) + int(claims[0, 2])) & 0xFFFFFFFF
+    byte, add = traces
+    assert byte.shape == (256, 1) and add.shape == (8, 14) and int(byte.sum()) == 12 * 8
+    x = sum(int(add[0, k]) << (8 * k) for k in range(4))
+    assert x == int(claims[0, 1]) and int(add[0, 13]) == 1
