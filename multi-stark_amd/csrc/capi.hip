@@ -235,7 +235,7 @@ int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proo
   size_t vals_bytes = off;
   size_t ns = t.cap_layer();
   for (size_t i = 0; i < ns; i++) {
-    GatherReq q{t.digests.p + t.layer_off[i], 0, (index >> i) ^ 1, 1, 1, off};
+    GatherReq q{t.base() + t.layer_off[i], 0, (index >> i) ^ 1, 1, 1, off};
     reqs.push_back(q);
     off += 32;
   }

@@ -96,6 +96,45 @@ GL_HD u64 gl_mul_2exp(u64 x, unsigned k) {
   return gl_sub(t, hi << 32);
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+
+// Lazy dot-product accumulator: sums 64x64-bit products in 160 bits (lo, hi, carry count) and reduces once.
+// A term costs four multiply-adds and five adds instead of a full multiplication plus a modular addition.
+struct GlAcc {
+  u64 lo, hi;
+  u32 c;
+};
+GL_HD void acc_init(GlAcc& a) {
+  a.lo = 0;
+  a.hi = 0;
+  a.c = 0;
+}
+GL_HD void acc_mad(GlAcc& a, u64 x, u64 y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+  u64 p00 = (u64)x0 * y0;
+  u64 p01 = (u64)x0 * y1 + (p00 >> 32);
+  u64 p10 = (u64)x1 * y0 + (u32)p01;
+  u64 phi = (u64)x1 * y1 + (p01 >> 32) + (p10 >> 32);
+  u64 plo = (p10 << 32) | (u32)p00;
+#else
+  unsigned __int128 pr = (unsigned __int128)x * y;
+  u64 plo = (u64)pr, phi = (u64)(pr >> 64);
+#endif
+  u64 lo = a.lo + plo;
+  u64 c1 = lo < plo ? 1u : 0u;
+  u64 hi = a.hi + phi;
+  u32 c2 = hi < phi ? 1u : 0u;
+  u64 hi2 = hi + c1;
+  c2 += hi2 < c1 ? 1u : 0u;
+  a.lo = lo;
+  a.hi = hi2;
+  a.c += c2;
+}
+// value = c * 2^128 + hi * 2^64 + lo, with 2^128 = -2^32 (mod p); c stays far below 2^31 for any realistic sum
+GL_HD u64 acc_reduce(const GlAcc& a) {
+  u64 r = gl_reduce_limbs(a.lo, (u32)a.hi, (u32)(a.hi >> 32));
+  return gl_sub(r, (u64)a.c << 32);
+}
 // multiply by a small constant c < 2^32: the high word is < 2^32 so only the 2^64 = 2^32 - 1 fold is needed
 GL_HD u64 gl_mul_small(u64 a, u32 c) {
 #if defined(__HIP_DEVICE_COMPILE__)

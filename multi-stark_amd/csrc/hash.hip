@@ -176,36 +176,57 @@ __device__ __forceinline__ void lds_load_digest(const u32* sh, u32 idx, u32 cv[8
   cv[7] = b.w;
 }
 
-// three levels per launch: a workgroup turns 2048 children into 1024 + 512 + 256 ancestors (no injection)
+// three levels per launch, entirely in registers: thread i turns children [8i, 8i+8) into 4 + 2 + 1 ancestors
+// (no LDS, no barrier: full occupancy; the 256-byte child run of a lane stays in L1 across its 16 loads)
 __global__ __launch_bounds__(256) void compress3_k(const Digest* __restrict__ child, Digest* __restrict__ l1, Digest* __restrict__ l2,
-                                                   Digest* __restrict__ l3) {
+                                                   Digest* __restrict__ l3, size_t n3) {
+  const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= n3) return;
+  u32 a[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    u32 l[8], r[8];
+    load_digest(child + 8 * i + 2 * k, l);
+    load_digest(child + 8 * i + 2 * k + 1, r);
+    b3_compress_pair_root(l, r, a[k]);
+    store_digest(l1 + 4 * i + k, a[k]);
+  }
+  u32 b0[8], b1[8], c[8];
+  b3_compress_pair_root(a[0], a[1], b0);
+  b3_compress_pair_root(a[2], a[3], b1);
+  store_digest(l2 + 2 * i, b0);
+  store_digest(l2 + 2 * i + 1, b1);
+  b3_compress_pair_root(b0, b1, c);
+  store_digest(l3 + i, c);
+}
+
+// latency-oriented variant for small layers: 1024 threads turn 2048 children into 1024 + 512 + 256 ancestors with
+// one compression per thread per level (three dependent compressions instead of seven)
+__global__ __launch_bounds__(1024) void compress3_lds_k(const Digest* __restrict__ child, Digest* __restrict__ l1,
+                                                        Digest* __restrict__ l2, Digest* __restrict__ l3) {
   __shared__ __attribute__((aligned(16))) u32 sh1[1024 * 8];
   __shared__ __attribute__((aligned(16))) u32 sh2[512 * 8];
   const u32 t = threadIdx.x;
   const size_t b = blockIdx.x;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    u32 i = t + 256 * k;
-    u32 l[8], r[8], d[8];
-    load_digest(child + b * 2048 + 2 * i, l);
-    load_digest(child + b * 2048 + 2 * i + 1, r);
-    b3_compress_pair_root(l, r, d);
-    store_digest(l1 + b * 1024 + i, d);
-    lds_store_digest(sh1, i, d);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    u32 i = t + 256 * k;
-    u32 l[8], r[8], d[8];
-    lds_load_digest(sh1, 2 * i, l);
-    lds_load_digest(sh1, 2 * i + 1, r);
-    b3_compress_pair_root(l, r, d);
-    store_digest(l2 + b * 512 + i, d);
-    lds_store_digest(sh2, i, d);
-  }
-  __syncthreads();
   {
+    u32 l[8], r[8], d[8];
+    load_digest(child + b * 2048 + 2 * t, l);
+    load_digest(child + b * 2048 + 2 * t + 1, r);
+    b3_compress_pair_root(l, r, d);
+    store_digest(l1 + b * 1024 + t, d);
+    lds_store_digest(sh1, t, d);
+  }
+  __syncthreads();
+  if (t < 512) {
+    u32 l[8], r[8], d[8];
+    lds_load_digest(sh1, 2 * t, l);
+    lds_load_digest(sh1, 2 * t + 1, r);
+    b3_compress_pair_root(l, r, d);
+    store_digest(l2 + b * 512 + t, d);
+    lds_store_digest(sh2, t, d);
+  }
+  __syncthreads();
+  if (t < 256) {
     u32 l[8], r[8], d[8];
     lds_load_digest(sh2, 2 * t, l);
     lds_load_digest(sh2, 2 * t + 1, r);
@@ -361,7 +382,7 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
   size_t li = 1;
   while (li < L) {
     const size_t child_len = t.layer_len[li - 1];
-    Digest* child = t.digests.p + t.layer_off[li - 1];
+    Digest* child = t.base() + t.layer_off[li - 1];
     if (child_len <= 1024 && li > last_inject) {
       hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
       hipLaunchKernelGGL(tree_tail_k, dim3(1), dim3(256), 0, ctx.stream, child, (u32)child_len);
@@ -370,14 +391,19 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
     }
     if (child_len >= 2048 && li + 2 < L && !inj[li].count && !inj[li + 1].count && !inj[li + 2].count) {
       hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
-      hipLaunchKernelGGL(compress3_k, dim3((unsigned)(child_len / 2048)), dim3(256), 0, ctx.stream, (const Digest*)child,
-                         t.digests.p + t.layer_off[li], t.digests.p + t.layer_off[li + 1], t.digests.p + t.layer_off[li + 2]);
+      const size_t n3 = child_len / 8;
+      if (n3 >= (size_t(1) << 17))  // throughput-bound: registers only; below that the dependent chain is what costs
+        hipLaunchKernelGGL(compress3_k, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, ctx.stream, (const Digest*)child,
+                           t.base() + t.layer_off[li], t.base() + t.layer_off[li + 1], t.base() + t.layer_off[li + 2], n3);
+      else
+        hipLaunchKernelGGL(compress3_lds_k, dim3((unsigned)(child_len / 2048)), dim3(1024), 0, ctx.stream, (const Digest*)child,
+                           t.base() + t.layer_off[li], t.base() + t.layer_off[li + 1], t.base() + t.layer_off[li + 2]);
       ctx.prof_end(K_COMPRESS, ev, 32.0 * double(child_len) * 1.875);
       li += 3;
       continue;
     }
     const size_t n = t.layer_len[li];
-    Digest* next = t.digests.p + t.layer_off[li];
+    Digest* next = t.base() + t.layer_off[li];
     dim3 grid((unsigned)((n + 255) / 256));
     hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
     if (inj[li].count == 0)
@@ -436,9 +462,9 @@ void merkle_build(Ctx& ctx, DTree& t) {
     dim3 grid((unsigned)((maxh + 255) / 256));
     hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
     if (tw <= 128)
-      hipLaunchKernelGGL(leaf_hash_k<false>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.digests.p);
+      hipLaunchKernelGGL(leaf_hash_k<false>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.base());
     else
-      hipLaunchKernelGGL(leaf_hash_k<true>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.digests.p);
+      hipLaunchKernelGGL(leaf_hash_k<true>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.base());
     ctx.prof_end(K_LEAF_HASH, ev, double(maxh) * (8.0 * tw + 32.0));
   }
   std::vector<InjectAt> inj(t.layer_len.size());
@@ -456,7 +482,7 @@ void merkle_build(Ctx& ctx, DTree& t) {
 std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t) {
   size_t cl = t.cap_layer();
   std::vector<Digest> cap(t.layer_len[cl]);
-  ctx.d2h(cap.data(), t.digests.p + t.layer_off[cl], cap.size() * sizeof(Digest));
+  ctx.d2h(cap.data(), t.base() + t.layer_off[cl], cap.size() * sizeof(Digest));
   return cap;
 }
 

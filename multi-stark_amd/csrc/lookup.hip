@@ -8,10 +8,29 @@ namespace msamd {
 
 namespace {
 
-constexpr int INV_CHUNK = 8;  // Montgomery batch size per thread (one Ext2 inversion per chunk)
+constexpr int INV_CHUNK = 8;    // Montgomery batch size per thread (one Ext2 inversion per chunk; 16 spills to scratch)
+constexpr int CLAIMS_CHUNK = 8;
+constexpr int MAX_GPOW = 64;    // gamma powers kept in a kernel argument; longer argument lists fall back to Horner
 
-// m = beta + sum_i args[i] gamma^i  (Horner over the reversed args, src/lookup.rs:375-384)
-__device__ __forceinline__ E2 message(const u64* __restrict__ a, u32 n, E2 beta, E2 gamma) {
+struct GammaPows {
+  E2 g[MAX_GPOW];
+  u32 n;  // number of valid powers (gamma^0 .. gamma^(n-1))
+};
+
+// m = beta + sum_i args[i] gamma^i (src/lookup.rs:375-384). With the powers precomputed every term is a
+// base x ext product accumulated unreduced; otherwise Horner over the reversed args.
+__device__ __forceinline__ E2 message(const u64* __restrict__ a, u32 n, E2 beta, E2 gamma, const GammaPows& gp) {
+  if (n <= gp.n) {
+    GlAcc a0, a1;
+    acc_init(a0);
+    acc_init(a1);
+    for (u32 k = 0; k < n; k++) {
+      const u64 v = a[k];
+      acc_mad(a0, v, gp.g[k].c0);
+      acc_mad(a1, v, gp.g[k].c1);
+    }
+    return e2(gl_add(acc_reduce(a0), beta.c0), gl_add(acc_reduce(a1), beta.c1));
+  }
   E2 f = e2(0);
   for (u32 k = n; k-- > 0;) {
     f = e2_mul(f, gamma);
@@ -23,7 +42,7 @@ __device__ __forceinline__ E2 message(const u64* __restrict__ a, u32 n, E2 beta,
 // Visit every lookup j of one row with its inverse message; F(j, inv_msg).
 template <class F>
 __device__ __forceinline__ void for_each_inverse(const u64* __restrict__ args_row, const u32* __restrict__ offs, u32 L, E2 beta,
-                                                 E2 gamma, F&& f) {
+                                                 E2 gamma, const GammaPows& gp, F&& f) {
   for (u32 j0 = 0; j0 < L; j0 += INV_CHUNK) {
     E2 msg[INV_CHUNK], pre[INV_CHUNK];
     E2 acc = e2(1);
@@ -31,7 +50,7 @@ __device__ __forceinline__ void for_each_inverse(const u64* __restrict__ args_ro
     for (int t = 0; t < INV_CHUNK; t++) {
       u32 j = j0 + t;
       if (j < L) {
-        msg[t] = message(args_row + offs[j], offs[j + 1] - offs[j], beta, gamma);
+        msg[t] = message(args_row + offs[j], offs[j + 1] - offs[j], beta, gamma, gp);
         pre[t] = acc;
         acc = e2_mul(acc, msg[t]);
       }
@@ -54,32 +73,37 @@ __device__ __forceinline__ void for_each_inverse(const u64* __restrict__ args_ro
   }
 }
 
-__global__ __launch_bounds__(256) void stage2_rowsum_k(const u64* __restrict__ mult, const u64* __restrict__ args,
-                                                       const u32* __restrict__ offs, size_t n, u32 L, u32 aw, E2 beta, E2 gamma,
-                                                       E2* __restrict__ rowsum) {
+// pass 1 (natural row order): terms[r][j] = mult * msg^-1 and the row total
+__global__ __launch_bounds__(256) void stage2_terms_k(const u64* __restrict__ mult, const u64* __restrict__ args,
+                                                      const u32* __restrict__ offs, size_t n, u32 L, u32 aw, E2 beta, E2 gamma,
+                                                      GammaPows gp, E2* __restrict__ terms, E2* __restrict__ rowsum) {
   size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (r >= n) return;
   E2 s = e2(0);
   const u64* mrow = mult + r * L;
-  for_each_inverse(args + r * aw, offs, L, beta, gamma, [&](u32 j, E2 inv) { s = e2_add(s, e2_mul_base(inv, mrow[j])); });
+  E2* trow = terms + r * L;
+  for_each_inverse(args + r * aw, offs, L, beta, gamma, gp, [&](u32 j, E2 inv) {
+    E2 t = e2_mul_base(inv, mrow[j]);
+    trow[j] = t;
+    s = e2_add(s, t);
+  });
   rowsum[r] = s;
 }
 
-__global__ __launch_bounds__(256) void stage2_write_k(const u64* __restrict__ mult, const u64* __restrict__ args,
-                                                      const u32* __restrict__ offs, size_t n, unsigned logn, u32 L, u32 aw, E2 beta,
-                                                      E2 gamma, const E2* __restrict__ rowprefix, u64* __restrict__ out) {
-  // thread t owns storage row t = natural row bitrev(t): row reads are scattered 8(L + aw)-byte runs, but the
-  // 2L column stores are coalesced (the other way round costs 2L scattered 8-byte stores per row)
+// pass 2: thread t owns storage row t = natural row bitrev(t): one scattered 16 L-byte row read, then 2L coalesced
+// column stores of the running sum (the other way round costs 2L scattered 8-byte stores per row)
+__global__ __launch_bounds__(256) void stage2_write_k(const E2* __restrict__ terms, size_t n, unsigned logn, u32 L,
+                                                      const E2* __restrict__ rowprefix, u64* __restrict__ out) {
   size_t rr = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (rr >= n) return;
   const size_t r = bitrev64(rr, logn);
   E2 run = rowprefix[r];
-  const u64* mrow = mult + r * L;
-  for_each_inverse(args + r * aw, offs, L, beta, gamma, [&](u32 j, E2 inv) {
+  const E2* trow = terms + r * L;
+  for (u32 j = 0; j < L; j++) {
     out[size_t(2 * j) * n + rr] = run.c0;
     out[size_t(2 * j + 1) * n + rr] = run.c1;
-    run = e2_add(run, e2_mul_base(inv, mrow[j]));
-  });
+    run = e2_add(run, trow[j]);
+  }
 }
 
 // ---- exclusive scan of Ext2 values (field addition), three launches
@@ -144,16 +168,16 @@ __global__ __launch_bounds__(256) void scan_add_k(E2* __restrict__ out, size_t n
 }
 
 __global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n, E2 beta,
-                                                    E2 gamma, E2* __restrict__ partial) {
+                                                    E2 gamma, GammaPows gp, E2* __restrict__ partial) {
   __shared__ E2 sh[256];
-  size_t base = (blockIdx.x * size_t(256) + threadIdx.x) * INV_CHUNK;
-  E2 msg[INV_CHUNK], pre[INV_CHUNK];
+  size_t base = (blockIdx.x * size_t(256) + threadIdx.x) * CLAIMS_CHUNK;
+  E2 msg[CLAIMS_CHUNK], pre[CLAIMS_CHUNK];
   E2 acc = e2(1), sum = e2(0);
 #pragma unroll
-  for (int t = 0; t < INV_CHUNK; t++) {
+  for (int t = 0; t < CLAIMS_CHUNK; t++) {
     size_t i = base + t;
     if (i < n) {
-      msg[t] = message(data + offs[i], (u32)(offs[i + 1] - offs[i]), beta, gamma);
+      msg[t] = message(data + offs[i], (u32)(offs[i + 1] - offs[i]), beta, gamma, gp);
       pre[t] = acc;
       acc = e2_mul(acc, msg[t]);
     }
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data
   if (base < n) {
     E2 inv = e2_inv(acc);
 #pragma unroll
-    for (int t = INV_CHUNK - 1; t >= 0; t--) {
+    for (int t = CLAIMS_CHUNK - 1; t >= 0; t--) {
       size_t i = base + t;
       if (i < n) {
         sum = e2_add(sum, e2_mul(inv, pre[t]));
@@ -205,6 +229,17 @@ static E2 scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n) {
   return total;
 }
 
+static GammaPows gamma_pows(E2 gamma, size_t max_args) {
+  GammaPows gp;
+  gp.n = (u32)(max_args < (size_t)MAX_GPOW ? max_args : (size_t)MAX_GPOW);
+  E2 g = e2(1);
+  for (int i = 0; i < MAX_GPOW; i++) {
+    gp.g[i] = g;
+    g = e2_mul(g, gamma);
+  }
+  return gp;
+}
+
 E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
   size_t n = lk.height;
   if (lk.num_lookups == 0) {
@@ -213,28 +248,29 @@ E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
     return e2(0);
   }
   unsigned logn = log2_strict(n);
-  DBuf<E2> rowsum(ctx, n), prefix(ctx, n);
-  dim3 grid((unsigned)((n + 255) / 256));
   u32 L = (u32)lk.num_lookups, aw = (u32)lk.args_width;
+  DBuf<E2> rowsum(ctx, n), prefix(ctx, n), terms(ctx, n * L);
+  dim3 grid((unsigned)((n + 255) / 256));
+  GammaPows gp = gamma_pows(gamma, MAX_GPOW);
   hipEvent_t ev = ctx.prof_begin(K_STAGE2);
-  hipLaunchKernelGGL(stage2_rowsum_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma,
-                     rowsum.p);
+  hipLaunchKernelGGL(stage2_terms_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma, gp,
+                     terms.p, rowsum.p);
   ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw));
   E2 total = scan_exclusive(ctx, rowsum.p, prefix.p, n);
   ev = ctx.prof_begin(K_STAGE2);
-  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, logn, L, aw, beta,
-                     gamma, prefix.p, out);
-  ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw + 2 * L));
+  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out);
+  ctx.prof_end(K_STAGE2, ev, double(n) * 16.0 * L);
   HIP_CHECK(hipGetLastError());
   return total;
 }
 
 E2 claims_accumulator(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, E2 beta, E2 gamma) {
   if (n == 0) return e2(0);
-  size_t per = 256 * INV_CHUNK;
+  size_t per = 256 * CLAIMS_CHUNK;
   size_t nb = (n + per - 1) / per;
   DBuf<E2> partial(ctx, nb);
-  hipLaunchKernelGGL(claims_acc_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, d_data, d_offs, n, beta, gamma, partial.p);
+  GammaPows gp = gamma_pows(gamma, MAX_GPOW);
+  hipLaunchKernelGGL(claims_acc_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, d_data, d_offs, n, beta, gamma, gp, partial.p);
   HIP_CHECK(hipGetLastError());
   std::vector<E2> h(nb);
   ctx.d2h(h.data(), partial.p, nb * sizeof(E2));

@@ -169,6 +169,8 @@ struct DTree {
   std::vector<const u64*> mat_d;   // matrices in input order (not owned)
   std::vector<size_t> mat_h, mat_w;
   DBuf<Digest> digests;            // all layers back to back, leaf layer first
+  Digest* ext = nullptr;           // layers living in someone else's buffer (FRI tail rounds); overrides `digests`
+  Digest* base() const { return ext ? ext : digests.p; }
   std::vector<size_t> layer_off, layer_len;
   unsigned cap_height = 0;
   size_t max_height() const { return layer_len.empty() ? 0 : layer_len[0]; }
@@ -258,6 +260,22 @@ struct GatherReq {
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes);
 // proof-of-work search on the device (single-chunk transcripts); false = not applicable, use the host loop
 bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out);
+// Last FRI rounds (vectors of <= 2048 elements) in ONE single-workgroup launch: per round leaf hashes, tree, the
+// challenger step (observe root, grind, sample beta) and the fold all stay on the device; the host replays the
+// transcript from the returned roots / witnesses / betas afterwards. cap_height 0 only.
+struct FriTailRound {
+  uint32_t root[8];
+  uint64_t witness;
+  E2 beta;
+};
+struct FriTailRoll {
+  const E2* p;
+  uint32_t len;
+  uint32_t pad;
+};
+void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, const uint8_t state32[32],
+              const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, std::vector<FriTailRound>& rounds_out,
+              std::vector<E2>& final_out);
 // cap of a tree + (when it fits) the PoW witness for transcript prefix || cap, in one host synchronisation
 std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<uint8_t>& prefix, unsigned bits, bool* found,
                                   u64* witness);

@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
 template <bool DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
                                                const u64* __restrict__ twc, const u64* __restrict__ t0,
-                                               const u64* __restrict__ t1, unsigned src_div, const u64* __restrict__ scale,
-                                               u64 out_mul) {
+                                               const u64* __restrict__ t1, const u64* __restrict__ ttab, unsigned src_div,
+                                               const u64* __restrict__ scale, u64 out_mul) {
   __shared__ u64 sm[NTT12_LDS];
   const size_t n = size_t(1) << logn;
   const unsigned logB = 8 + logS;
@@ -312,16 +312,17 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
     for (int j = 0; j < 16; j++) {
       // h = hq * 16 + j, bitrev8(h) = bitrev4(j) * 16 + bitrev4(hq)
       const u32 rev = (u32)(((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) << 4) + rev_hq;
-      u64 v = gl_mul(x[j], tw_lookup(t0, t1, (lg * rev) << esh));
+      const size_t pos = (size_t(hq * 16 + j) << logS) + lg;
+      u64 v = gl_mul(x[j], ttab ? ttab[pos] : tw_lookup(t0, t1, (lg * rev) << esh));
       if (out_mul != 1) v = gl_mul(v, out_mul);
-      d[(size_t(hq * 16 + j) << logS) + lg] = v;
+      d[pos] = v;
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const u32 rev = (u32)(((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) << 4) + rev_hq;
-      u64 v = s[(size_t(hq * 16 + j) << logS) + lg];
-      x[j] = gl_mul(v, tw_lookup(t0, t1, (lg * rev) << esh));
+      const size_t pos = (size_t(hq * 16 + j) << logS) + lg;
+      x[j] = gl_mul(s[pos], ttab ? ttab[pos] : tw_lookup(t0, t1, (lg * rev) << esh));
     }
     reg_stages16_uniform<true, INV>(x);  // h bits 0..3
 #pragma unroll
@@ -337,6 +338,30 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
       d[(size_t(hq + 16 * j) << logS) + lg] = v;
     }
   }
+}
+
+// inter-pass twiddle table of the 8-bit strided pass on blocks of 2^logB: tab[h * S + l] = w_B^{l * bitrev8(h)}
+__global__ void ntt8s_table_k(u64* __restrict__ tab, unsigned logB, const u64* __restrict__ t0, const u64* __restrict__ t1) {
+  const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= (size_t(1) << logB)) return;
+  const unsigned logS = logB - 8;
+  const u32 h = (u32)(i >> logS), l = (u32)(i & ((size_t(1) << logS) - 1));
+  tab[i] = tw_lookup(t0, t1, (l * bitrev32(h, 8)) << (TW_LOG - logB));
+}
+
+const u64* ntt8s_table(Ctx& ctx, unsigned logB, bool inverse) {
+  if (logB > 22) return nullptr;  // 32 MiB at most; larger blocks compute the factor from the two-level tables
+  auto key = std::make_pair(logB + (inverse ? 100u : 0u), 0xFFu);
+  auto it = ctx.lde_scales.find(key);
+  if (it != ctx.lde_scales.end()) return it->second;
+  size_t cnt = size_t(1) << logB;
+  u64* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, cnt * 8));
+  hipLaunchKernelGGL(ntt8s_table_k, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx.stream, p, logB,
+                     inverse ? ctx.tw0i : ctx.tw0, inverse ? ctx.tw1i : ctx.tw1);
+  HIP_CHECK(hipGetLastError());
+  ctx.lde_scales[key] = p;
+  return p;
 }
 
 struct Plan {
@@ -368,12 +393,13 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
     size_t gx8 = (size_t(1) << (logS - 4)) << (logn - logB);
     const int id = DIT ? K_NTT8S_DIT : K_NTT8S_DIF;
     hipEvent_t ev8 = ctx.prof_begin(id);
+    const u64* ttab = ntt8s_table(ctx, logB, inverse);
     if (inverse)
       hipLaunchKernelGGL((ntt8s_k<(DIT != 0), true>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twci, ctx.tw0i, ctx.tw1i, src_div, scale, out_mul);
+                         logn, ctx.twci, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul);
     else
       hipLaunchKernelGGL((ntt8s_k<(DIT != 0), false>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twc, ctx.tw0, ctx.tw1, src_div, scale, out_mul);
+                         logn, ctx.twc, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul);
     ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }

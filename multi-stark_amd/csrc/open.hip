@@ -76,19 +76,22 @@ __global__ __launch_bounds__(256) void bary_partial_k(const u64* __restrict__ ma
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (u32 c = 0; c < w; c++) {
     const u64* col = mat + size_t(c) * mat_h;
-    u64 a[NP * 2];
+    GlAcc acc[NP * 2];
 #pragma unroll
-    for (int j = 0; j < NP * 2; j++) a[j] = 0;
+    for (int j = 0; j < NP * 2; j++) acc_init(acc[j]);
 #pragma unroll
     for (int k = 0; k < BARY_ROWS; k++) {
       size_t i = base + size_t(k) * 256 + threadIdx.x;
       u64 v = i < h ? col[i] : 0;
 #pragma unroll
       for (int p = 0; p < NP; p++) {
-        a[2 * p] = gl_add(a[2 * p], gl_mul(cs[k][p].c0, v));
-        a[2 * p + 1] = gl_add(a[2 * p + 1], gl_mul(cs[k][p].c1, v));
+        acc_mad(acc[2 * p], cs[k][p].c0, v);
+        acc_mad(acc[2 * p + 1], cs[k][p].c1, v);
       }
     }
+    u64 a[NP * 2];
+#pragma unroll
+    for (int j = 0; j < NP * 2; j++) a[j] = acc_reduce(acc[j]);
 #pragma unroll
     for (int j = 0; j < NP * 2; j++) a[j] = wave_sum(a[j]);
     if (lane == 0) {
@@ -137,16 +140,38 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
     acc1 = p.ro[i + 1];
   }
   for (u32 m = 0; m < p.nmats; m++) {
-    const DeepMat dm = p.mats[m];
-    u64 s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-    for (u32 c = 0; c < dm.w; c++) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(dm.d + size_t(c) * p.height + i);
-      const E2 a = p.apow[c];
-      s00 = gl_add(s00, gl_mul(a.c0, v.x));
-      s01 = gl_add(s01, gl_mul(a.c1, v.x));
-      s10 = gl_add(s10, gl_mul(a.c0, v.y));
-      s11 = gl_add(s11, gl_mul(a.c1, v.y));
+    const DeepMat& dm = p.mats[m];
+    // sum_c alpha^c * m[i][c]: base x ext terms, accumulated unreduced (one reduction per coordinate)
+    GlAcc a00, a01, a10, a11;
+    acc_init(a00);
+    acc_init(a01);
+    acc_init(a10);
+    acc_init(a11);
+    const u64* __restrict__ md = dm.d + i;
+    const u32 mw = dm.w;
+    u32 c = 0;
+    for (; c + 4 <= mw; c += 4) {
+      ulonglong2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const ulonglong2*>(md + size_t(c + u) * p.height);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const E2 a = p.apow[c + u];
+        acc_mad(a00, a.c0, v[u].x);
+        acc_mad(a01, a.c1, v[u].x);
+        acc_mad(a10, a.c0, v[u].y);
+        acc_mad(a11, a.c1, v[u].y);
+      }
     }
+    for (; c < mw; c++) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(md + size_t(c) * p.height);
+      const E2 a = p.apow[c];
+      acc_mad(a00, a.c0, v.x);
+      acc_mad(a01, a.c1, v.x);
+      acc_mad(a10, a.c0, v.y);
+      acc_mad(a11, a.c1, v.y);
+    }
+    const u64 s00 = acc_reduce(a00), s01 = acc_reduce(a01), s10 = acc_reduce(a10), s11 = acc_reduce(a11);
     for (u32 q = 0; q < dm.npoints; q++) {
       const E2* den = p.den[dm.inv_idx[q]];
       E2 d0 = e2(gl_sub(dm.red_z[q].c0, s00), gl_sub(dm.red_z[q].c1, s01));
@@ -266,6 +291,203 @@ __global__ __launch_bounds__(256) void grind_cap_k(GrindCapParams p, const u32* 
   if ((v & p.mask) == 0) atomicMin(best, (unsigned long long)w);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// FRI tail: every remaining commit-phase round in one single-workgroup launch (vectors of <= 2048 elements).
+struct FriTailParams {
+  const E2* cur0;
+  u32 len0, n_rounds, pow_bits, n_roll;
+  u32 state[8];  // challenger input buffer (one 32-byte digest) as little-endian words
+  FriTailRoll roll[8];
+  Digest* tree_out;   // round r: rows_r + rows_r/2 + ... + 1 digests, rounds back to back
+  E2* layers_out;     // input vectors of rounds 1.. (round 0's input is cur0), back to back
+  E2* final_out;
+  FriTailRound* rounds;
+  const u64 *t0i, *t1i;
+};
+
+__device__ __forceinline__ u64 be64_at(const u32* d, int pos) {
+  // the challenger pops bytes from the back: the u64 built from digest bytes [pos, pos + 8) read big-endian
+  return (u64)__builtin_bswap32(d[pos / 4 + 1]) | ((u64)__builtin_bswap32(d[pos / 4]) << 32);
+}
+
+__global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
+  __shared__ E2 cur[2048];
+  __shared__ __attribute__((aligned(16))) u32 tree[1024 * 8];
+  __shared__ u32 st[8];     // challenger state (latest digest)
+  __shared__ u32 dg[8];     // working digest for sampling
+  __shared__ unsigned long long best;
+  __shared__ E2 beta_sh;
+  const u32 t = threadIdx.x;
+  u32 len = p.len0;
+  for (u32 i = t; i < len; i += 1024) cur[i] = p.cur0[i];
+  if (t < 8) st[t] = p.state[t];
+  __syncthreads();
+  Digest* tout = p.tree_out;
+  E2* lout = p.layers_out;
+  u32 roll_i = 0;
+  while (roll_i < p.n_roll && p.roll[roll_i].len >= len) roll_i++;  // inputs taller than the tail never roll in here
+  const u64 half = 0x7FFFFFFF80000001ULL;  // 1/2 mod p
+  for (u32 r = 0; r < p.n_rounds; r++) {
+    const u32 rows = len >> 1;
+    const unsigned log_rows = 31 - __clz(rows);
+    // ---- leaf digests (ExtensionMmcs rows of two Ext2 values = 32 bytes)
+    if (t < rows) {
+      E2 lo = cur[2 * t], hi = cur[2 * t + 1];
+      u32 m[16];
+      m[0] = (u32)lo.c0;
+      m[1] = (u32)(lo.c0 >> 32);
+      m[2] = (u32)lo.c1;
+      m[3] = (u32)(lo.c1 >> 32);
+      m[4] = (u32)hi.c0;
+      m[5] = (u32)(hi.c0 >> 32);
+      m[6] = (u32)hi.c1;
+      m[7] = (u32)(hi.c1 >> 32);
+#pragma unroll
+      for (int k = 8; k < 16; k++) m[k] = 0;
+      u32 cv[8];
+      b3_iv(cv);
+      b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      uint4* q = reinterpret_cast<uint4*>(tree + t * 8);
+      q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+      q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+      uint4* g = reinterpret_cast<uint4*>(tout + t);
+      g[0] = q[0];
+      g[1] = q[1];
+    }
+    __syncthreads();
+    tout += rows;
+    // ---- tree levels
+    for (u32 n = rows >> 1; n >= 1; n >>= 1) {
+      u32 d[8];
+      if (t < n) {
+        u32 m[16];
+        const uint4* q = reinterpret_cast<const uint4*>(tree + 2 * t * 8);
+        uint4 a = q[0], b = q[1], c = q[2], e = q[3];
+        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+        m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = e.x; m[13] = e.y; m[14] = e.z; m[15] = e.w;
+        b3_iv(d);
+        b3_compress(d, m, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      }
+      __syncthreads();
+      if (t < n) {
+        uint4* q = reinterpret_cast<uint4*>(tree + t * 8);
+        q[0] = make_uint4(d[0], d[1], d[2], d[3]);
+        q[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        uint4* g = reinterpret_cast<uint4*>(tout + t);
+        g[0] = q[0];
+        g[1] = q[1];
+      }
+      __syncthreads();
+      tout += n;
+    }
+    // ---- challenger: observe the root, grind, sample beta. Transcript block 0 = state || root (64 bytes).
+    u32 blk0[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      blk0[k] = st[k];
+      blk0[8 + k] = tree[k];
+    }
+    u64 wit = 0;
+    if (p.pow_bits) {
+      u32 mid[8];
+      b3_iv(mid);
+      b3_compress(mid, blk0, 0, 64, B3_CHUNK_START);
+      if (t == 0) best = ~0ull;
+      __syncthreads();
+      const u64 mask = (u64(1) << p.pow_bits) - 1;
+      for (u64 base = 0;; base += 1024) {
+        const u64 w = base + t;
+        u32 m[16];
+        m[0] = (u32)w;
+        m[1] = (u32)(w >> 32);
+#pragma unroll
+        for (int k = 2; k < 16; k++) m[k] = 0;
+        u32 cv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cv[k] = mid[k];
+        b3_compress(cv, m, 0, 8, B3_CHUNK_END | B3_ROOT);
+        const u64 v = (u64)__builtin_bswap32(cv[7]) | ((u64)__builtin_bswap32(cv[6]) << 32);
+        if ((v & mask) == 0) atomicMin(&best, (unsigned long long)w);
+        __syncthreads();
+        const unsigned long long b = best;
+        __syncthreads();
+        if (b != ~0ull) {
+          wit = b;
+          break;
+        }
+      }
+    }
+    if (t == 0) {
+      u32 cv[8];
+      b3_iv(cv);
+      int pos;
+      if (p.pow_bits) {
+        b3_compress(cv, blk0, 0, 64, B3_CHUNK_START);
+        u32 m[16];
+        m[0] = (u32)wit;
+        m[1] = (u32)(wit >> 32);
+        for (int k = 2; k < 16; k++) m[k] = 0;
+        b3_compress(cv, m, 0, 8, B3_CHUNK_END | B3_ROOT);
+        pos = 24;  // check_witness' sample_bits consumed digest bytes 24..31
+      } else {
+        b3_compress(cv, blk0, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+        pos = 32;
+      }
+      for (int k = 0; k < 8; k++) dg[k] = cv[k];
+      u64 c[2];
+      for (int ci = 0; ci < 2; ci++) {
+        for (;;) {
+          if (pos == 0) {  // output buffer exhausted: flush, i.e. digest <- BLAKE3(digest)
+            u32 m[16], nv[8];
+            for (int k = 0; k < 8; k++) m[k] = dg[k];
+            for (int k = 8; k < 16; k++) m[k] = 0;
+            b3_iv(nv);
+            b3_compress(nv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+            for (int k = 0; k < 8; k++) dg[k] = nv[k];
+            pos = 32;
+          }
+          pos -= 8;
+          const u64 v = be64_at(dg, pos);
+          if (v < GL_P) {
+            c[ci] = v;
+            break;
+          }
+        }
+      }
+      for (int k = 0; k < 8; k++) st[k] = dg[k];
+      beta_sh = e2(c[0], c[1]);
+      FriTailRound& out = p.rounds[r];
+      for (int k = 0; k < 8; k++) out.root[k] = tree[k];
+      out.witness = wit;
+      out.beta = beta_sh;
+    }
+    __syncthreads();
+    // ---- fold (+ roll-in of a reduced opening of matching length)
+    const E2 beta = beta_sh;
+    const E2 hb = e2_mul_base(beta, half);
+    const bool do_roll = roll_i < p.n_roll && p.roll[roll_i].len == rows;
+    E2 nv = e2(0);
+    if (t < rows) {
+      u32 e = bitrev32(t, log_rows) << (TW_LOG - log_rows - 1);
+      u64 gp = gl_mul(p.t1i[e >> TW_HALF], p.t0i[e & ((1u << TW_HALF) - 1)]);
+      E2 pw = e2_mul_base(hb, gp);
+      E2 lo = cur[2 * t], hi = cur[2 * t + 1];
+      nv = e2_add(e2_mul(e2(gl_add(half, pw.c0), pw.c1), lo), e2_mul(e2(gl_sub(half, pw.c0), gl_neg(pw.c1)), hi));
+      if (do_roll) nv = e2_add(nv, e2_mul(e2_sqr(beta), p.roll[roll_i].p[t]));
+    }
+    __syncthreads();
+    if (t < rows) {
+      cur[t] = nv;
+      if (r + 1 < p.n_rounds) lout[t] = nv;
+    }
+    if (do_roll) roll_i++;
+    lout += rows;
+    len = rows;
+    __syncthreads();
+  }
+  if (t < len) p.final_out[t] = cur[t];
+}
+
 __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* __restrict__ out) {
   size_t r = blockIdx.x;
   if (r >= n) return;
@@ -353,7 +575,7 @@ void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in, 
 void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows) {
   merkle_alloc(ctx, t, rows);
   hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
-  hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.digests.p);
+  hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.base());
   ctx.prof_end(K_LEAF_HASH, ev, 64.0 * rows);
   HIP_CHECK(hipGetLastError());
   merkle_compress_plain(ctx, t);
@@ -411,7 +633,7 @@ std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<ui
   *found = false;
   const bool fits = bits > 0 && bits <= 40 && (prefix.size() % 4) == 0 && prefix.size() + 32 * ncap + 8 <= 128;
   if (!fits) {
-    ctx.d2h(cap.data(), t.digests.p + t.layer_off[cl], ncap * sizeof(Digest));
+    ctx.d2h(cap.data(), t.base() + t.layer_off[cl], ncap * sizeof(Digest));
     return cap;
   }
   GrindCapParams p;
@@ -425,16 +647,47 @@ std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<ui
   HIP_CHECK(hipMemsetAsync(best.p, 0xff, 8, ctx.stream));
   const u64 batch = u64(1) << (bits + 6 < 16 ? 16 : bits + 6 > 24 ? 24 : bits + 6);
   hipLaunchKernelGGL(grind_cap_k, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx.stream, p,
-                     (const u32*)(t.digests.p + t.layer_off[cl]), best.p);
+                     (const u32*)(t.base() + t.layer_off[cl]), best.p);
   HIP_CHECK(hipGetLastError());
   unsigned long long r = 0;
-  HIP_CHECK(hipMemcpyAsync(cap.data(), t.digests.p + t.layer_off[cl], ncap * sizeof(Digest), hipMemcpyDeviceToHost, ctx.stream));
+  HIP_CHECK(hipMemcpyAsync(cap.data(), t.base() + t.layer_off[cl], ncap * sizeof(Digest), hipMemcpyDeviceToHost, ctx.stream));
   ctx.d2h(&r, best.p, 8);
   if (r != ~0ull) {
     *found = true;
     *witness = r;
   }
   return cap;
+}
+
+void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, const uint8_t state32[32],
+              const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, std::vector<FriTailRound>& rounds_out,
+              std::vector<E2>& final_out) {
+  if (len0 > 2048 || len0 < 2 || (len0 & (len0 - 1))) throw std::runtime_error("fri_tail: bad length");
+  if (rolls.size() > 8) throw std::runtime_error("fri_tail: too many roll-in inputs");
+  FriTailParams p;
+  memset(&p, 0, sizeof(p));
+  p.cur0 = cur0;
+  p.len0 = len0;
+  p.n_rounds = n_rounds;
+  p.pow_bits = pow_bits;
+  p.n_roll = (u32)rolls.size();
+  memcpy(p.state, state32, 32);
+  for (size_t i = 0; i < rolls.size(); i++) p.roll[i] = rolls[i];
+  p.tree_out = tree_out;
+  p.layers_out = layers_out;
+  const size_t final_len = len0 >> n_rounds;
+  DBuf<E2> d_final(ctx, final_len);
+  DBuf<FriTailRound> d_rounds(ctx, n_rounds);
+  p.final_out = d_final.p;
+  p.rounds = d_rounds.p;
+  p.t0i = ctx.tw0i;
+  p.t1i = ctx.tw1i;
+  hipLaunchKernelGGL(fri_tail_k, dim3(1), dim3(1024), 0, ctx.stream, p);
+  HIP_CHECK(hipGetLastError());
+  rounds_out.resize(n_rounds);
+  final_out.resize(final_len);
+  HIP_CHECK(hipMemcpyAsync(rounds_out.data(), d_rounds.p, n_rounds * sizeof(FriTailRound), hipMemcpyDeviceToHost, ctx.stream));
+  ctx.d2h(final_out.data(), d_final.p, final_len * sizeof(E2));
 }
 
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes) {

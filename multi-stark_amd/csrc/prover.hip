@@ -613,14 +613,73 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   // ---- FRI commit phase (prove_fri / commit_phase)
   const size_t final_len = size_t(1) << prm.log_final_poly_len;
   const size_t stop = (size_t(1) << lb) * final_len;
-  std::vector<DBuf<E2>> layers;  // folded vectors kept for the query phase
+  std::vector<DBuf<E2>> layer_bufs;   // owners of the folded vectors kept for the query phase
+  std::vector<const E2*> layers;      // input vector of every commit-phase round
   std::vector<DTree> trees;
   std::vector<std::vector<Digest>> commits;
   std::vector<u64> pow_w;
   DBuf<E2> folded = std::move(inputs[0]);
   size_t next_in = 1;
   const unsigned log_max_height = log2_strict(folded.n);
+  std::vector<E2> fin;                // final folded vector (host)
+  DBuf<Digest> tail_tree;
+  DBuf<E2> tail_layers;
   while (folded.n > stop) {
+    // ---- last rounds on the device in one launch (see fri_tail_k): needs a root-only commitment and the
+    // challenger's pending input to be exactly one digest (true right after a sample)
+    if (folded.n <= 2048 && prm.cap_height == 0 && ch.input.size() == 32 && !getenv("MSAMD_NO_FRI_TAIL")) {
+      const uint32_t len0 = (uint32_t)folded.n;
+      uint32_t n_rounds = 0;
+      size_t tree_digests = 0, layer_elems = 0;
+      for (size_t l = len0; l > stop; l >>= 1) {
+        n_rounds++;
+        tree_digests += l - 1;            // rows + rows/2 + ... + 1 with rows = l/2
+        if (l != len0) layer_elems += l;  // inputs of rounds 1..
+      }
+      std::vector<FriTailRoll> rolls;
+      for (size_t k = next_in; k < inputs.size(); k++) rolls.push_back(FriTailRoll{inputs[k].p, (uint32_t)inputs[k].n, 0});
+      tail_tree = DBuf<Digest>(ctx, tree_digests);
+      tail_layers = DBuf<E2>(ctx, std::max<size_t>(layer_elems, 1));
+      std::vector<FriTailRound> rr;
+      fri_tail(ctx, folded.p, len0, n_rounds, (unsigned)prm.commit_pow_bits, ch.input.data(), rolls, tail_tree.p, tail_layers.p, rr,
+               fin);
+      // replay the transcript on the host challenger; the device values are checked, not trusted
+      size_t toff = 0, loff = 0;
+      size_t l = len0;
+      for (uint32_t r = 0; r < n_rounds; r++, l >>= 1) {
+        const size_t rows = l / 2;
+        trees.emplace_back();
+        DTree& t = trees.back();
+        t.cap_height = 0;
+        t.ext = tail_tree.p + toff;
+        size_t o = 0;
+        for (size_t n = rows;; n >>= 1) {
+          t.layer_off.push_back(o);
+          t.layer_len.push_back(n);
+          o += n;
+          if (n == 1) break;
+        }
+        toff += o;
+        layers.push_back(r == 0 ? folded.p : tail_layers.p + loff);
+        if (r > 0) loff += l;
+        Digest root;
+        memcpy(root.b, rr[r].root, 32);
+        std::vector<Digest> cap(1, root);
+        ch.observe_cap(cap);
+        commits.push_back(cap);
+        if (prm.commit_pow_bits) {
+          ch.observe(rr[r].witness);
+          if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("fri_tail: witness rejected by the host challenger");
+        }
+        pow_w.push_back(prm.commit_pow_bits ? rr[r].witness : 0);
+        E2 beta = ch.sample_ext();
+        if (!e2_same(beta, rr[r].beta)) throw std::runtime_error("fri_tail: device challenger diverged from the host transcript");
+        if (next_in < inputs.size() && inputs[next_in].n == rows) next_in++;
+      }
+      layer_bufs.push_back(std::move(folded));
+      folded = DBuf<E2>();
+      break;
+    }
     size_t rows = folded.n / 2;
     trees.emplace_back();
     DTree& t = trees.back();
@@ -643,15 +702,19 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     const E2* roll = nullptr;
     if (next_in < inputs.size() && inputs[next_in].n == rows) roll = inputs[next_in].p;
     fri_fold(ctx, folded.p, rows, beta, roll, nxt.p);
-    if (roll) inputs[next_in++].reset();
-    layers.push_back(std::move(folded));
+    if (roll) next_in++;
+    layers.push_back(folded.p);
+    layer_bufs.push_back(std::move(folded));
     folded = std::move(nxt);
   }
   tr.mark("fri_commit_phase");
   if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
+  if (folded.p) {
+    fin.resize(folded.n);
+    ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
+  }
   // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
-  std::vector<E2> fin(folded.n);
-  ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
+  if (fin.size() != stop) throw std::runtime_error("FRI: unexpected final length");
   std::vector<E2> final_poly(final_len);
   {
     unsigned lf = (unsigned)prm.log_final_poly_len;
@@ -694,13 +757,13 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       unsigned lmh = log2_strict(t.max_height());
       size_t ridx = index >> (log_gmax - lmh);
       for (auto& m : r.data->ldes) add_req(m.d(), m.h, ridx >> (lmh - log2_strict(m.h)), (uint32_t)m.w, 0);
-      for (size_t i = 0; i < n_siblings(t); i++) add_req(t.digests.p + t.layer_off[i], 0, (ridx >> i) ^ 1, 1, 1);
+      for (size_t i = 0; i < n_siblings(t); i++) add_req(t.base() + t.layer_off[i], 0, (ridx >> i) ^ 1, 1, 1);
     }
     for (size_t i = 0; i < trees.size(); i++) {
       size_t index_i = index >> i, sib = index_i ^ 1, pair = index_i >> 1;
-      add_req((const u64*)(layers[i].p + 2 * pair + (sib & 1)), 1, 0, 2, 0);
+      add_req((const u64*)(layers[i] + 2 * pair + (sib & 1)), 1, 0, 2, 0);
       const DTree& t = trees[i];
-      for (size_t l = 0; l < n_siblings(t); l++) add_req(t.digests.p + t.layer_off[l], 0, (pair >> l) ^ 1, 1, 1);
+      for (size_t l = 0; l < n_siblings(t); l++) add_req(t.base() + t.layer_off[l], 0, (pair >> l) ^ 1, 1, 1);
     }
   }
   tr.mark("final_poly+grind");

@@ -36,6 +36,7 @@ struct QParams {
   u64* out;
   u64* scratch;       // global slot storage (when !LDS)
   size_t row0, rows;  // batch of storage rows handled by this launch
+  E2 gpow[32];        // gamma^0 .. gamma^31: fingerprints as unreduced base x ext dot products
 };
 
 __device__ __forceinline__ void mul2(u64 a0, u64 a1, u64 b0, u64 b1, u64& c0, u64& c1) {
@@ -98,20 +99,24 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
   }
 
   // fold: user roots first, then the logUp values, constraint i weighted by alpha^{k-1-i}
-  u64 acc0 = 0, acc1 = 0;
+  GlAcc fa0, fa1;  // unreduced sums of (constraint value) x (alpha power coordinate)
+  acc_init(fa0);
+  acc_init(fa1);
   u32 ci = 0;
   for (u32 z = 0; z < p.n_zeros; z++, ci++) {
     u64 cv = slots[p.zero_slots[z] * stride];
     E2 a = p.alpha_rev[ci];
-    acc0 = gl_add(acc0, gl_mul(cv, a.c0));
-    acc1 = gl_add(acc1, gl_mul(cv, a.c1));
+    acc_mad(fa0, cv, a.c0);
+    acc_mad(fa1, cv, a.c1);
   }
   const u64 beta0 = p.publics[0], beta1 = p.publics[1], gamma0 = p.publics[2], gamma1 = p.publics[3];
   const u64 inj0 = gl_mul(is_last, p.delta_scaled[0]), inj1 = gl_mul(is_last, p.delta_scaled[1]);
   auto fold2 = [&](u64 c0, u64 c1) {
     E2 a = p.alpha_rev[ci], b = p.alpha_rev[ci + 1];
-    acc0 = gl_add(acc0, gl_add(gl_mul(c0, a.c0), gl_mul(c1, b.c0)));
-    acc1 = gl_add(acc1, gl_add(gl_mul(c0, a.c1), gl_mul(c1, b.c1)));
+    acc_mad(fa0, c0, a.c0);
+    acc_mad(fa0, c1, b.c0);
+    acc_mad(fa1, c0, a.c1);
+    acc_mad(fa1, c1, b.c1);
     ci += 2;
   };
   if (p.n_lookups == 0) {
@@ -131,12 +136,26 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
         tgt0 = gl_add(p.s2[tn], inj0);
         tgt1 = gl_add(p.s2[p.s2_h + tn], inj1);
       }
+      // fingerprint = sum_k args[k] gamma^k (src/lookup.rs:192-197)
       u64 f0 = 0, f1 = 0;
-      for (u32 k = na; k-- > 0;) {
-        u64 g0, g1;
-        mul2(f0, f1, gamma0, gamma1, g0, g1);
-        f0 = gl_add(g0, slots[ls[2 + k] * stride]);
-        f1 = g1;
+      if (na <= 32) {
+        GlAcc g0, g1;
+        acc_init(g0);
+        acc_init(g1);
+        for (u32 k = 0; k < na; k++) {
+          const u64 v = slots[ls[2 + k] * stride];
+          acc_mad(g0, v, p.gpow[k].c0);
+          acc_mad(g1, v, p.gpow[k].c1);
+        }
+        f0 = acc_reduce(g0);
+        f1 = acc_reduce(g1);
+      } else {
+        for (u32 k = na; k-- > 0;) {
+          u64 g0, g1;
+          mul2(f0, f1, gamma0, gamma1, g0, g1);
+          f0 = gl_add(g0, slots[ls[2 + k] * stride]);
+          f1 = g1;
+        }
       }
       u64 c0, c1;
       mul2(gl_add(f0, beta0), gl_add(f1, beta1), gl_sub(tgt0, src0), gl_sub(tgt1, src1), c0, c1);
@@ -149,8 +168,8 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
     }
   }
   const u64 iv = p.zh_inv[qi];
-  p.out[t] = gl_mul(acc0, iv);
-  p.out[nq + t] = gl_mul(acc1, iv);
+  p.out[t] = gl_mul(acc_reduce(fa0), iv);
+  p.out[nq + t] = gl_mul(acc_reduce(fa1), iv);
 }
 
 }  // namespace
@@ -321,6 +340,13 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
   p.t1 = ctx.tw1;
   p.out = out;
   p.scratch = nullptr;
+  {
+    E2 g = e2(1), gam = e2(a.publics[2], a.publics[3]);
+    for (int i = 0; i < 32; i++) {
+      p.gpow[i] = g;
+      g = e2_mul(g, gam);
+    }
+  }
 
   const double bytes = double(nq) * 8.0 * (2.0 * (prog.main_w + prog.s2_w + prog.pre_w) + 2.0);
   unsigned threads = 256;
