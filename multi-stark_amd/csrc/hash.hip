@@ -20,12 +20,21 @@ struct RowIter {
   size_t H, row;
   unsigned mi;
   u32 c;
+  const u64* cur;  // column c of matrix mi at this row
+  u32 w;           // width of matrix mi
+  __device__ __forceinline__ void init() {
+    cur = g[0].d + row;
+    w = g[0].w;
+  }
   __device__ __forceinline__ u64 next() {
-    while (c == g[mi].w) {
+    while (c == w) {  // next matrix of the group (never taken for a single-matrix group)
       mi++;
       c = 0;
+      cur = g[mi].d + row;
+      w = g[mi].w;
     }
-    u64 v = g[mi].d[size_t(c) * H + row];
+    u64 v = *cur;
+    cur += H;
     c++;
     return v;
   }
@@ -45,7 +54,8 @@ __device__ __forceinline__ void parent_cv(const u32 l[8], const u32 r[8], u32 fl
 // BLAKE3 of the serialised row (total_w elements, 8 bytes each). MULTI: rows longer than one 1024-byte chunk.
 template <bool MULTI>
 __device__ __forceinline__ void hash_row(const MatRef* g, size_t H, size_t row, u32 total_w, u32 out[8]) {
-  RowIter it{g, H, row, 0, 0};
+  RowIter it{g, H, row, 0, 0, nullptr, 0};
+  it.init();
   u32 cv[8];
   b3_iv(cv);
   u32 m[16];

@@ -258,6 +258,18 @@ struct GatherReq {
   uint64_t out_off;   // byte offset in the output buffer
 };
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes);
+// query-phase gather: the same segment list is applied to every query index on the device
+struct GatherSeg {
+  const void* base;   // matrix (u64, column-major), digest layer, or FRI layer (E2)
+  uint64_t stride;    // column stride for matrices
+  uint32_t count;     // columns of a matrix row; ignored otherwise
+  uint32_t kind;      // 0 = matrix row, 1 = digest, 2 = one E2 value
+  uint32_t shift;     // element index = (query_index >> shift) ^ flip
+  uint32_t flip;
+  uint64_t out_off;   // byte offset inside one query's block
+};
+void gather_queries(Ctx& ctx, const std::vector<GatherSeg>& segs, const std::vector<uint64_t>& indices, size_t bytes_per_query,
+                    uint8_t* host_out);
 // proof-of-work search on the device (single-chunk transcripts); false = not applicable, use the host loop
 bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out);
 // Last FRI rounds (vectors of <= 2048 elements) in ONE single-workgroup launch: per round leaf hashes, tree, the

@@ -503,6 +503,24 @@ __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* 
   }
 }
 
+__global__ void gather_queries_k(const GatherSeg* __restrict__ segs, const u64* __restrict__ indices, size_t qbytes,
+                                 uint8_t* __restrict__ out) {
+  const GatherSeg s = segs[blockIdx.x];
+  const u64 e = (indices[blockIdx.y] >> s.shift) ^ s.flip;
+  uint8_t* o = out + size_t(blockIdx.y) * qbytes + s.out_off;
+  if (s.kind == 0) {
+    const u64* m = (const u64*)s.base;
+    u64* ow = (u64*)o;
+    for (u32 c = threadIdx.x; c < s.count; c += blockDim.x) ow[c] = m[size_t(c) * s.stride + e];
+  } else if (s.kind == 1) {
+    const u32* d = (const u32*)((const Digest*)s.base + e);
+    if (threadIdx.x < 8) ((u32*)o)[threadIdx.x] = d[threadIdx.x];
+  } else {
+    const u32* d = (const u32*)((const E2*)s.base + e);
+    if (threadIdx.x < 4) ((u32*)o)[threadIdx.x] = d[threadIdx.x];
+  }
+}
+
 }  // namespace
 
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out) {
@@ -688,6 +706,20 @@ void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsign
   final_out.resize(final_len);
   HIP_CHECK(hipMemcpyAsync(rounds_out.data(), d_rounds.p, n_rounds * sizeof(FriTailRound), hipMemcpyDeviceToHost, ctx.stream));
   ctx.d2h(final_out.data(), d_final.p, final_len * sizeof(E2));
+}
+
+void gather_queries(Ctx& ctx, const std::vector<GatherSeg>& segs, const std::vector<uint64_t>& indices, size_t bytes_per_query,
+                    uint8_t* host_out) {
+  if (segs.empty() || indices.empty()) return;
+  DBuf<GatherSeg> ds(ctx, segs.size());
+  DBuf<u64> di(ctx, indices.size());
+  DBuf<uint8_t> dout(ctx, bytes_per_query * indices.size());
+  ctx.h2d(ds.p, segs.data(), segs.size() * sizeof(GatherSeg));
+  ctx.h2d(di.p, indices.data(), indices.size() * 8);
+  hipLaunchKernelGGL(gather_queries_k, dim3((unsigned)segs.size(), (unsigned)indices.size()), dim3(64), 0, ctx.stream, ds.p, di.p,
+                     bytes_per_query, dout.p);
+  HIP_CHECK(hipGetLastError());
+  ctx.d2h(host_out, dout.p, bytes_per_query * indices.size());
 }
 
 void gather_rows(Ctx& ctx, const std::vector<GatherReq>& reqs, uint8_t* host_out, size_t out_bytes) {

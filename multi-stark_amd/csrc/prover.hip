@@ -735,40 +735,41 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   const u64 query_pow = grind(ctx, ch, (unsigned)prm.query_pow_bits);
 
   // ---- query phase: sample every index, one gather for all openings
-  std::vector<size_t> indices(prm.num_queries);
-  for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
-  std::vector<GatherReq> reqs;
+  // the segment list (what to read for ONE query) is built while the device still works; only the indices follow
+  std::vector<GatherSeg> segs;
   size_t out_off = 0;
-  auto add_req = [&](const void* base, u64 stride, u64 index, uint32_t count, uint32_t kind) {
-    GatherReq q;
+  auto add_seg = [&](const void* base, u64 stride, uint32_t count, uint32_t kind, uint32_t shift, uint32_t flip) {
+    GatherSeg q;
     q.base = base;
     q.stride = stride;
-    q.index = index;
     q.count = count;
     q.kind = kind;
+    q.shift = shift;
+    q.flip = flip;
     q.out_off = out_off;
-    reqs.push_back(q);
-    out_off += kind == 0 ? size_t(count) * 8 : size_t(count) * 32;
+    segs.push_back(q);
+    out_off += kind == 0 ? size_t(count) * 8 : kind == 1 ? 32 : 16;
   };
   auto n_siblings = [](const DTree& t) { return t.cap_layer(); };
-  for (size_t index : indices) {
-    for (auto& r : rounds) {
-      const DTree& t = r.data->tree;
-      unsigned lmh = log2_strict(t.max_height());
-      size_t ridx = index >> (log_gmax - lmh);
-      for (auto& m : r.data->ldes) add_req(m.d(), m.h, ridx >> (lmh - log2_strict(m.h)), (uint32_t)m.w, 0);
-      for (size_t i = 0; i < n_siblings(t); i++) add_req(t.base() + t.layer_off[i], 0, (ridx >> i) ^ 1, 1, 1);
-    }
-    for (size_t i = 0; i < trees.size(); i++) {
-      size_t index_i = index >> i, sib = index_i ^ 1, pair = index_i >> 1;
-      add_req((const u64*)(layers[i] + 2 * pair + (sib & 1)), 1, 0, 2, 0);
-      const DTree& t = trees[i];
-      for (size_t l = 0; l < n_siblings(t); l++) add_req(t.base() + t.layer_off[l], 0, (pair >> l) ^ 1, 1, 1);
-    }
+  for (auto& r : rounds) {
+    const DTree& t = r.data->tree;
+    const unsigned lmh = log2_strict(t.max_height());
+    const unsigned sh0 = log_gmax - lmh;
+    for (auto& m : r.data->ldes) add_seg(m.d(), m.h, (uint32_t)m.w, 0, sh0 + (lmh - log2_strict(m.h)), 0);
+    for (size_t i = 0; i < n_siblings(t); i++) add_seg(t.base() + t.layer_off[i], 0, 1, 1, sh0 + (unsigned)i, 1);
   }
+  for (size_t i = 0; i < trees.size(); i++) {
+    // sibling value of round i sits at element (index >> i) ^ 1 of that round's vector
+    add_seg(layers[i], 0, 1, 2, (uint32_t)i, 1);
+    const DTree& t = trees[i];
+    for (size_t l = 0; l < n_siblings(t); l++) add_seg(t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(i + 1 + l), 1);
+  }
+  const size_t qbytes = out_off;
+  std::vector<uint64_t> indices(prm.num_queries);
+  for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
   tr.mark("final_poly+grind");
-  std::vector<uint8_t> g(out_off);
-  gather_rows(ctx, reqs, g.data(), out_off);
+  std::vector<uint8_t> g(qbytes * indices.size());
+  gather_queries(ctx, segs, indices, qbytes, g.data());
   tr.mark("query_gather");
 
   // ---- FriProof bytes

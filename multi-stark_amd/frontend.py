@@ -584,6 +584,27 @@ def u32_add_bench_witness(num_adds, a0=0xDEADBEEF, b0=0xCAFEBABE):
     return _u32_add_traces(xs, ys, h)
 
 
+def multi_u32_add_system_inputs(k):
+    """[ByteTable, U32Add x k]: SURVEY §8d config 3 as ONE system (all AIRs in one proof)."""
+    base = u32_add_system_inputs()
+    return [base[0]] + [u32_add_system_inputs()[1] for _ in range(k)]
+
+
+def multi_u32_add_witness(k, num_adds):
+    """Per-AIR xorshift seeds a0 ^ (i * 0x9e3779b9), b0 ^ (i * 0x85ebca6b); byte multiplicities summed; all claims."""
+    byte = np.zeros((256, 1), dtype=np.uint64)
+    traces, claims = [None], []
+    for i in range(k):
+        a0 = 0xDEADBEEF ^ ((i * 0x9E3779B9) & 0xFFFFFFFF)
+        b0 = 0xCAFEBABE ^ ((i * 0x85EBCA6B) & 0xFFFFFFFF)
+        (bt, add), cl = u32_add_bench_witness(num_adds, a0, b0)
+        byte += bt
+        traces.append(add)
+        claims.append(cl)
+    traces[0] = byte
+    return traces, np.concatenate(claims, axis=0)
+
+
 def pythagorean_inputs():
     """examples/simple_proof.rs:21-44."""
 

@@ -28,7 +28,7 @@ def test_field_ops(ctx, oracle):
     assert np.all(prod[:, 0] == 1) and np.all(prod[:, 1] == 0)
 
 
-@pytest.mark.parametrize("log_h", [0, 1, 2, 5, 8, 11, 12, 13, 16, 20])
+@pytest.mark.parametrize("log_h", [0, 1, 2, 5, 8, 11, 12, 13, 16, 20, 21, 22])
 @pytest.mark.parametrize("w", [1, 3])
 def test_dft_batch(ctx, oracle, log_h, w):
     rng = np.random.default_rng(100 + log_h)

@@ -68,6 +68,25 @@ def test_bench_workload(pkg, ctx, oracle, fe, log_adds):
     _prove_both(pkg, ctx, oracle, fe, fe.u32_add_system_inputs(), fe.bench_params(), traces, claims)
 
 
+# SURVEY §8d config 3 as one system on one GPU: [ByteTable, U32Add x k] — several equal-height matrices share
+# every Merkle leaf and every reduced opening
+@pytest.mark.parametrize("k,log_adds", [(2, 5), (8, 7)])
+def test_multi_air_system(pkg, ctx, oracle, fe, k, log_adds):
+    traces, claims = fe.multi_u32_add_witness(k, 1 << log_adds)
+    _prove_both(pkg, ctx, oracle, fe, fe.multi_u32_add_system_inputs(k), fe.bench_params(), traces, claims)
+
+
+# transforms above 2^20 take the multi-pass strided path (8-bit register pass + generic remainder)
+def test_large_trace_verifies(pkg, ctx, oracle, fe):
+    traces, claims = fe.u32_add_bench_witness(1 << 22)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    o = oracle.System(g.blob)
+    packed = fe.pack_claims(claims)
+    w = g.witness(traces, packed)
+    proof = g.prove_multiple_claims(w).to_bytes()
+    assert o.verify(packed, proof) == 0
+
+
 def test_cap_height_and_final_poly(pkg, ctx, oracle, fe):
     params = fe.Params(log_blowup=2, cap_height=2, log_final_poly_len=2, num_queries=20, commit_proof_of_work_bits=3,
                        query_proof_of_work_bits=5)
