@@ -185,7 +185,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(dominant),
                 "avg_launch_ms": avg_ms,
                 "alg_bytes_per_launch": bytes_per_launch,
                 "launches": dom["launches"],
@@ -198,6 +198,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+    separately on this same command, corrected as MI355X_MICROARCH.md prescribes; tools/traffic_from_pmc.py)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(fe, blob, log_adds):
