@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--cpu-log-adds", type=int, default=16, help="bounded sample for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path with several ranks sharing one GPU)")
     return ap.parse_args()
 
 
@@ -66,8 +68,14 @@ def main():
         import torch.distributed as _dist
 
         dist = _dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(ndev, 1)  # rehearsal: ranks may share a device
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=args.backend)
 
     pkg = load_package()
     fe = pkg.frontend
@@ -102,7 +110,8 @@ def main():
     def step():
         proof = system.prove_multiple_claims(witness)
         if dist is not None:
-            allc = mgpu.gather_commitments(mgpu.commitments_of(proof.to_bytes(), 2), torch.device("cuda", local_rank))
+            allc = mgpu.gather_commitments(mgpu.commitments_of(proof.to_bytes(), 2),
+                                           torch.device("cuda", local_rank) if args.backend == "nccl" else None)
             if rank == 0:
                 mgpu.joint_digest(allc)
         return proof
@@ -141,7 +150,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     dom = ctx.kernel_stats()[dominant]
