@@ -77,12 +77,28 @@ Ctx::Ctx(int dev) : device(dev) {
       y = gl_mul(y, wi);
     }
   }
+  std::vector<u64> c3f(2048, 0), c3i(2048, 0);
+  for (unsigned r = 2; r <= 12; r++) {
+    u64 w = gl_two_adic_generator(r), wi = gl_inv(w);
+    u64 w3 = gl_mul(w, gl_mul(w, w)), wi3 = gl_mul(wi, gl_mul(wi, wi)), x = 1, y = 1;
+    size_t off = (size_t(1) << (r - 2)) - 1;
+    for (size_t i = 0; i < (size_t(1) << (r - 2)); i++) {
+      c3f[off + i] = x;
+      c3i[off + i] = y;
+      x = gl_mul(x, w3);
+      y = gl_mul(y, wi3);
+    }
+  }
   u64* tc = nullptr;
-  HIP_CHECK(hipMalloc(&tc, 2 * 4096 * sizeof(u64)));
+  HIP_CHECK(hipMalloc(&tc, (2 * 4096 + 2 * 2048) * sizeof(u64)));
   HIP_CHECK(hipMemcpy(tc, cf.data(), 4096 * sizeof(u64), hipMemcpyHostToDevice));
   HIP_CHECK(hipMemcpy(tc + 4096, ci.data(), 4096 * sizeof(u64), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(tc + 8192, c3f.data(), 2048 * sizeof(u64), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(tc + 8192 + 2048, c3i.data(), 2048 * sizeof(u64), hipMemcpyHostToDevice));
   twc = tc;
   twci = tc + 4096;
+  twc3 = tc + 8192;
+  twc3i = tc + 8192 + 2048;
 }
 
 Ctx::~Ctx() {

@@ -25,15 +25,53 @@ static constexpr u64 GL_GEN = 7;                          // multiplicative gene
 static constexpr u64 GL_W32 = 1753635133440165772ULL;     // generator of the order-2^32 subgroup = 7^((p-1)/2^32)
 static constexpr u64 GL_EXT_W = 7;                        // X^2 = 7
 
-GL_HD u64 gl_add(u64 a, u64 b) {
-  u64 s = a + b;
-  if (s < a || s >= GL_P) s -= GL_P;
-  return s;
-}
+// On the device the modular add/sub/reduce are written as VCC carry chains in inline assembly: the compiler's own
+// lowering of the same C (64-bit compares into SGPR pairs + v_cndmask, register-pair shuffles for v_lshl_add_u64 and
+// the hazard s_nops between them) costs about twice the instructions. All sequences are pure VALU, keep every
+// intermediate in VGPRs and only clobber VCC; VALU->VALU carry-in needs no wait states on gfx950.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u64 gl_pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+#endif
+
 GL_HD u64 gl_sub(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // d = a - b; on borrow add p, i.e. subtract 2^32 - 1 (mod 2^64)
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32), d0, d1, m;
+  asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(d0), "=&v"(d1), "=&v"(m)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "vcc");
+  return gl_pack(d0, d1);
+#else
   u64 d = a - b;
   if (a < b) d += GL_P;
   return d;
+#endif
+}
+GL_HD u64 gl_add(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // a + b = a - (p - b); p - b = (1 - b0, 0xFFFFFFFF - b1 - borrow) needs no reduction (b = 0 gives p, still correct)
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32), d0, d1, m;
+  asm("v_sub_co_u32 %0, vcc, 1, %5\n\t"
+      "v_subb_co_u32 %1, vcc, -1, %6, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %3, %0\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %1, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(d0), "=&v"(d1), "=&v"(m)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "vcc");
+  return gl_pack(d0, d1);
+#else
+  u64 s = a + b;
+  if (s < a || s >= GL_P) s -= GL_P;
+  return s;
+#endif
 }
 GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 
@@ -48,29 +86,70 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   return r;
 }
 
-// x = (h1:h0) * 2^64 + lo  ->  canonical x mod p. Limb-wise: lo - h1 + (h0 << 32) - h0, each 64-bit add/sub folds
-// its carry/borrow back as -/+ (2^32 - 1). Written so that the compiler does not turn (h0 << 32) - h0 into a multiply.
+// x = (h1:h0) * 2^64 + lo  ->  canonical x mod p: lo - h1 + (h0 << 32) - h0, each step a 64-bit add/sub whose
+// carry/borrow is folded back as -/+ (2^32 - 1); then one conditional subtraction of p.
 GL_HD u64 gl_reduce_limbs(u64 lo, u32 h0, u32 h1) {
-  u64 A = lo - h1;
-  A -= (u64)(0u - (u32)(lo < (u64)h1));
-  u64 B = A + ((u64)h0 << 32);
-  B += (u64)(0u - (u32)(B < A));
-  u64 C = B - h0;
-  C -= (u64)(0u - (u32)(B < (u64)h0));
-  u64 s = C + GL_EPS;  // C >= p  <=>  C + (2^32 - 1) overflows
-  return s < C ? s : C;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, m, t0, t1;
+  asm("v_sub_co_u32 %0, vcc, %5, %8\n\t"           // A = lo - h1
+      "v_subbrev_co_u32 %1, vcc, 0, %6, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_add_co_u32 %1, vcc, %1, %7\n\t"            // B = A + (h0 << 32)
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %7\n\t"            // C = B - h0
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_add_co_u32 %3, vcc, -1, %0\n\t"            // C >= p  <=>  C + (2^32 - 1) carries out
+      "v_addc_co_u32 %4, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %3, %0, %3, vcc\n\t"
+      "v_cndmask_b32 %4, %1, %4, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(m), "=&v"(t0), "=&v"(t1)
+      : "v"(l0), "v"(l1), "v"(h0), "v"(h1)
+      : "vcc");
+  return gl_pack(t0, t1);
+#else
+  return gl_reduce128(lo, ((u64)h1 << 32) | h0);
+#endif
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// 64 x 64 -> 128: four v_mad_u64_u32 partial products, summed limb-wise with one carry chain
+__device__ __forceinline__ void gl_mul_wide(u64 a, u64 b, u32& l0, u32& l1, u32& h0, u32& h1) {
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p00, p01, p10, p11;
+  asm("v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+      "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+      "v_mad_u64_u32 %2, vcc, %5, %6, 0\n\t"
+      "v_mad_u64_u32 %3, vcc, %5, %7, 0"
+      : "=&v"(p00), "=&v"(p01), "=&v"(p10), "=&v"(p11)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "vcc");
+  u32 p00l = (u32)p00, p00h = (u32)(p00 >> 32), p01l = (u32)p01, p01h = (u32)(p01 >> 32);
+  u32 p10l = (u32)p10, p10h = (u32)(p10 >> 32), p11l = (u32)p11, p11h = (u32)(p11 >> 32);
+  asm("v_add_co_u32 %0, vcc, %3, %4\n\t"        // l1 = p00h + p01l
+      "v_addc_co_u32 %1, vcc, %5, %7, vcc\n\t"  // h0 = p01h + p10h + c
+      "v_addc_co_u32 %2, vcc, 0, %9, vcc\n\t"   // h1 = p11h + c
+      "v_add_co_u32 %0, vcc, %0, %6\n\t"        // l1 += p10l
+      "v_addc_co_u32 %1, vcc, %1, %8, vcc\n\t"  // h0 += p11l + c
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc"        // h1 += c
+      : "=&v"(l1), "=&v"(h0), "=&v"(h1)
+      : "v"(p00h), "v"(p01l), "v"(p01h), "v"(p10l), "v"(p10h), "v"(p11l), "v"(p11h)
+      : "vcc");
+  l0 = p00l;
+}
+#endif
 
 GL_HD u64 gl_mul(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  // 64x64 -> 128 as four 32x32+64 multiply-adds (v_mad_u64_u32)
-  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  u64 p00 = (u64)a0 * b0;
-  u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-  u64 p10 = (u64)a1 * b0 + (u32)p01;
-  u64 hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-  u64 lo = (p10 << 32) | (u32)p00;
-  return gl_reduce_limbs(lo, (u32)hi, (u32)(hi >> 32));
+  u32 l0, l1, h0, h1;
+  gl_mul_wide(a, b, l0, l1, h0, h1);
+  return gl_reduce_limbs(gl_pack(l0, l1), h0, h1);
 #else
   unsigned __int128 x = (unsigned __int128)a * b;
   return gl_reduce128((u64)x, (u64)(x >> 64));
@@ -110,16 +189,23 @@ GL_HD void acc_init(GlAcc& a) {
 }
 GL_HD void acc_mad(GlAcc& a, u64 x, u64 y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
-  u64 p00 = (u64)x0 * y0;
-  u64 p01 = (u64)x0 * y1 + (p00 >> 32);
-  u64 p10 = (u64)x1 * y0 + (u32)p01;
-  u64 phi = (u64)x1 * y1 + (p01 >> 32) + (p10 >> 32);
-  u64 plo = (p10 << 32) | (u32)p00;
+  u32 l0, l1, h0, h1;
+  gl_mul_wide(x, y, l0, l1, h0, h1);
+  u32 a0 = (u32)a.lo, a1 = (u32)(a.lo >> 32), a2 = (u32)a.hi, a3 = (u32)(a.hi >> 32), c = a.c;
+  asm("v_add_co_u32 %0, vcc, %0, %5\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %6, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %7, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, 0, %4, vcc"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c)
+      : "v"(l0), "v"(l1), "v"(h0), "v"(h1)
+      : "vcc");
+  a.lo = gl_pack(a0, a1);
+  a.hi = gl_pack(a2, a3);
+  a.c = c;
 #else
   unsigned __int128 pr = (unsigned __int128)x * y;
   u64 plo = (u64)pr, phi = (u64)(pr >> 64);
-#endif
   u64 lo = a.lo + plo;
   u64 c1 = lo < plo ? 1u : 0u;
   u64 hi = a.hi + phi;
@@ -129,6 +215,7 @@ GL_HD void acc_mad(GlAcc& a, u64 x, u64 y) {
   a.lo = lo;
   a.hi = hi2;
   a.c += c2;
+#endif
 }
 // value = c * 2^128 + hi * 2^64 + lo, with 2^128 = -2^32 (mod p); c stays far below 2^31 for any realistic sum
 GL_HD u64 acc_reduce(const GlAcc& a) {

@@ -63,6 +63,8 @@ struct Ctx {
   u64 *tw0 = nullptr, *tw1 = nullptr, *tw0i = nullptr, *tw1i = nullptr;
   // compact per-order tables: table r (root of order 2^r, r = 1..12) holds w^i for i < 2^(r-1) at offset 2^(r-1) - 1
   u64 *twc = nullptr, *twci = nullptr;
+  // cubes for the radix-4 butterflies: table r (r = 2..12) holds w^(3i) for i < 2^(r-2) at offset 2^(r-2) - 1
+  u64 *twc3 = nullptr, *twc3i = nullptr;
   // pooled device memory: exact-size buckets, reused across proofs
   std::multimap<size_t, void*> pool_free;
   std::map<void*, size_t> pool_live;

@@ -195,6 +195,49 @@ __device__ __forceinline__ void reg_stages16_uniform(u64 (&x)[16]) {
   }
 }
 
+// Same 4 stages as reg_stages16, as two radix-4 layers: a radix-4 butterfly needs three general multiplications
+// (by w, w^2, w^3) and one multiplication by w_4 = 2^48 (a shift) where two radix-2 stages need four.
+// tw1 = compact tables (w^i), tw3 = cube tables (w^(3i)); w_4^-1 = -2^48 for the inverse transform.
+template <bool DIT, bool INV>
+__device__ __forceinline__ void reg_stages16_r4(u64 (&x)[16], u32 lo, unsigned shift, const u64* __restrict__ tw1,
+                                                const u64* __restrict__ tw3) {
+  // multiply by the 4th root used by this direction: forward i = 2^48, inverse i^-1 = -2^48
+  auto mul_i = [](u64 pos, u64 neg) -> u64 { return INV ? gl_mul_2exp(gl_sub(neg, pos), 48) : gl_mul_2exp(gl_sub(pos, neg), 48); };
+#pragma unroll
+  for (int layer = 0; layer < 2; layer++) {
+    const int q = DIT ? (layer == 0 ? 1 : 4) : (layer == 0 ? 4 : 1);  // quarter size in j units
+    const unsigned r = (q == 4 ? 4u : 2u) + shift;                     // butterfly root order 2^r = 4 q << shift
+    const u64* t1 = tw1 + ((1u << (r - 1)) - 1) + lo;                  // w   = w_{2^r}^e,      e = (jl << shift) + lo
+    const u64* t2 = tw1 + ((1u << (r - 2)) - 1) + lo;                  // w^2 = w_{2^(r-1)}^e
+    const u64* t3 = tw3 + ((1u << (r - 2)) - 1) + lo;                  // w^3
+#pragma unroll
+    for (int jl = 0; jl < q; jl++) {
+      const u64 w1 = t1[jl << shift], w2 = t2[jl << shift], w3 = t3[jl << shift];
+#pragma unroll
+      for (int g = 0; g < 4 / q; g++) {
+        const int j0 = g * 4 * q + jl;
+        u64 x0 = x[j0], x1 = x[j0 + q], x2 = x[j0 + 2 * q], x3 = x[j0 + 3 * q];
+        if (!DIT) {
+          u64 s02 = gl_add(x0, x2), s13 = gl_add(x1, x3), d02 = gl_sub(x0, x2);
+          u64 id13 = mul_i(x1, x3);  // i (x1 - x3)
+          x[j0] = gl_add(s02, s13);
+          x[j0 + q] = gl_mul(gl_sub(s02, s13), w2);
+          x[j0 + 2 * q] = gl_mul(gl_add(d02, id13), w1);
+          x[j0 + 3 * q] = gl_mul(gl_sub(d02, id13), w3);
+        } else {
+          u64 t1v = gl_mul(w2, x1), t2v = gl_mul(w1, x2), t3v = gl_mul(w3, x3);
+          u64 a = gl_add(x0, t1v), b = gl_sub(x0, t1v), c = gl_add(t2v, t3v);
+          u64 id = mul_i(t2v, t3v);  // i (t2 - t3)
+          x[j0] = gl_add(a, c);
+          x[j0 + 2 * q] = gl_sub(a, c);
+          x[j0 + q] = gl_add(b, id);
+          x[j0 + 3 * q] = gl_sub(b, id);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ u32 pad_hi(u32 e) { return e + ((e >> 8) << 4); }  // 16 spare slots per 256
 __device__ __forceinline__ u32 pad_lo(u32 e) { return e + (e >> 4); }         // 1 spare slot per 16
 constexpr int NTT12_LDS = 4096 + 256 + 16;
@@ -202,8 +245,8 @@ constexpr int NTT12_LDS = 4096 + 256 + 16;
 // 12-bit contiguous pass over one 4096-element tile (bits 11..0 of the position inside the tile).
 template <bool DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logn,
-                                               const u64* __restrict__ twc, unsigned src_div, const u64* __restrict__ scale,
-                                               u64 out_mul) {
+                                               const u64* __restrict__ twc, const u64* __restrict__ twc3, unsigned src_div,
+                                               const u64* __restrict__ scale, u64 out_mul) {
   __shared__ u64 sm[NTT12_LDS];
   const size_t n = size_t(1) << logn;
   const size_t col = blockIdx.y, off = size_t(blockIdx.x) << 12;
@@ -219,13 +262,13 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
     x[j] = v;
   }
   if (!DIT) {
-    reg_stages16<false>(x, t, 8, twc);  // bits 11..8
+    reg_stages16_r4<false, INV>(x, t, 8, twc, twc3);  // bits 11..8
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi(t + 256 * j)] = x[j];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi(a * 256 + 16 * j + b)];
-    reg_stages16<false>(x, b, 4, twc);  // bits 7..4
+    reg_stages16_r4<false, INV>(x, b, 4, twc, twc3);  // bits 7..4
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_lo(a * 256 + 16 * j + b)] = x[j];
@@ -252,14 +295,14 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(a * 256 + 16 * j + b)];
-    reg_stages16<true>(x, b, 4, twc);  // bits 4..7
+    reg_stages16_r4<true, INV>(x, b, 4, twc, twc3);  // bits 4..7
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi(a * 256 + 16 * j + b)] = x[j];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi(t + 256 * j)];
-    reg_stages16<true>(x, t, 8, twc);  // bits 8..11
+    reg_stages16_r4<true, INV>(x, t, 8, twc, twc3);  // bits 8..11
   }
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -273,9 +316,10 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
 // 256 (h) x 16 (l) with l contiguous in memory. Includes the four-step inter-pass twiddle w_B^{l * bitrev8(h)}.
 template <bool DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
-                                               const u64* __restrict__ twc, const u64* __restrict__ t0,
-                                               const u64* __restrict__ t1, const u64* __restrict__ ttab, unsigned src_div,
-                                               const u64* __restrict__ scale, u64 out_mul) {
+                                               const u64* __restrict__ twc, const u64* __restrict__ twc3,
+                                               const u64* __restrict__ t0, const u64* __restrict__ t1,
+                                               const u64* __restrict__ ttab, unsigned src_div, const u64* __restrict__ scale,
+                                               u64 out_mul) {
   __shared__ u64 sm[NTT12_LDS];
   const size_t n = size_t(1) << logn;
   const unsigned logB = 8 + logS;
@@ -301,7 +345,7 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
       if (sc) v = gl_mul(v, sc[pos]);
       x[j] = v;
     }
-    reg_stages16<false>(x, hq, 4, twc);  // h bits 7..4
+    reg_stages16_r4<false, INV>(x, hq, 4, twc, twc3);  // h bits 7..4
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi((hq + 16 * j) * 16 + l)] = x[j];
     __syncthreads();
@@ -330,7 +374,7 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq + 16 * j) * 16 + l)];
-    reg_stages16<true>(x, hq, 4, twc);  // h bits 4..7
+    reg_stages16_r4<true, INV>(x, hq, 4, twc, twc3);  // h bits 4..7
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       u64 v = x[j];
@@ -396,10 +440,10 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
     const u64* ttab = ntt8s_table(ctx, logB, inverse);
     if (inverse)
       hipLaunchKernelGGL((ntt8s_k<(DIT != 0), true>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twci, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul);
+                         logn, ctx.twci, ctx.twc3i, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul);
     else
       hipLaunchKernelGGL((ntt8s_k<(DIT != 0), false>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twc, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul);
+                         logn, ctx.twc, ctx.twc3, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul);
     ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
@@ -422,9 +466,9 @@ void launch_contig(Ctx& ctx, const u64* src, u64* dst, unsigned K, unsigned logn
     const int id = DIT ? K_NTT12_DIT : K_NTT12_DIF;
     hipEvent_t ev12 = ctx.prof_begin(id);
     if (inverse)
-      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, ctx.twc3i, src_div, scale, out_mul);
     else
-      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, ctx.twc3, src_div, scale, out_mul);
     ctx.prof_end(id, ev12, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
