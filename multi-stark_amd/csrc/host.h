@@ -59,7 +59,10 @@ struct HCircuit {
   size_t main_width = 0, pre_width = 0, pre_height = 0, num_lookups = 0, stage2_width = 0, constraint_count = 0,
          max_constraint_degree = 0, args_width = 0, lookup_prefix_len = 0;
   std::vector<u64> preprocessed;  // row-major
+  DBuf<u64> d_preprocessed;       // same, on the device (witness preparation)
   DProgram prog;
+  DProgram prefix_prog;           // lookup-expression prefix only (SystemWitness::from_stage_1)
+  bool prefix_on_device = false;
   size_t quotient_degree() const {
     size_t d = (max_constraint_degree > 2 ? max_constraint_degree : 2) - 1, q = 1;
     while (q < d) q <<= 1;

@@ -255,6 +255,17 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
     if (c.quotient_degree() > (size_t(1) << p.log_blowup))  // src/system.rs:171-178
       throw std::runtime_error("circuit " + std::to_string(ci) + ": constraint degree needs a quotient degree beyond the blowup");
     build_program(ctx, c.nodes, c.zeros, c.lookups, c.prog);
+    {
+      // the lookup prefix may only read trace columns and row selectors (src/graph.rs: Stage2InBaseContext; publics
+      // do not exist at witness time); anything else keeps the host sweep, which reports the error
+      bool ok = !c.lookups.empty();
+      for (size_t i = 0; i < c.lookup_prefix_len && ok; i++)
+        ok = !(c.nodes[i].kind == OP_PUBLIC || (c.nodes[i].kind == OP_VAR && c.nodes[i].source == 2));
+      if (ok) {
+        build_program(ctx, c.nodes, std::vector<uint32_t>(), c.lookups, c.prefix_prog);
+        c.prefix_on_device = true;
+      }
+    }
     c.prog.constraint_count = c.constraint_count;
     c.prog.main_w = c.main_width;
     c.prog.pre_w = c.pre_width;
@@ -268,10 +279,10 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
         x = rd.word();
         if (x >= GL_P) throw std::runtime_error("non-canonical preprocessed value");
       }
-      DBuf<u64> up(ctx, cnt);
-      ctx.h2d(up.p, c.preprocessed.data(), cnt * 8);
+      c.d_preprocessed = DBuf<u64>(ctx, cnt);
+      ctx.h2d(c.d_preprocessed.p, c.preprocessed.data(), cnt * 8);
       sys->pre_indices.push_back((int)pre_ldes.size());
-      pre_ldes.push_back(lde_of_host_matrix(ctx, up.p, c.pre_height, c.pre_width, (unsigned)p.log_blowup));
+      pre_ldes.push_back(lde_of_host_matrix(ctx, c.d_preprocessed.p, c.pre_height, c.pre_width, (unsigned)p.log_blowup));
       ctx.sync();
     } else {
       c.pre_height = 0;
@@ -359,8 +370,12 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
       ctx.h2d(lk.mult.p, mult[ci], h * c.num_lookups * 8);
       if (c.args_width) ctx.h2d(lk.args.p, args[ci], h * c.args_width * 8);
       ctx.sync();
+    } else if (c.prefix_on_device && !getenv("MSAMD_HOST_LOOKUP_VALUES") &&
+               lookup_values_device(ctx, c.prefix_prog, w->traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h, c.main_width,
+                                    c.pre_width, c.args_width, lk.mult.p, lk.args.p)) {
+      ctx.sync();  // SystemWitness::from_stage_1 ran as one kernel
     } else {
-      // SystemWitness::from_stage_1, src/system.rs:275-328
+      // SystemWitness::from_stage_1, src/system.rs:275-328 (host sweep: huge prefixes or malformed programs)
       std::vector<u64> hm(h * c.num_lookups), ha(h * c.args_width), buf;
       const u64* tr = traces[ci];
       for (size_t r = 0; r < h; r++) {

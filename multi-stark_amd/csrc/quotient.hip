@@ -172,6 +172,63 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
   p.out[nq + t] = gl_mul(acc_reduce(fa1), iv);
 }
 
+
+// ---- SystemWitness::from_stage_1 on the device (src/system.rs:275-328): the lookup prefix of the node program is
+// swept over every trace row (with wrap-around for the next-row window) and the multiplicity / argument values are
+// written into the flat LookupValues storage (src/lookup.rs:392-405). Traces are row-major here, as uploaded.
+struct LvParams {
+  const u64* trace;   // h x main_w row-major
+  const u64* pre;     // h x pre_w row-major (or null)
+  size_t h;
+  uint32_t main_w, pre_w;
+  const uint32_t* code;
+  const u64* consts;
+  const uint32_t* lookup_slots;
+  uint32_t n_instr, n_lookups, n_slots, args_w;
+  u64* mult;          // h x L
+  u64* args;          // h x args_w
+};
+__global__ __launch_bounds__(256) void lookup_values_k(LvParams p) {
+  extern __shared__ u64 sm[];
+  const size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (r >= p.h) return;
+  const size_t rn = r + 1 == p.h ? 0 : r + 1;
+  u64* slots = sm + threadIdx.x;
+  const size_t stride = blockDim.x;
+  const u64 is_first = r == 0, is_last = r + 1 == p.h, is_trans = r + 1 != p.h;
+  for (u32 pc = 0; pc < p.n_instr; pc++) {
+    const uint4 ins = reinterpret_cast<const uint4*>(p.code)[pc];
+    u64 v;
+    switch (ins.x) {
+      case OP_CONST: v = p.consts[ins.z]; break;
+      case OP_VAR: {
+        u32 src = ins.z & 0xff, off = ins.z >> 8;
+        size_t row = off ? rn : r;
+        v = src == 1 ? p.trace[row * p.main_w + ins.w] : p.pre[row * p.pre_w + ins.w];
+        break;
+      }
+      case OP_IS_FIRST: v = is_first; break;
+      case OP_IS_LAST: v = is_last; break;
+      case OP_IS_TRANS: v = is_trans; break;
+      case OP_ADD: v = gl_add(slots[ins.z * stride], slots[ins.w * stride]); break;
+      case OP_SUB: v = gl_sub(slots[ins.z * stride], slots[ins.w * stride]); break;
+      case OP_MUL: v = gl_mul(slots[ins.z * stride], slots[ins.w * stride]); break;
+      case OP_NEG: v = gl_neg(slots[ins.z * stride]); break;
+      default: v = 0; break;  // publics / stage-2 columns cannot occur in lookup expressions (checked on the host)
+    }
+    slots[ins.y * stride] = v;
+  }
+  const uint32_t* ls = p.lookup_slots;
+  u64* arow = p.args + r * p.args_w;
+  for (u32 j = 0; j < p.n_lookups; j++) {
+    const u32 mslot = ls[0], na = ls[1];
+    p.mult[r * p.n_lookups + j] = slots[mslot * stride];
+    for (u32 k = 0; k < na; k++) arow[k] = slots[ls[2 + k] * stride];
+    arow += na;
+    ls += 2 + na;
+  }
+}
+
 }  // namespace
 
 // ---- host: lower the compiled node vector to a slot-allocated program
@@ -283,6 +340,33 @@ void build_program(Ctx& ctx, const std::vector<PNode>& nodes, const std::vector<
   if (!zslots.empty()) ctx.h2d(out.zero_slots.p, zslots.data(), zslots.size() * 4);
   if (!lslots.empty()) ctx.h2d(out.lookup_slots.p, lslots.data(), lslots.size() * 4);
   ctx.sync();
+}
+
+
+bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, const u64* d_pre, size_t h, size_t main_w,
+                          size_t pre_w, size_t args_w, u64* d_mult, u64* d_args) {
+  unsigned threads = 256;
+  while (threads > 64 && prefix.n_slots * threads * 8 > 64 * 1024) threads >>= 1;
+  if (prefix.n_slots * threads * 8 > 64 * 1024) return false;  // very large prefix: the caller sweeps on the host
+  LvParams p;
+  p.trace = d_trace;
+  p.pre = d_pre;
+  p.h = h;
+  p.main_w = (uint32_t)main_w;
+  p.pre_w = (uint32_t)pre_w;
+  p.code = prefix.code.p;
+  p.consts = prefix.consts.p;
+  p.lookup_slots = prefix.lookup_slots.p;
+  p.n_instr = (uint32_t)prefix.n_instr;
+  p.n_lookups = (uint32_t)prefix.n_lookups;
+  p.n_slots = (uint32_t)prefix.n_slots;
+  p.args_w = (uint32_t)args_w;
+  p.mult = d_mult;
+  p.args = d_args;
+  hipLaunchKernelGGL(lookup_values_k, dim3((unsigned)((h + threads - 1) / threads)), dim3(threads), prefix.n_slots * threads * 8,
+                     ctx.stream, p);
+  HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* out) {
