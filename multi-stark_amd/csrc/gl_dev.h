@@ -86,21 +86,21 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
   return r;
 }
 
-// x = (h1:h0) * 2^64 + lo  ->  canonical x mod p: lo - h1 + (h0 << 32) - h0, each step a 64-bit add/sub whose
-// carry/borrow is folded back as -/+ (2^32 - 1); then one conditional subtraction of p.
+// x = (h1:h0) * 2^64 + lo  ->  canonical x mod p = lo + ((h0 << 32) - h0) - h1: u = (h0 << 32) - h0 is formed exactly
+// in two instructions, then one 64-bit add and one 64-bit sub whose carry / borrow is folded back as +/- (2^32 - 1)
+// (neither fold can wrap again: lo + u - 2^64 <= 2^64 - 2^33, and a borrowed difference is >= p), then one
+// conditional subtraction of p.
 GL_HD u64 gl_reduce_limbs(u64 lo, u32 h0, u32 h1) {
 #if defined(__HIP_DEVICE_COMPILE__)
   u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, m, t0, t1;
-  asm("v_sub_co_u32 %0, vcc, %5, %8\n\t"           // A = lo - h1
-      "v_subbrev_co_u32 %1, vcc, 0, %6, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_add_co_u32 %1, vcc, %1, %7\n\t"            // B = A + (h0 << 32)
+  asm("v_sub_co_u32 %0, vcc, 0, %7\n\t"            // u = (h0 << 32) - h0
+      "v_subbrev_co_u32 %1, vcc, 0, %7, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %5, %0\n\t"            // A = lo + u
+      "v_addc_co_u32 %1, vcc, %6, %1, vcc\n\t"
       "v_cndmask_b32 %2, 0, -1, vcc\n\t"
       "v_add_co_u32 %0, vcc, %0, %2\n\t"
       "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %7\n\t"            // C = B - h0
+      "v_sub_co_u32 %0, vcc, %0, %8\n\t"            // C = A - h1
       "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
       "v_cndmask_b32 %2, 0, -1, vcc\n\t"
       "v_sub_co_u32 %0, vcc, %0, %2\n\t"
@@ -115,6 +115,29 @@ GL_HD u64 gl_reduce_limbs(u64 lo, u32 h0, u32 h1) {
   return gl_pack(t0, t1);
 #else
   return gl_reduce128(lo, ((u64)h1 << 32) | h0);
+#endif
+}
+// the same with h1 = 0 (a 96-bit value), as produced by shifts of less than 32 bits
+GL_HD u64 gl_reduce_limbs96(u64 lo, u32 h0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, m, t0, t1;
+  asm("v_sub_co_u32 %0, vcc, 0, %7\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %7, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %5, %0\n\t"
+      "v_addc_co_u32 %1, vcc, %6, %1, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_add_co_u32 %3, vcc, -1, %0\n\t"
+      "v_addc_co_u32 %4, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %3, %0, %3, vcc\n\t"
+      "v_cndmask_b32 %4, %1, %4, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(m), "=&v"(t0), "=&v"(t1)
+      : "v"(l0), "v"(l1), "v"(h0)
+      : "vcc");
+  return gl_pack(t0, t1);
+#else
+  return gl_reduce128(lo, (u64)h0);
 #endif
 }
 
@@ -160,6 +183,10 @@ GL_HD u64 gl_mul(u64 a, u64 b) {
 // signed power of two, so the innermost NTT stages need no multiplier). Meant for k known at compile time.
 GL_HD u64 gl_mul_2exp(u64 x, unsigned k) {
   if (k == 0) return x;
+  if (k <= 32) {
+    u64 lo = x << k, hi = x >> (64 - k);
+    return gl_reduce_limbs96(lo, (u32)hi);
+  }
   if (k < 64) {
     u64 lo = x << k, hi = x >> (64 - k);
     return gl_reduce_limbs(lo, (u32)hi, (u32)(hi >> 32));

@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "b3_dev.h"
+#include "challenge_dev.h"
 #include "msamd.h"
 
 namespace msamd {
@@ -285,6 +286,47 @@ __global__ __launch_bounds__(256) void tree_tail_k(Digest* __restrict__ layer, u
   }
 }
 
+// tree_tail_k for an FRI commit-phase tree, followed in the same launch by that round's challenger step: the root is
+// observed, the proof-of-work witness searched and beta sampled without the commitment leaving the device
+__global__ __launch_bounds__(1024) void tree_tail_challenge_k(Digest* __restrict__ layer, u32 len, FriChallenge fc) {
+  __shared__ __attribute__((aligned(16))) u32 sh[1024 * 8];
+  __shared__ ChallengeShared cs;
+  const u32 t = threadIdx.x;
+  if (t < len) {
+    u32 d[8];
+    load_digest(layer + t, d);
+    lds_store_digest(sh, t, d);
+  }
+  if (t < 8) cs.st[t] = fc.state[t];
+  __syncthreads();
+  Digest* out = layer + len;
+  for (u32 n = len >> 1; n >= 1; n >>= 1) {
+    u32 d[8];
+    if (t < n) {
+      u32 l[8], r[8];
+      lds_load_digest(sh, 2 * t, l);
+      lds_load_digest(sh, 2 * t + 1, r);
+      b3_compress_pair_root(l, r, d);
+    }
+    __syncthreads();
+    if (t < n) {
+      lds_store_digest(sh, t, d);
+      store_digest(out + t, d);
+    }
+    __syncthreads();
+    out += n;
+  }
+  challenger_round<1024>(cs, sh, fc.pow_bits);
+  if (t < 8) {
+    fc.state[t] = cs.st[t];
+    fc.rec->root[t] = sh[t];
+  }
+  if (t == 0) {
+    fc.rec->witness = cs.wit;
+    fc.rec->beta = cs.beta;
+  }
+}
+
 // ---- whole-stream BLAKE3. The stream is `prefix` (prefix_len bytes, any alignment) followed by `nwords`
 // little-endian u64 words (8-byte aligned), which is how the transcript up to the claims is shaped: a short
 // host-built prefix, then the length-prefixed claims as field elements.
@@ -384,7 +426,7 @@ struct InjectAt {
   u32 total_w = 0;
   size_t count = 0;
 };
-static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, const MatRef* drefs) {
+static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, const MatRef* drefs, const FriChallenge* fc = nullptr) {
   const size_t L = t.layer_len.size();
   size_t last_inject = 0;
   for (size_t li = 1; li < L; li++)
@@ -394,9 +436,14 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
     const size_t child_len = t.layer_len[li - 1];
     Digest* child = t.base() + t.layer_off[li - 1];
     if (child_len <= 1024 && li > last_inject) {
-      hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
-      hipLaunchKernelGGL(tree_tail_k, dim3(1), dim3(256), 0, ctx.stream, child, (u32)child_len);
-      ctx.prof_end(K_COMPRESS, ev, 96.0 * double(child_len));
+      const KernelId kid = fc ? K_OTHER : K_COMPRESS;  // the challenger step's grinding is not tree work
+      hipEvent_t ev = ctx.prof_begin(kid);
+      if (fc)
+        hipLaunchKernelGGL(tree_tail_challenge_k, dim3(1), dim3(1024), 0, ctx.stream, child, (u32)child_len, *fc);
+      else
+        hipLaunchKernelGGL(tree_tail_k, dim3(1), dim3(256), 0, ctx.stream, child, (u32)child_len);
+      ctx.prof_end(kid, ev, 96.0 * double(child_len));
+      fc = nullptr;
       break;
     }
     if (child_len >= 2048 && li + 2 < L && !inj[li].count && !inj[li + 1].count && !inj[li + 2].count) {
@@ -428,12 +475,17 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
     ctx.prof_end(K_COMPRESS, ev, double(n) * (96.0 + 8.0 * inj[li].total_w));
     li++;
   }
+  if (fc && L == 1) {  // a single leaf is its own root
+    hipLaunchKernelGGL(tree_tail_challenge_k, dim3(1), dim3(1024), 0, ctx.stream, t.base(), 1u, *fc);
+    fc = nullptr;
+  }
+  if (fc) throw std::runtime_error("build_levels: the tree never reached the single-workgroup tail");
   HIP_CHECK(hipGetLastError());
 }
 
-void merkle_compress_plain(Ctx& ctx, DTree& t) {
+void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc) {
   std::vector<InjectAt> inj(t.layer_len.size());
-  build_levels(ctx, t, inj, nullptr);
+  build_levels(ctx, t, inj, nullptr, fc);
 }
 
 void merkle_build(Ctx& ctx, DTree& t) {

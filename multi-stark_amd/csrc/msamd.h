@@ -184,7 +184,8 @@ struct DTree {
 };
 void merkle_build(Ctx& ctx, DTree& t);                     // fills digests for t.mat_* (already set)
 void merkle_alloc(Ctx& ctx, DTree& t, size_t max_height);  // layer table + digest storage only
-void merkle_compress_plain(Ctx& ctx, DTree& t);            // layers 1.. from a filled leaf layer, no injection
+struct FriChallenge;
+void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc = nullptr);            // layers 1.. from a filled leaf layer, no injection
 std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t);  // D2H of the cap layer (synchronises)
 // BLAKE3 of the byte stream prefix (prefix_len bytes) || nwords little-endian u64 words; result to host
 Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords);
@@ -249,7 +250,9 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, size_t height, cons
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
 void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out);
 // Merkle tree of one FRI layer: leaf i = BLAKE3 of the 32-byte row (cur[2i], cur[2i+1]) (ExtensionMmcs flattening)
-void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows);
+// With fc, the launch that produces the root also runs the challenger step of that round (see challenge_dev.h);
+// cur == nullptr means the leaf layer of t (already allocated) was written by fri_fold_dev.
+void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriChallenge* fc = nullptr);
 // gather: rows of column-major matrices and digest siblings for the query phase
 struct GatherReq {
   const void* base;   // matrix (u64) or digest layer
@@ -287,9 +290,18 @@ struct FriTailRoll {
   uint32_t len;
   uint32_t pad;
 };
-void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, const uint8_t state32[32],
-              const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, std::vector<FriTailRound>& rounds_out,
-              std::vector<E2>& final_out);
+// launches only: state_dev (8 words) is read and updated, records / final vector stay on the device
+void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, uint32_t* state_dev,
+              const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, FriTailRound* rounds_dev, E2* final_dev);
+// where one commit-phase round's challenger step reads its state and leaves its record (device pointers)
+struct FriChallenge {
+  uint32_t* state;
+  FriTailRound* rec;
+  uint32_t pow_bits;
+};
+// fold with beta read from rec (device); next_leaves != nullptr also writes the next layer's leaf digests
+void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in /*nullable*/, E2* out,
+                  Digest* next_leaves /*nullable*/);
 // cap of a tree + (when it fits) the PoW witness for transcript prefix || cap, in one host synchronisation
 std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<uint8_t>& prefix, unsigned bits, bool* found,
                                   u64* witness);

@@ -4,6 +4,7 @@
 // (rounds built at :540-579): interpolate_coset, the reduced-opening pass, prover::commit_phase fold_matrix,
 // and mmcs.open_batch for the queries. The transcript itself stays on the host (prover.hip).
 #include "b3_dev.h"
+#include "challenge_dev.h"
 #include "msamd.h"
 
 namespace msamd {
@@ -224,6 +225,57 @@ __global__ __launch_bounds__(256) void fri_leaf_hash_k(const E2* __restrict__ cu
 }
 
 
+// Fold with the challenge still on the device (rec->beta written by the previous round's challenger step) and,
+// when LEAF, the next round's leaf digests in the same pass: thread j produces out[2j], out[2j+1] (one FRI row of
+// the next layer) from cur[4j .. 4j+3] and hashes that row.
+template <bool LEAF>
+__global__ __launch_bounds__(256) void fri_fold_dev_k(const E2* __restrict__ cur, size_t rows, unsigned log_rows,
+                                                      const FriTailRound* __restrict__ rec, const E2* __restrict__ roll,
+                                                      const u64* __restrict__ t0i, const u64* __restrict__ t1i, E2* __restrict__ out,
+                                                      Digest* __restrict__ leaves) {
+  const size_t j = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (2 * j >= rows) return;
+  const u64 half = 0x7FFFFFFF80000001ULL;  // 1/2 mod p
+  const E2 beta = rec->beta;
+  const E2 hb = e2_mul_base(beta, half);
+  const E2 rf = e2_sqr(beta);
+  E2 o[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const size_t i = 2 * j + k;
+    o[k] = e2(0);
+    if (i < rows) {
+      u32 e = bitrev32((u32)i, log_rows) << (TW_LOG - log_rows - 1);
+      u64 gp = gl_mul(t1i[e >> TW_HALF], t0i[e & ((1u << TW_HALF) - 1)]);
+      E2 pw = e2_mul_base(hb, gp);
+      E2 lo = cur[2 * i], hi = cur[2 * i + 1];
+      E2 r = e2_add(e2_mul(e2(gl_add(half, pw.c0), pw.c1), lo), e2_mul(e2(gl_sub(half, pw.c0), gl_neg(pw.c1)), hi));
+      if (roll) r = e2_add(r, e2_mul(rf, roll[i]));
+      out[i] = r;
+      o[k] = r;
+    }
+  }
+  if (LEAF) {
+    u32 m[16];
+    m[0] = (u32)o[0].c0;
+    m[1] = (u32)(o[0].c0 >> 32);
+    m[2] = (u32)o[0].c1;
+    m[3] = (u32)(o[0].c1 >> 32);
+    m[4] = (u32)o[1].c0;
+    m[5] = (u32)(o[1].c0 >> 32);
+    m[6] = (u32)o[1].c1;
+    m[7] = (u32)(o[1].c1 >> 32);
+#pragma unroll
+    for (int k = 8; k < 16; k++) m[k] = 0;
+    u32 cv[8];
+    b3_iv(cv);
+    b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+    uint4* q = reinterpret_cast<uint4*>(leaves + j);
+    q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+  }
+}
+
 // proof-of-work search: smallest w in [w0, w0 + n) such that BLAKE3(prefix || w as 8 LE bytes), read as the
 // challenger's sample_bits (u64 from the LAST 8 digest bytes, reversed), has its low `bits` bits clear.
 // cv_mid = chaining value after the prefix blocks that cannot contain witness bytes; tail = remaining prefix bytes.
@@ -296,7 +348,7 @@ __global__ __launch_bounds__(256) void grind_cap_k(GrindCapParams p, const u32* 
 struct FriTailParams {
   const E2* cur0;
   u32 len0, n_rounds, pow_bits, n_roll;
-  u32 state[8];  // challenger input buffer (one 32-byte digest) as little-endian words
+  u32* state;    // device: challenger input buffer (one 32-byte digest) as little-endian words; updated
   FriTailRoll roll[8];
   Digest* tree_out;   // round r: rows_r + rows_r/2 + ... + 1 digests, rounds back to back
   E2* layers_out;     // input vectors of rounds 1.. (round 0's input is cur0), back to back
@@ -305,22 +357,14 @@ struct FriTailParams {
   const u64 *t0i, *t1i;
 };
 
-__device__ __forceinline__ u64 be64_at(const u32* d, int pos) {
-  // the challenger pops bytes from the back: the u64 built from digest bytes [pos, pos + 8) read big-endian
-  return (u64)__builtin_bswap32(d[pos / 4 + 1]) | ((u64)__builtin_bswap32(d[pos / 4]) << 32);
-}
-
 __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
   __shared__ E2 cur[2048];
   __shared__ __attribute__((aligned(16))) u32 tree[1024 * 8];
-  __shared__ u32 st[8];     // challenger state (latest digest)
-  __shared__ u32 dg[8];     // working digest for sampling
-  __shared__ unsigned long long best;
-  __shared__ E2 beta_sh;
+  __shared__ ChallengeShared cs;
   const u32 t = threadIdx.x;
   u32 len = p.len0;
   for (u32 i = t; i < len; i += 1024) cur[i] = p.cur0[i];
-  if (t < 8) st[t] = p.state[t];
+  if (t < 8) cs.st[t] = p.state[t];
   __syncthreads();
   Digest* tout = p.tree_out;
   E2* lout = p.layers_out;
@@ -380,90 +424,16 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
       __syncthreads();
       tout += n;
     }
-    // ---- challenger: observe the root, grind, sample beta. Transcript block 0 = state || root (64 bytes).
-    u32 blk0[16];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      blk0[k] = st[k];
-      blk0[8 + k] = tree[k];
-    }
-    u64 wit = 0;
-    if (p.pow_bits) {
-      u32 mid[8];
-      b3_iv(mid);
-      b3_compress(mid, blk0, 0, 64, B3_CHUNK_START);
-      if (t == 0) best = ~0ull;
-      __syncthreads();
-      const u64 mask = (u64(1) << p.pow_bits) - 1;
-      for (u64 base = 0;; base += 1024) {
-        const u64 w = base + t;
-        u32 m[16];
-        m[0] = (u32)w;
-        m[1] = (u32)(w >> 32);
-#pragma unroll
-        for (int k = 2; k < 16; k++) m[k] = 0;
-        u32 cv[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) cv[k] = mid[k];
-        b3_compress(cv, m, 0, 8, B3_CHUNK_END | B3_ROOT);
-        const u64 v = (u64)__builtin_bswap32(cv[7]) | ((u64)__builtin_bswap32(cv[6]) << 32);
-        if ((v & mask) == 0) atomicMin(&best, (unsigned long long)w);
-        __syncthreads();
-        const unsigned long long b = best;
-        __syncthreads();
-        if (b != ~0ull) {
-          wit = b;
-          break;
-        }
-      }
-    }
+    // ---- challenger: observe the root, grind, sample beta
+    challenger_round<1024>(cs, tree, p.pow_bits);
     if (t == 0) {
-      u32 cv[8];
-      b3_iv(cv);
-      int pos;
-      if (p.pow_bits) {
-        b3_compress(cv, blk0, 0, 64, B3_CHUNK_START);
-        u32 m[16];
-        m[0] = (u32)wit;
-        m[1] = (u32)(wit >> 32);
-        for (int k = 2; k < 16; k++) m[k] = 0;
-        b3_compress(cv, m, 0, 8, B3_CHUNK_END | B3_ROOT);
-        pos = 24;  // check_witness' sample_bits consumed digest bytes 24..31
-      } else {
-        b3_compress(cv, blk0, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-        pos = 32;
-      }
-      for (int k = 0; k < 8; k++) dg[k] = cv[k];
-      u64 c[2];
-      for (int ci = 0; ci < 2; ci++) {
-        for (;;) {
-          if (pos == 0) {  // output buffer exhausted: flush, i.e. digest <- BLAKE3(digest)
-            u32 m[16], nv[8];
-            for (int k = 0; k < 8; k++) m[k] = dg[k];
-            for (int k = 8; k < 16; k++) m[k] = 0;
-            b3_iv(nv);
-            b3_compress(nv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-            for (int k = 0; k < 8; k++) dg[k] = nv[k];
-            pos = 32;
-          }
-          pos -= 8;
-          const u64 v = be64_at(dg, pos);
-          if (v < GL_P) {
-            c[ci] = v;
-            break;
-          }
-        }
-      }
-      for (int k = 0; k < 8; k++) st[k] = dg[k];
-      beta_sh = e2(c[0], c[1]);
       FriTailRound& out = p.rounds[r];
       for (int k = 0; k < 8; k++) out.root[k] = tree[k];
-      out.witness = wit;
-      out.beta = beta_sh;
+      out.witness = cs.wit;
+      out.beta = cs.beta;
     }
-    __syncthreads();
     // ---- fold (+ roll-in of a reduced opening of matching length)
-    const E2 beta = beta_sh;
+    const E2 beta = cs.beta;
     const E2 hb = e2_mul_base(beta, half);
     const bool do_roll = roll_i < p.n_roll && p.roll[roll_i].len == rows;
     E2 nv = e2(0);
@@ -486,6 +456,7 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
     __syncthreads();
   }
   if (t < len) p.final_out[t] = cur[t];
+  if (t < 8) p.state[t] = cs.st[t];
 }
 
 __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* __restrict__ out) {
@@ -590,15 +561,32 @@ void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in, 
   HIP_CHECK(hipGetLastError());
 }
 
-void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows) {
-  merkle_alloc(ctx, t, rows);
-  hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
-  hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.base());
-  ctx.prof_end(K_LEAF_HASH, ev, 64.0 * rows);
-  HIP_CHECK(hipGetLastError());
-  merkle_compress_plain(ctx, t);
+void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriChallenge* fc) {
+  if (!t.digests.p) merkle_alloc(ctx, t, rows);  // already allocated when the fold wrote the leaf layer
+  if (cur) {
+    hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
+    hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.base());
+    ctx.prof_end(K_LEAF_HASH, ev, 64.0 * rows);
+    HIP_CHECK(hipGetLastError());
+  }
+  merkle_compress_plain(ctx, t, fc);
 }
 
+void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in, E2* out, Digest* next_leaves) {
+  unsigned lr = log2_strict(rows);
+  if (lr + 1 > TW_LOG) throw std::runtime_error("FRI layer above 2^28 is not supported");
+  if (next_leaves && rows < 2) throw std::runtime_error("fri_fold_dev: no next layer to hash");
+  const size_t threads = (rows + 1) / 2;
+  hipEvent_t ev = ctx.prof_begin(K_FRI_FOLD);
+  if (next_leaves)
+    hipLaunchKernelGGL(fri_fold_dev_k<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, rec, roll_in,
+                       ctx.tw0i, ctx.tw1i, out, next_leaves);
+  else
+    hipLaunchKernelGGL(fri_fold_dev_k<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, rec,
+                       roll_in, ctx.tw0i, ctx.tw1i, out, next_leaves);
+  ctx.prof_end(K_FRI_FOLD, ev, (next_leaves ? 64.0 : 48.0) * rows);
+  HIP_CHECK(hipGetLastError());
+}
 
 // Device grinding. `input` is the challenger's pending input buffer; returns the minimal witness.
 bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out) {
@@ -677,9 +665,8 @@ std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<ui
   return cap;
 }
 
-void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, const uint8_t state32[32],
-              const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, std::vector<FriTailRound>& rounds_out,
-              std::vector<E2>& final_out) {
+void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, uint32_t* state_dev,
+              const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, FriTailRound* rounds_dev, E2* final_dev) {
   if (len0 > 2048 || len0 < 2 || (len0 & (len0 - 1))) throw std::runtime_error("fri_tail: bad length");
   if (rolls.size() > 8) throw std::runtime_error("fri_tail: too many roll-in inputs");
   FriTailParams p;
@@ -689,23 +676,16 @@ void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsign
   p.n_rounds = n_rounds;
   p.pow_bits = pow_bits;
   p.n_roll = (u32)rolls.size();
-  memcpy(p.state, state32, 32);
+  p.state = state_dev;
   for (size_t i = 0; i < rolls.size(); i++) p.roll[i] = rolls[i];
   p.tree_out = tree_out;
   p.layers_out = layers_out;
-  const size_t final_len = len0 >> n_rounds;
-  DBuf<E2> d_final(ctx, final_len);
-  DBuf<FriTailRound> d_rounds(ctx, n_rounds);
-  p.final_out = d_final.p;
-  p.rounds = d_rounds.p;
+  p.final_out = final_dev;
+  p.rounds = rounds_dev;
   p.t0i = ctx.tw0i;
   p.t1i = ctx.tw1i;
   hipLaunchKernelGGL(fri_tail_k, dim3(1), dim3(1024), 0, ctx.stream, p);
   HIP_CHECK(hipGetLastError());
-  rounds_out.resize(n_rounds);
-  final_out.resize(final_len);
-  HIP_CHECK(hipMemcpyAsync(rounds_out.data(), d_rounds.p, n_rounds * sizeof(FriTailRound), hipMemcpyDeviceToHost, ctx.stream));
-  ctx.d2h(final_out.data(), d_final.p, final_len * sizeof(E2));
 }
 
 void gather_queries(Ctx& ctx, const std::vector<GatherSeg>& segs, const std::vector<uint64_t>& indices, size_t bytes_per_query,

@@ -639,62 +639,113 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   std::vector<E2> fin;                // final folded vector (host)
   DBuf<Digest> tail_tree;
   DBuf<E2> tail_layers;
-  while (folded.n > stop) {
-    // ---- last rounds on the device in one launch (see fri_tail_k): needs a root-only commitment and the
-    // challenger's pending input to be exactly one digest (true right after a sample)
-    if (folded.n <= 2048 && prm.cap_height == 0 && ch.input.size() == 32 && !getenv("MSAMD_NO_FRI_TAIL")) {
-      const uint32_t len0 = (uint32_t)folded.n;
-      uint32_t n_rounds = 0;
-      size_t tree_digests = 0, layer_elems = 0;
-      for (size_t l = len0; l > stop; l >>= 1) {
-        n_rounds++;
-        tree_digests += l - 1;            // rows + rows/2 + ... + 1 with rows = l/2
-        if (l != len0) layer_elems += l;  // inputs of rounds 1..
+  // ---- device transcript: with a root-only commitment and the challenger's pending input being exactly one digest
+  // (true right after the alpha sample) every round's challenger step runs on the device (challenge_dev.h), so the
+  // whole commit phase is submitted without a host synchronisation. The host then replays the transcript from
+  // the returned roots / witnesses on its own challenger; the device values are checked, not trusted.
+  const bool dev_rounds = folded.n > stop && prm.cap_height == 0 && ch.input.size() == 32 && prm.commit_pow_bits <= 16 &&
+                          !getenv("MSAMD_HOST_FRI");
+  if (dev_rounds) {
+    const bool use_tail = !getenv("MSAMD_NO_FRI_TAIL");
+    size_t n_total = 0;
+    for (size_t l = folded.n; l > stop; l >>= 1) n_total++;
+    DBuf<uint32_t> d_state(ctx, 8);
+    ctx.h2d(d_state.p, ch.input.data(), 32);
+    DBuf<FriTailRound> d_recs(ctx, n_total);
+    DBuf<E2> d_final(ctx, stop);
+    size_t r = 0;
+    bool leaves_done = false;
+    const E2* fin_src = nullptr;
+    while (folded.n > stop) {
+      if (use_tail && folded.n <= 2048) {
+        const uint32_t len0 = (uint32_t)folded.n;
+        const uint32_t n_rounds = (uint32_t)(n_total - r);
+        size_t tree_digests = 0, layer_elems = 0;
+        for (size_t l = len0; l > stop; l >>= 1) {
+          tree_digests += l - 1;            // rows + rows/2 + ... + 1 with rows = l/2
+          if (l != len0) layer_elems += l;  // inputs of rounds 1..
+        }
+        std::vector<FriTailRoll> rolls;
+        for (size_t k = next_in; k < inputs.size(); k++) rolls.push_back(FriTailRoll{inputs[k].p, (uint32_t)inputs[k].n, 0});
+        tail_tree = DBuf<Digest>(ctx, tree_digests);
+        tail_layers = DBuf<E2>(ctx, std::max<size_t>(layer_elems, 1));
+        fri_tail(ctx, folded.p, len0, n_rounds, (unsigned)prm.commit_pow_bits, d_state.p, rolls, tail_tree.p, tail_layers.p, d_recs.p + r,
+                 d_final.p);
+        size_t toff = 0, loff = 0, l = len0;
+        for (uint32_t k = 0; k < n_rounds; k++, l >>= 1) {
+          const size_t rows = l / 2;
+          trees.emplace_back();
+          DTree& t = trees.back();
+          t.cap_height = 0;
+          t.ext = tail_tree.p + toff;
+          size_t o = 0;
+          for (size_t n = rows;; n >>= 1) {
+            t.layer_off.push_back(o);
+            t.layer_len.push_back(n);
+            o += n;
+            if (n == 1) break;
+          }
+          toff += o;
+          layers.push_back(k == 0 ? folded.p : tail_layers.p + loff);
+          if (k > 0) loff += l;
+          if (next_in < inputs.size() && inputs[next_in].n == rows) next_in++;
+        }
+        r += n_rounds;
+        layer_bufs.push_back(std::move(folded));
+        folded = DBuf<E2>();
+        fin_src = d_final.p;
+        break;
       }
-      std::vector<FriTailRoll> rolls;
-      for (size_t k = next_in; k < inputs.size(); k++) rolls.push_back(FriTailRoll{inputs[k].p, (uint32_t)inputs[k].n, 0});
-      tail_tree = DBuf<Digest>(ctx, tree_digests);
-      tail_layers = DBuf<E2>(ctx, std::max<size_t>(layer_elems, 1));
-      std::vector<FriTailRound> rr;
-      fri_tail(ctx, folded.p, len0, n_rounds, (unsigned)prm.commit_pow_bits, ch.input.data(), rolls, tail_tree.p, tail_layers.p, rr,
-               fin);
-      // replay the transcript on the host challenger; the device values are checked, not trusted
-      size_t toff = 0, loff = 0;
-      size_t l = len0;
-      for (uint32_t r = 0; r < n_rounds; r++, l >>= 1) {
-        const size_t rows = l / 2;
+      const size_t rows = folded.n / 2;
+      if (!leaves_done) {
         trees.emplace_back();
-        DTree& t = trees.back();
-        t.cap_height = 0;
-        t.ext = tail_tree.p + toff;
-        size_t o = 0;
-        for (size_t n = rows;; n >>= 1) {
-          t.layer_off.push_back(o);
-          t.layer_len.push_back(n);
-          o += n;
-          if (n == 1) break;
-        }
-        toff += o;
-        layers.push_back(r == 0 ? folded.p : tail_layers.p + loff);
-        if (r > 0) loff += l;
-        Digest root;
-        memcpy(root.b, rr[r].root, 32);
-        std::vector<Digest> cap(1, root);
-        ch.observe_cap(cap);
-        commits.push_back(cap);
-        if (prm.commit_pow_bits) {
-          ch.observe(rr[r].witness);
-          if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("fri_tail: witness rejected by the host challenger");
-        }
-        pow_w.push_back(prm.commit_pow_bits ? rr[r].witness : 0);
-        E2 beta = ch.sample_ext();
-        if (!e2_same(beta, rr[r].beta)) throw std::runtime_error("fri_tail: device challenger diverged from the host transcript");
-        if (next_in < inputs.size() && inputs[next_in].n == rows) next_in++;
+        trees.back().cap_height = 0;
       }
+      DTree& t = trees.back();
+      FriChallenge fc{d_state.p, d_recs.p + r, (uint32_t)prm.commit_pow_bits};
+      fri_tree_build(ctx, t, leaves_done ? nullptr : folded.p, rows, &fc);
+      DBuf<E2> nxt(ctx, rows);
+      const E2* roll = nullptr;
+      if (next_in < inputs.size() && inputs[next_in].n == rows) roll = inputs[next_in++].p;
+      // the next round's leaf layer is hashed by the fold itself unless that round belongs to the tail kernel
+      leaves_done = rows > stop && rows >= 2 && !(use_tail && rows <= 2048);
+      Digest* next_leaves = nullptr;
+      if (leaves_done) {
+        trees.emplace_back();
+        trees.back().cap_height = 0;
+        merkle_alloc(ctx, trees.back(), rows / 2);
+        next_leaves = trees.back().base();
+      }
+      fri_fold_dev(ctx, folded.p, rows, d_recs.p + r, roll, nxt.p, next_leaves);
+      layers.push_back(folded.p);
       layer_bufs.push_back(std::move(folded));
-      folded = DBuf<E2>();
-      break;
+      folded = std::move(nxt);
+      r++;
     }
+    if (r != n_total) throw std::runtime_error("FRI: round count mismatch");
+    if (!fin_src) fin_src = folded.p;
+    std::vector<FriTailRound> recs(n_total);
+    fin.resize(stop);
+    HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs.p, n_total * sizeof(FriTailRound), hipMemcpyDeviceToHost, ctx.stream));
+    ctx.d2h(fin.data(), fin_src, stop * sizeof(E2));
+    folded = DBuf<E2>();
+    for (size_t k = 0; k < n_total; k++) {
+      Digest root;
+      memcpy(root.b, recs[k].root, 32);
+      std::vector<Digest> cap(1, root);
+      ch.observe_cap(cap);
+      commits.push_back(cap);
+      if (prm.commit_pow_bits) {
+        ch.observe(recs[k].witness);
+        if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("FRI: device witness rejected by the host challenger");
+        // minimality (the reference accepts any witness; ours is pinned to the smallest) is the kernel's atomicMin
+      }
+      pow_w.push_back(prm.commit_pow_bits ? recs[k].witness : 0);
+      E2 beta = ch.sample_ext();
+      if (!e2_same(beta, recs[k].beta)) throw std::runtime_error("FRI: device challenger diverged from the host transcript");
+    }
+  }
+  while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, or MSAMD_HOST_FRI)
     size_t rows = folded.n / 2;
     trees.emplace_back();
     DTree& t = trees.back();
