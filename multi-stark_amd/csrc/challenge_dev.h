@@ -13,6 +13,7 @@ namespace msamd {
 struct ChallengeShared {
   u32 st[8];  // challenger input buffer (latest digest)
   u32 dg[8];  // working digest while sampling
+  u32 mid[8]; // chaining value after the first transcript block (state || root)
   unsigned long long best;
   u64 wit;
   E2 beta;
@@ -28,29 +29,39 @@ __device__ __forceinline__ u64 be64_at(const u32* d, int pos) {
 template <int NT>
 __device__ __forceinline__ void challenger_round(ChallengeShared& s, const u32* root, u32 pow_bits) {
   const u32 t = threadIdx.x;
-  // transcript block 0 = state || root (64 bytes)
-  u32 blk0[16];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    blk0[k] = s.st[k];
-    blk0[8 + k] = root[k];
-  }
+  // transcript block 0 = state || root (64 bytes); its chaining value is needed by every grinding thread and by the
+  // final digest, so one wave computes it once
   u64 wit = 0;
   if (pow_bits) {
-    u32 mid[8];
-    b3_iv(mid);
-    b3_compress(mid, blk0, 0, 64, B3_CHUNK_START);
-    if (t == 0) s.best = ~0ull;
+    if (t < 64) {
+      u32 blk0[16], mid[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        blk0[k] = s.st[k];
+        blk0[8 + k] = root[k];
+      }
+      b3_iv(mid);
+      b3_compress(mid, blk0, 0, 64, B3_CHUNK_START);
+      if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.mid[k] = mid[k];
+        s.best = ~0ull;
+      }
+    }
     __syncthreads();
+    u32 mid[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) mid[k] = s.mid[k];
     const u64 mask = (u64(1) << pow_bits) - 1;
+    u32 cv[8];
+    u64 w;
     for (u64 base = 0;; base += NT) {
-      const u64 w = base + t;
+      w = base + t;
       u32 m[16];
       m[0] = (u32)w;
       m[1] = (u32)(w >> 32);
 #pragma unroll
       for (int k = 2; k < 16; k++) m[k] = 0;
-      u32 cv[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) cv[k] = mid[k];
       b3_compress(cv, m, 0, 8, B3_CHUNK_END | B3_ROOT);
@@ -64,26 +75,28 @@ __device__ __forceinline__ void challenger_round(ChallengeShared& s, const u32* 
         break;
       }
     }
-  } else {
-    __syncthreads();  // every thread has read s.st before thread 0 replaces it
+    // the thread that tried the winning witness already holds the digest the sampling continues from
+    if (w == wit) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s.dg[k] = cv[k];
+    }
+    __syncthreads();
   }
   if (t == 0) {
-    u32 cv[8];
-    b3_iv(cv);
     int pos;
     if (pow_bits) {
-      b3_compress(cv, blk0, 0, 64, B3_CHUNK_START);
-      u32 m[16];
-      m[0] = (u32)wit;
-      m[1] = (u32)(wit >> 32);
-      for (int k = 2; k < 16; k++) m[k] = 0;
-      b3_compress(cv, m, 0, 8, B3_CHUNK_END | B3_ROOT);
       pos = 24;  // check_witness' sample_bits consumed digest bytes 24..31
     } else {
+      u32 cv[8], blk0[16];
+      for (int k = 0; k < 8; k++) {
+        blk0[k] = s.st[k];
+        blk0[8 + k] = root[k];
+      }
+      b3_iv(cv);
       b3_compress(cv, blk0, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      for (int k = 0; k < 8; k++) s.dg[k] = cv[k];
       pos = 32;
     }
-    for (int k = 0; k < 8; k++) s.dg[k] = cv[k];
     u64 c[2];
     for (int ci = 0; ci < 2; ci++) {
       for (;;) {

@@ -216,17 +216,15 @@ __global__ __launch_bounds__(256) void claims_words_k(const u64* __restrict__ da
 
 }  // namespace
 
-static E2 scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n) {
+// exclusive prefix sums of in[0..n) into out; the grand total goes to *total_dev (device), nothing is read back
+static void scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n, E2* total_dev) {
   size_t per = 256 * SCAN_ITEMS;
   size_t nb = (n + per - 1) / per;
-  DBuf<E2> tot(ctx, nb + 1);
+  DBuf<E2> tot(ctx, nb);
   hipLaunchKernelGGL(scan_block_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, in, out, n, tot.p);
-  hipLaunchKernelGGL(scan_totals_k, dim3(1), dim3(256), 0, ctx.stream, tot.p, nb, tot.p + nb);
+  hipLaunchKernelGGL(scan_totals_k, dim3(1), dim3(256), 0, ctx.stream, tot.p, nb, total_dev);
   hipLaunchKernelGGL(scan_add_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, out, n, tot.p);
   HIP_CHECK(hipGetLastError());
-  E2 total;
-  ctx.d2h(&total, tot.p + nb, sizeof(E2));
-  return total;
 }
 
 static GammaPows gamma_pows(E2 gamma, size_t max_args) {
@@ -240,12 +238,13 @@ static GammaPows gamma_pows(E2 gamma, size_t max_args) {
   return gp;
 }
 
-E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
+void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, E2* total_dev) {
   size_t n = lk.height;
   if (lk.num_lookups == 0) {
     // pass-through accumulator column: zeros (src/lookup.rs:517-521)
     HIP_CHECK(hipMemsetAsync(out, 0, n * 2 * sizeof(u64), ctx.stream));
-    return e2(0);
+    HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(E2), ctx.stream));
+    return;
   }
   unsigned logn = log2_strict(n);
   u32 L = (u32)lk.num_lookups, aw = (u32)lk.args_width;
@@ -256,26 +255,40 @@ E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
   hipLaunchKernelGGL(stage2_terms_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma, gp,
                      terms.p, rowsum.p);
   ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw));
-  E2 total = scan_exclusive(ctx, rowsum.p, prefix.p, n);
+  scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev);
   ev = ctx.prof_begin(K_STAGE2);
   hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out);
   ctx.prof_end(K_STAGE2, ev, double(n) * 16.0 * L);
   HIP_CHECK(hipGetLastError());
+}
+
+E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
+  DBuf<E2> tot(ctx, 1);
+  stage2_build_async(ctx, lk, beta, gamma, out, tot.p);
+  E2 total;
+  ctx.d2h(&total, tot.p, sizeof(E2));
   return total;
 }
 
-E2 claims_accumulator(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, E2 beta, E2 gamma) {
-  if (n == 0) return e2(0);
+void claims_accumulator_async(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, E2 beta, E2 gamma, E2* out_dev) {
+  if (n == 0) {
+    HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(E2), ctx.stream));
+    return;
+  }
   size_t per = 256 * CLAIMS_CHUNK;
   size_t nb = (n + per - 1) / per;
   DBuf<E2> partial(ctx, nb);
   GammaPows gp = gamma_pows(gamma, MAX_GPOW);
   hipLaunchKernelGGL(claims_acc_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, d_data, d_offs, n, beta, gamma, gp, partial.p);
+  hipLaunchKernelGGL(scan_totals_k, dim3(1), dim3(256), 0, ctx.stream, partial.p, nb, out_dev);  // only the total is used
   HIP_CHECK(hipGetLastError());
-  std::vector<E2> h(nb);
-  ctx.d2h(h.data(), partial.p, nb * sizeof(E2));
-  E2 s = e2(0);
-  for (auto& x : h) s = e2_add(s, x);
+}
+
+E2 claims_accumulator(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, E2 beta, E2 gamma) {
+  DBuf<E2> out(ctx, 1);
+  claims_accumulator_async(ctx, d_data, d_offs, n, beta, gamma, out.p);
+  E2 s;
+  ctx.d2h(&s, out.p, sizeof(E2));
   return s;
 }
 

@@ -200,6 +200,10 @@ struct DLookups {
 // stage-2 trace of one circuit: writes column-major (n x max(L,1)*2) with rows bit-reversed (ready for the
 // inverse DIT); returns the circuit's total contribution sum_{r,j} mult/msg
 E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev);
+// launches only: the contribution is left in *total_dev (device memory)
+void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev);
+void claims_accumulator_async(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma,
+                              E2* out_dev);
 E2 claims_accumulator(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma);
 // the claims part of the transcript as u64 words: count, then per claim its length and elements
 // (src/prover.rs:369-373); d_words must hold 1 + n_claims + total_elems words; returns that count

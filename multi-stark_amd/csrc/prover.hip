@@ -965,32 +965,32 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   ch.observe_ext(beta);
   const E2 gamma = ch.sample_ext();
   ch.observe_ext(gamma);
-  // initial accumulator from the claims (src/prover.rs:382-387)
-  E2 acc;
+  // initial accumulator from the claims (src/prover.rs:382-387). Nothing below needs the accumulators on the
+  // host until they are observed after the stage-2 commitment, so the claims sum and every circuit's contribution
+  // stay in device memory (d_tot[0] = claims, d_tot[1 + pos] = circuit) and come back with that commitment.
+  DBuf<E2> d_tot(ctx, NA + 1);
+  std::vector<E2> h_tot(NA + 1);
   if (n_claims > 256) {
-    acc = claims_accumulator(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, beta, gamma);
+    claims_accumulator_async(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, beta, gamma, d_tot.p);
   } else {
-    acc = e2(0);
+    E2 acc0 = e2(0);
     for (size_t i = 0; i < n_claims; i++) {
       E2 f = e2(0);
       for (size_t k = wit.claim_offsets[i + 1]; k-- > wit.claim_offsets[i];) f = e2_add(e2_mul(f, gamma), e2(wit.claim_data[k]));
-      acc = e2_add(acc, e2_inv(e2_add(beta, f)));
+      acc0 = e2_add(acc0, e2_inv(e2_add(beta, f)));
     }
+    ctx.h2d(d_tot.p, &acc0, sizeof(E2));
   }
-  const E2 acc_initial = acc;
 
   // ---- lookup construction (src/prover.rs:391-409) + stage 2 commit (:413-421)
   t0 = now_ms();
-  std::vector<E2> accs;
   std::vector<DBuf<u64>> s2_evals(NA);
   for (size_t pos = 0; pos < NA; pos++) {
     size_t ci = aidx[pos];
     const HCircuit& c = sys.circuits[ci];
     size_t n = wit.heights[ci];
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
-    E2 total = stage2_build(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p);
-    acc = e2_add(acc, total);
-    accs.push_back(acc);
+    stage2_build_async(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
   }
   lap(1);
   t0 = now_ms();
@@ -1010,7 +1010,17 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s2);
   }
-  std::vector<Digest> s2_cap = merkle_cap(ctx, s2.tree);
+  HIP_CHECK(hipMemcpyAsync(h_tot.data(), d_tot.p, (NA + 1) * sizeof(E2), hipMemcpyDeviceToHost, ctx.stream));
+  std::vector<Digest> s2_cap = merkle_cap(ctx, s2.tree);  // synchronises: h_tot is complete as well
+  const E2 acc_initial = h_tot[0];
+  std::vector<E2> accs;
+  {
+    E2 acc = acc_initial;
+    for (size_t pos = 0; pos < NA; pos++) {
+      acc = e2_add(acc, h_tot[1 + pos]);
+      accs.push_back(acc);
+    }
+  }
   lap(2);
   ch.observe_cap(s2_cap);
   for (auto& a : accs) ch.observe_ext(a);
