@@ -119,3 +119,19 @@ def test_full_size_proof_verifies(pkg, ctx, oracle, fe):
     bad = claims.copy()
     bad[12345, 3] ^= 1
     assert o.verify(fe.pack_claims(bad), proof) != 0
+
+
+# BASELINE config 5: 2^26 additions (228 GiB of the 288 GiB HBM, about a minute with witness generation and the
+# oracle verifier). Opt-in because of its footprint: MSAMD_STRESS=1 python -m pytest tests -m gpu -k config5;
+# the recorded run is profiles/r01_config5_stress.txt (tools/stress.py is the same flow as a script).
+@pytest.mark.skipif(not __import__("os").environ.get("MSAMD_STRESS"), reason="set MSAMD_STRESS=1 for the 2^26-row run")
+def test_config5_two_pow_26_verifies(pkg, ctx, oracle, fe):
+    traces, claims = fe.u32_add_bench_witness(1 << 26)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    o = oracle.System(g.blob)
+    packed = fe.pack_claims(claims)
+    w = g.witness(traces, packed)
+    proof = g.prove_multiple_claims(w).to_bytes()
+    assert o.verify(packed, proof) == 0
+    del w
+    ctx.trim()
