@@ -1,6 +1,7 @@
 """Large-trace stress run of the bench workload (BASELINE config 5 = 2^26 additions): prove, time, verify.
 
-usage: python3 tools/stress.py LOG_ADDS [--no-verify] [--proofs N]
+usage: python3 tools/stress.py LOG_ADDS [--no-verify] [--proofs N] [--airs K]
+--airs K proves the system [ByteTable, U32Add x K] (config 3 as ONE proof, here on one GPU), 2^LOG_ADDS additions per AIR.
 The oracle is used only as the checker (its verifier accepts or rejects the proof bytes)."""
 import ctypes
 import os
@@ -31,11 +32,16 @@ n_proofs = int(sys.argv[sys.argv.index("--proofs") + 1]) if "--proofs" in sys.ar
 pkg = load_package()
 fe = pkg.frontend
 ctx = pkg.Context(0)
-system = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
-say("system ready; generating witness for 2^%d additions" % log_adds)
-traces, claims = fe.u32_add_bench_witness(1 << log_adds)
+airs = int(sys.argv[sys.argv.index("--airs") + 1]) if "--airs" in sys.argv else 0
+inputs = fe.multi_u32_add_system_inputs(airs) if airs else fe.u32_add_system_inputs()
+system = pkg.System.new(ctx, fe.bench_params(), inputs)
+say("system ready (%d circuits); generating witness for 2^%d additions per AIR" % (len(inputs), log_adds))
+if airs:
+    traces, claims = fe.multi_u32_add_witness(airs, 1 << log_adds)
+else:
+    traces, claims = fe.u32_add_bench_witness(1 << log_adds)
 packed = fe.pack_claims(claims)
-say("witness on host: trace %.2f GB, claims %.2f GB" % (traces[1].nbytes / 1e9, packed[1].nbytes / 1e9))
+say("witness on host: traces %.2f GB, claims %.2f GB" % (sum(t.nbytes for t in traces) / 1e9, packed[1].nbytes / 1e9))
 w = system.witness(traces, packed)
 ctx.sync()
 say("witness resident in HBM; device memory in use %.1f of %.1f GiB" % mem_gb())
@@ -44,7 +50,7 @@ for i in range(n_proofs):
     t = time.time()
     p = system.prove_multiple_claims(w, want_times=True)
     dt = time.time() - t
-    rows = (1 << log_adds) + 256
+    rows = max(airs, 1) * (1 << log_adds) + 256
     say("proof %d: %.1f ms wall (%.1f M rows/s), %d bytes, stages %s; device memory %.1f GiB" % (
         i, 1e3 * dt, rows / dt / 1e6, len(p.to_bytes()), {k: round(v, 1) for k, v in p.stage_ms.items()}, mem_gb()[0]))
     if proof is not None and p.to_bytes() != proof:
