@@ -43,6 +43,11 @@ Ctx::Ctx(int dev) : device(dev) {
   if (dev < 0 || dev >= count) throw std::runtime_error("HIP device index out of range");
   HIP_CHECK(hipSetDevice(dev));
   HIP_CHECK(hipStreamCreate(&stream));
+  pinned_half = size_t(8) << 20;
+  if (hipHostMalloc((void**)&pinned, 2 * pinned_half, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    pinned = nullptr;  // transfers fall back to pageable staging by the runtime
+  }
   const size_t T = size_t(1) << TW_HALF;
   std::vector<u64> h(4 * T);
   u64 W = gl_two_adic_generator(TW_LOG), Wi = gl_inv(W);
@@ -112,6 +117,7 @@ Ctx::~Ctx() {
   for (auto& kv : pool_free) (void)hipFree(kv.second);
   for (auto& kv : pool_live) (void)hipFree(kv.first);
   for (auto& kv : lde_scales) (void)hipFree(kv.second);
+  if (pinned) (void)hipHostFree(pinned);
   if (tw0) (void)hipFree(tw0);
   if (twc) (void)hipFree(twc);
   (void)hipStreamDestroy(stream);
@@ -155,14 +161,43 @@ void Ctx::trim() {
   pool_free.clear();
 }
 
+void Ctx::sync_and_deliver() {
+  HIP_CHECK(hipStreamSynchronize(stream));
+  for (auto& d : down_pending) memcpy(d.dst, pinned + pinned_half + d.off, d.n);
+  down_pending.clear();
+  down_used = 0;
+  up_used = 0;  // every queued upload has executed
+}
+
 void Ctx::h2d(void* dst, const void* src, size_t n) {
   if (n == 0) return;
+  if (pinned && n <= (size_t(1) << 20)) {
+    size_t need = (n + 63) & ~size_t(63);
+    if (up_used + need > pinned_half) sync_and_deliver();
+    memcpy(pinned + up_used, src, n);
+    HIP_CHECK(hipMemcpyAsync(dst, pinned + up_used, n, hipMemcpyHostToDevice, stream));
+    up_used += need;
+    return;
+  }
   HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
 }
 
+void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
+  if (n == 0) return;
+  size_t need = (n + 63) & ~size_t(63);
+  if (!pinned || need > pinned_half) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));  // pageable: staged by the runtime
+    return;
+  }
+  if (down_used + need > pinned_half) sync_and_deliver();
+  HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
+  down_pending.push_back(PendingD2H{dst, down_used, n});
+  down_used += need;
+}
+
 void Ctx::d2h(void* dst, const void* src, size_t n) {
-  if (n) HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
+  d2h_queue(dst, src, n);
+  sync_and_deliver();
 }
 
 hipEvent_t Ctx::prof_begin(int id) {

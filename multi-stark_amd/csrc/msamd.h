@@ -69,9 +69,16 @@ struct Ctx {
   std::multimap<size_t, void*> pool_free;
   std::map<void*, size_t> pool_live;
   size_t pool_bytes = 0;
-  // pinned staging for small D2H/H2D transfers
+  // pinned staging for small transfers: the first half takes uploads (bump-allocated; every block stays untouched
+  // until the stream has been synchronised, then the half is reused), the second half receives read-backs.
+  // Pageable buffers would make hipMemcpyAsync stage and block on the host for every call.
   uint8_t* pinned = nullptr;
-  size_t pinned_cap = 0;
+  size_t pinned_half = 0, up_used = 0, down_used = 0;
+  struct PendingD2H {
+    void* dst;
+    size_t off, n;
+  };
+  std::vector<PendingD2H> down_pending;
   // LDE scale vectors (g w^k0)^j / n, per log_n and log_blowup
   std::map<std::pair<unsigned, unsigned>, u64*> lde_scales;
   // profiling
@@ -90,9 +97,11 @@ struct Ctx {
   void* alloc(size_t bytes);
   void release(void* p);
   void trim();  // return pooled blocks to the driver
-  void sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+  void sync() { sync_and_deliver(); }
+  void sync_and_deliver();  // stream synchronisation + hand-over of queued read-backs
   void h2d(void* dst, const void* src, size_t n);
-  void d2h(void* dst, const void* src, size_t n);  // synchronous (waits for the stream)
+  void d2h(void* dst, const void* src, size_t n);        // synchronous (waits for the stream)
+  void d2h_queue(void* dst, const void* src, size_t n);  // delivered to dst by the next d2h / sync_and_deliver
   const u64* lde_scale(unsigned log_n, unsigned log_blowup);
   // profiling hooks around one launch
   bool prof_on(int id) const { return (prof_mask >> id) & 1u; }
@@ -279,6 +288,13 @@ struct GatherSeg {
 };
 void gather_queries(Ctx& ctx, const std::vector<GatherSeg>& segs, const std::vector<uint64_t>& indices, size_t bytes_per_query,
                     uint8_t* host_out);
+// launches only: segment list uploaded to segs_dev, indices read from device memory, openings left in out_dev
+void gather_queries_launch(Ctx& ctx, const std::vector<GatherSeg>& segs, GatherSeg* segs_dev, const u64* indices_dev, size_t n_queries,
+                           size_t bytes_per_query, uint8_t* out_dev);
+// query-phase challenger step on the device (one-coefficient final polynomial): out_dev[0] = PoW witness,
+// out_dev[1 + q] = query index q; state_dev is the challenger state the commit phase left
+void fri_query_challenge(Ctx& ctx, const uint32_t* state_dev, const E2* final_dev, unsigned pow_bits, uint32_t n_queries,
+                         unsigned log_max_height, u64* out_dev);
 // proof-of-work search on the device (single-chunk transcripts); false = not applicable, use the host loop
 bool grind_device(Ctx& ctx, const std::vector<uint8_t>& input, unsigned bits, u64* witness_out);
 // Last FRI rounds (vectors of <= 2048 elements) in ONE single-workgroup launch: per round leaf hashes, tree, the

@@ -459,6 +459,81 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
   if (t < 8) p.state[t] = cs.st[t];
 }
 
+// Query-phase challenger work in one single-workgroup launch, for a one-coefficient final polynomial: the
+// transcript block is state (32 bytes) || final coefficient (16 bytes) [|| witness (8 bytes)]; after the
+// proof-of-work check every query index is one sample_bits(log_max_height). out[0] = witness, out[1 + q] = index q.
+__global__ __launch_bounds__(1024) void fri_query_challenge_k(const u32* __restrict__ state, const E2* __restrict__ fin, u32 pow_bits,
+                                                              u32 n_queries, u32 log_max_height, u64* __restrict__ out) {
+  __shared__ u32 dg[8];
+  __shared__ unsigned long long best;
+  const u32 t = threadIdx.x;
+  u32 blk[16];
+#pragma unroll
+  for (int k = 0; k < 8; k++) blk[k] = state[k];
+  const E2 f = fin[0];
+  blk[8] = (u32)f.c0;
+  blk[9] = (u32)(f.c0 >> 32);
+  blk[10] = (u32)f.c1;
+  blk[11] = (u32)(f.c1 >> 32);
+  blk[12] = blk[13] = blk[14] = blk[15] = 0;
+  u64 wit = 0;
+  if (pow_bits) {
+    if (t == 0) best = ~0ull;
+    __syncthreads();
+    const u64 mask = (u64(1) << pow_bits) - 1;
+    u32 cv[8];
+    u64 w;
+    for (u64 base = 0;; base += 1024) {
+      w = base + t;
+      blk[12] = (u32)w;
+      blk[13] = (u32)(w >> 32);
+      b3_iv(cv);
+      b3_compress(cv, blk, 0, 56, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      const u64 v = (u64)__builtin_bswap32(cv[7]) | ((u64)__builtin_bswap32(cv[6]) << 32);
+      if ((v & mask) == 0) atomicMin(&best, (unsigned long long)w);
+      __syncthreads();
+      const unsigned long long b = best;
+      __syncthreads();
+      if (b != ~0ull) {
+        wit = b;
+        break;
+      }
+    }
+    if (w == wit) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) dg[k] = cv[k];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    int pos;
+    if (pow_bits) {
+      pos = 24;  // check_witness' sample_bits consumed digest bytes 24..31
+    } else {
+      u32 cv[8];
+      b3_iv(cv);
+      b3_compress(cv, blk, 0, 48, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      for (int k = 0; k < 8; k++) dg[k] = cv[k];
+      pos = 32;
+    }
+    out[0] = wit;
+    const u64 imask = (u64(1) << log_max_height) - 1;
+    for (u32 q = 0; q < n_queries; q++) {
+      if (pos == 0) {  // output buffer exhausted: digest <- BLAKE3(digest)
+        u32 m[16], nv[8];
+        for (int k = 0; k < 8; k++) m[k] = dg[k];
+        for (int k = 8; k < 16; k++) m[k] = 0;
+        b3_iv(nv);
+        b3_compress(nv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+        for (int k = 0; k < 8; k++) dg[k] = nv[k];
+        pos = 32;
+      }
+      pos -= 8;
+      out[1 + q] = be64_at(dg, pos) & imask;
+    }
+  }
+}
+
 __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* __restrict__ out) {
   size_t r = blockIdx.x;
   if (r >= n) return;
@@ -656,7 +731,7 @@ std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<ui
                      (const u32*)(t.base() + t.layer_off[cl]), best.p);
   HIP_CHECK(hipGetLastError());
   unsigned long long r = 0;
-  HIP_CHECK(hipMemcpyAsync(cap.data(), t.base() + t.layer_off[cl], ncap * sizeof(Digest), hipMemcpyDeviceToHost, ctx.stream));
+  ctx.d2h_queue(cap.data(), t.base() + t.layer_off[cl], ncap * sizeof(Digest));
   ctx.d2h(&r, best.p, 8);
   if (r != ~0ull) {
     *found = true;
@@ -688,17 +763,31 @@ void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsign
   HIP_CHECK(hipGetLastError());
 }
 
+void fri_query_challenge(Ctx& ctx, const uint32_t* state_dev, const E2* final_dev, unsigned pow_bits, uint32_t n_queries,
+                         unsigned log_max_height, u64* out_dev) {
+  if (log_max_height >= 64) throw std::runtime_error("fri_query_challenge: bad height");
+  hipLaunchKernelGGL(fri_query_challenge_k, dim3(1), dim3(1024), 0, ctx.stream, state_dev, final_dev, pow_bits, n_queries, log_max_height,
+                     out_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+void gather_queries_launch(Ctx& ctx, const std::vector<GatherSeg>& segs, GatherSeg* segs_dev, const u64* indices_dev, size_t n_queries,
+                           size_t bytes_per_query, uint8_t* out_dev) {
+  if (segs.empty() || n_queries == 0) return;
+  ctx.h2d(segs_dev, segs.data(), segs.size() * sizeof(GatherSeg));
+  hipLaunchKernelGGL(gather_queries_k, dim3((unsigned)segs.size(), (unsigned)n_queries), dim3(64), 0, ctx.stream,
+                     (const GatherSeg*)segs_dev, indices_dev, bytes_per_query, out_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
 void gather_queries(Ctx& ctx, const std::vector<GatherSeg>& segs, const std::vector<uint64_t>& indices, size_t bytes_per_query,
                     uint8_t* host_out) {
   if (segs.empty() || indices.empty()) return;
   DBuf<GatherSeg> ds(ctx, segs.size());
   DBuf<u64> di(ctx, indices.size());
   DBuf<uint8_t> dout(ctx, bytes_per_query * indices.size());
-  ctx.h2d(ds.p, segs.data(), segs.size() * sizeof(GatherSeg));
   ctx.h2d(di.p, indices.data(), indices.size() * 8);
-  hipLaunchKernelGGL(gather_queries_k, dim3((unsigned)segs.size(), (unsigned)indices.size()), dim3(64), 0, ctx.stream, ds.p, di.p,
-                     bytes_per_query, dout.p);
-  HIP_CHECK(hipGetLastError());
+  gather_queries_launch(ctx, segs, ds.p, di.p, indices.size(), bytes_per_query, dout.p);
   ctx.d2h(host_out, dout.p, bytes_per_query * indices.size());
 }
 

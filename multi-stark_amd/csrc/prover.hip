@@ -645,17 +645,24 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   // the returned roots / witnesses on its own challenger; the device values are checked, not trusted.
   const bool dev_rounds = folded.n > stop && prm.cap_height == 0 && ch.input.size() == 32 && prm.commit_pow_bits <= 16 &&
                           !getenv("MSAMD_HOST_FRI");
+  // With a one-coefficient final polynomial the query phase's challenger work (observe the final polynomial, grind,
+  // sample every index) also runs on the device and the openings are gathered from the device-side indices, so
+  // the whole of FRI costs one host synchronisation; the host replay below checks witness and indices.
+  const bool dev_query = dev_rounds && final_len == 1 && prm.query_pow_bits <= 16 && prm.num_queries <= 4096 && !getenv("MSAMD_HOST_QUERY");
+  size_t n_total = 0;
+  DBuf<uint32_t> d_state;
+  DBuf<FriTailRound> d_recs;
+  DBuf<E2> d_final, fin_hold;
+  const E2* fin_src = nullptr;
   if (dev_rounds) {
     const bool use_tail = !getenv("MSAMD_NO_FRI_TAIL");
-    size_t n_total = 0;
     for (size_t l = folded.n; l > stop; l >>= 1) n_total++;
-    DBuf<uint32_t> d_state(ctx, 8);
+    d_state = DBuf<uint32_t>(ctx, 8);
     ctx.h2d(d_state.p, ch.input.data(), 32);
-    DBuf<FriTailRound> d_recs(ctx, n_total);
-    DBuf<E2> d_final(ctx, stop);
+    d_recs = DBuf<FriTailRound>(ctx, n_total);
+    d_final = DBuf<E2>(ctx, stop);
     size_t r = 0;
     bool leaves_done = false;
-    const E2* fin_src = nullptr;
     while (folded.n > stop) {
       if (use_tail && folded.n <= 2048) {
         const uint32_t len0 = (uint32_t)folded.n;
@@ -723,27 +730,11 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       r++;
     }
     if (r != n_total) throw std::runtime_error("FRI: round count mismatch");
-    if (!fin_src) fin_src = folded.p;
-    std::vector<FriTailRound> recs(n_total);
-    fin.resize(stop);
-    HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs.p, n_total * sizeof(FriTailRound), hipMemcpyDeviceToHost, ctx.stream));
-    ctx.d2h(fin.data(), fin_src, stop * sizeof(E2));
-    folded = DBuf<E2>();
-    for (size_t k = 0; k < n_total; k++) {
-      Digest root;
-      memcpy(root.b, recs[k].root, 32);
-      std::vector<Digest> cap(1, root);
-      ch.observe_cap(cap);
-      commits.push_back(cap);
-      if (prm.commit_pow_bits) {
-        ch.observe(recs[k].witness);
-        if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("FRI: device witness rejected by the host challenger");
-        // minimality (the reference accepts any witness; ours is pinned to the smallest) is the kernel's atomicMin
-      }
-      pow_w.push_back(prm.commit_pow_bits ? recs[k].witness : 0);
-      E2 beta = ch.sample_ext();
-      if (!e2_same(beta, recs[k].beta)) throw std::runtime_error("FRI: device challenger diverged from the host transcript");
+    if (!fin_src) {
+      fin_src = folded.p;
+      fin_hold = std::move(folded);
     }
+    folded = DBuf<E2>();
   }
   while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, or MSAMD_HOST_FRI)
     size_t rows = folded.n / 2;
@@ -773,35 +764,9 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     layer_bufs.push_back(std::move(folded));
     folded = std::move(nxt);
   }
-  tr.mark("fri_commit_phase");
   if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
-  if (folded.p) {
-    fin.resize(folded.n);
-    ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
-  }
-  // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
-  if (fin.size() != stop) throw std::runtime_error("FRI: unexpected final length");
-  std::vector<E2> final_poly(final_len);
-  {
-    unsigned lf = (unsigned)prm.log_final_poly_len;
-    std::vector<E2> ev(final_len);
-    for (size_t i = 0; i < final_len; i++) ev[bitrev64(i, lf)] = fin[i];
-    u64 winv = gl_inv(gl_two_adic_generator(lf)), ninv = gl_inv((u64)final_len);
-    for (size_t k = 0; k < final_len; k++) {
-      E2 s = e2(0);
-      u64 wk = gl_pow(winv, k), cur = 1;
-      for (size_t j = 0; j < final_len; j++) {
-        s = e2_add(s, e2_mul_base(ev[j], cur));
-        cur = gl_mul(cur, wk);
-      }
-      final_poly[k] = e2_mul_base(s, ninv);
-      ch.observe_ext(final_poly[k]);
-    }
-  }
-  const u64 query_pow = grind(ctx, ch, (unsigned)prm.query_pow_bits);
 
-  // ---- query phase: sample every index, one gather for all openings
-  // the segment list (what to read for ONE query) is built while the device still works; only the indices follow
+  // ---- query phase, part 1: the segment list (what to read for ONE query) needs no challenge
   std::vector<GatherSeg> segs;
   size_t out_off = 0;
   auto add_seg = [&](const void* base, u64 stride, uint32_t count, uint32_t kind, uint32_t shift, uint32_t flip) {
@@ -831,12 +796,87 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     for (size_t l = 0; l < n_siblings(t); l++) add_seg(t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(i + 1 + l), 1);
   }
   const size_t qbytes = out_off;
-  std::vector<uint64_t> indices(prm.num_queries);
-  for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
-  tr.mark("final_poly+grind");
-  std::vector<uint8_t> g(qbytes * indices.size());
-  gather_queries(ctx, segs, indices, qbytes, g.data());
-  tr.mark("query_gather");
+  const size_t nq = (size_t)prm.num_queries;
+  std::vector<uint8_t> g(qbytes * nq);
+  std::vector<u64> dq(1 + nq);  // device query step: [0] = PoW witness, [1..] = indices
+  if (dev_rounds) {
+    DBuf<u64> d_q;
+    DBuf<uint8_t> d_g;
+    DBuf<GatherSeg> d_segs;
+    if (dev_query) {
+      d_q = DBuf<u64>(ctx, 1 + nq);
+      fri_query_challenge(ctx, d_state.p, fin_src, (unsigned)prm.query_pow_bits, (uint32_t)nq, log_max_height, d_q.p);
+      d_g = DBuf<uint8_t>(ctx, std::max<size_t>(g.size(), 1));
+      d_segs = DBuf<GatherSeg>(ctx, std::max<size_t>(segs.size(), 1));
+      gather_queries_launch(ctx, segs, d_segs.p, d_q.p + 1, nq, qbytes, d_g.p);
+      ctx.d2h_queue(dq.data(), d_q.p, dq.size() * 8);
+      ctx.d2h_queue(g.data(), d_g.p, g.size());
+    }
+    std::vector<FriTailRound> recs(n_total);
+    fin.resize(stop);
+    ctx.d2h_queue(recs.data(), d_recs.p, n_total * sizeof(FriTailRound));
+    ctx.d2h(fin.data(), fin_src, stop * sizeof(E2));  // the one synchronisation of the FRI phase
+    fin_hold.reset();
+    for (size_t k = 0; k < n_total; k++) {
+      Digest root;
+      memcpy(root.b, recs[k].root, 32);
+      std::vector<Digest> cap(1, root);
+      ch.observe_cap(cap);
+      commits.push_back(cap);
+      if (prm.commit_pow_bits) {
+        ch.observe(recs[k].witness);
+        if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("FRI: device witness rejected by the host challenger");
+        // minimality (the reference accepts any witness; ours is pinned to the smallest) is the kernel's atomicMin
+      }
+      pow_w.push_back(prm.commit_pow_bits ? recs[k].witness : 0);
+      E2 beta = ch.sample_ext();
+      if (!e2_same(beta, recs[k].beta)) throw std::runtime_error("FRI: device challenger diverged from the host transcript");
+    }
+  } else if (folded.p) {
+    fin.resize(folded.n);
+    ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
+  }
+  tr.mark("fri_commit_phase");
+  // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
+  if (fin.size() != stop) throw std::runtime_error("FRI: unexpected final length");
+  std::vector<E2> final_poly(final_len);
+  {
+    unsigned lf = (unsigned)prm.log_final_poly_len;
+    std::vector<E2> ev(final_len);
+    for (size_t i = 0; i < final_len; i++) ev[bitrev64(i, lf)] = fin[i];
+    u64 winv = gl_inv(gl_two_adic_generator(lf)), ninv = gl_inv((u64)final_len);
+    for (size_t k = 0; k < final_len; k++) {
+      E2 s = e2(0);
+      u64 wk = gl_pow(winv, k), cur = 1;
+      for (size_t j = 0; j < final_len; j++) {
+        s = e2_add(s, e2_mul_base(ev[j], cur));
+        cur = gl_mul(cur, wk);
+      }
+      final_poly[k] = e2_mul_base(s, ninv);
+      ch.observe_ext(final_poly[k]);
+    }
+  }
+  // ---- query phase, part 2: proof of work, indices, openings
+  u64 query_pow = 0;
+  std::vector<uint64_t> indices(nq);
+  if (dev_query) {
+    query_pow = dq[0];
+    if (prm.query_pow_bits) {
+      ch.observe(query_pow);
+      if (ch.sample_bits((unsigned)prm.query_pow_bits) != 0) throw std::runtime_error("FRI: device query witness rejected by the host challenger");
+    }
+    for (size_t i = 0; i < nq; i++) {
+      indices[i] = ch.sample_bits(log_max_height);
+      if (indices[i] != dq[1 + i]) throw std::runtime_error("FRI: device query indices diverged from the host transcript");
+    }
+    tr.mark("final_poly+grind+gather");
+  } else {
+    query_pow = grind(ctx, ch, (unsigned)prm.query_pow_bits);
+    for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
+    tr.mark("final_poly+grind");
+    gather_queries(ctx, segs, indices, qbytes, g.data());
+    tr.mark("query_gather");
+  }
 
   // ---- FriProof bytes
   PW& w = fri_bytes;
@@ -1010,7 +1050,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s2);
   }
-  HIP_CHECK(hipMemcpyAsync(h_tot.data(), d_tot.p, (NA + 1) * sizeof(E2), hipMemcpyDeviceToHost, ctx.stream));
+  ctx.d2h_queue(h_tot.data(), d_tot.p, (NA + 1) * sizeof(E2));
   std::vector<Digest> s2_cap = merkle_cap(ctx, s2.tree);  // synchronises: h_tot is complete as well
   const E2 acc_initial = h_tot[0];
   std::vector<E2> accs;
