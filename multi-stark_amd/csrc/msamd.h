@@ -242,24 +242,29 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
 
 // ---------------------------------------------------------------- open.hip
 // 1/(z - x_i) for i < H over the bit-reversed coset x_i = 7 w_H^{bitrev(i)}; out: E2[H] (AoS)
-void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out);
+// xout (nullable): x_i / (z - x_i) for i < n_x, the barycentric weights of the trace-domain coset
+void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);
 // opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i].
 // bary_sums_async only launches (raw sums to device memory, index c * np + p); bary_finish applies scale_p on the host.
-void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* invden0, const E2* invden1,
+void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* xden0, const E2* xden1,
                      int npoints, E2* out_dev);
 void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npoints, E2* out /* p * w + c */);
 struct DeepMat {
-  const u64* d;       // column-major LDE
+  const u64* d;         // column-major LDE
   uint32_t w;
   uint32_t npoints;
-  E2 coeff[2];        // alpha^{offset_p}
-  E2 red_z[2];        // sum_c alpha^c y_p[c]
-  uint32_t inv_idx[2];  // which inverse-denominator vector each point uses
-  uint32_t pad[2];
+  uint32_t pt[2];       // which of the launch's points each opening uses
+  E2 coeff[2];          // alpha^{offset_p}
+  uint64_t coeff7[2];   // 7 * coeff.c1 (X^2 = 7), for the lazy product with the column sums
 };
-// ro[i] += sum over matrices/points of coeff_p * (red_z_p - sum_c alpha^c m[i][c]) * invden_{idx_p}[i]
-void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, size_t height, const E2* alpha_pows_dev, size_t n_alpha,
-                 const E2* const* invden_dev /* device array of pointers */, E2* ro, bool accumulate);
+struct DeepPoints {
+  uint32_t n;           // opening points at this height (at most two: zeta and zeta * g)
+  uint32_t pad;
+  const E2* den[2];     // 1 / (z_q - x_i), device
+  E2 K[2];              // sum over matrices opened at z_q of coeff * (sum_c alpha^c y_q[c])
+};
+// ro[i] = sum over matrices/points of coeff * (red_z - sum_c alpha^c m[i][c]) / (z - x_i)
+void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro);
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
 void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out);
 // Merkle tree of one FRI layer: leaf i = BLAKE3 of the 32-byte row (cur[2i], cur[2i+1]) (ExtensionMmcs flattening)

@@ -18,26 +18,33 @@ __device__ __forceinline__ u64 coset_point(const u64* __restrict__ t0, const u64
 }
 
 constexpr int DEN_CHUNK = 8;
+// out[i] = 1 / (z - x_i) for i < H; xout[i] = x_i / (z - x_i) for i < n_x (the barycentric weights: only the
+// first H / blowup storage rows, i.e. the trace-domain coset, are ever used there)
 __global__ __launch_bounds__(256) void inv_denoms_k(E2 z, unsigned log_h, const u64* __restrict__ t0, const u64* __restrict__ t1,
-                                                    E2* __restrict__ out) {
+                                                    E2* __restrict__ out, E2* __restrict__ xout, size_t n_x) {
   const size_t H = size_t(1) << log_h;
   size_t base = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * DEN_CHUNK;
   if (base >= H) return;
   E2 d[DEN_CHUNK], pre[DEN_CHUNK];
+  u64 x[DEN_CHUNK];
   E2 acc = e2(1);
 #pragma unroll
   for (int k = 0; k < DEN_CHUNK; k++) {
     if (base + k < H) {
-      d[k] = e2(gl_sub(z.c0, coset_point(t0, t1, (u32)(base + k), log_h)), z.c1);
+      x[k] = coset_point(t0, t1, (u32)(base + k), log_h);
+      d[k] = e2(gl_sub(z.c0, x[k]), z.c1);
       pre[k] = acc;
       acc = e2_mul(acc, d[k]);
     }
   }
   E2 inv = e2_inv(acc);
+  const bool want_x = base < n_x;  // n_x is a multiple of the chunk or smaller than one (then guarded per element)
 #pragma unroll
   for (int k = DEN_CHUNK - 1; k >= 0; k--) {
     if (base + k < H) {
-      out[base + k] = e2_mul(inv, pre[k]);
+      const E2 r = e2_mul(inv, pre[k]);
+      out[base + k] = r;
+      if (want_x && base + k < n_x) xout[base + k] = e2_mul_base(r, x[k]);
       inv = e2_mul(inv, d[k]);
     }
   }
@@ -52,60 +59,59 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
   return v;
 }
 
-constexpr int BARY_ROWS = 8;  // rows per thread
-// partial[(blk * w + c) * np + p] = sum over the block's rows of col_c[i] * x_i * invden_p[i]
+constexpr int BARY_ROWS = 32;  // rows per thread
+constexpr int BARY_COLS = 7;   // columns per workgroup: 4 lazy accumulators each stay in registers for the whole block
+// partial[(blk * w + c) * np + p] = sum over the block's rows of col_c[i] * xden_p[i], xden_p[i] = x_i / (z_p - x_i).
+// grid = (row blocks, column groups): every thread walks BARY_ROWS rows of BARY_COLS columns with 160-bit lazy
+// accumulators and the cross-lane reduction happens once per block, not once per column
 template <int NP>
 __global__ __launch_bounds__(256) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
-                                                      const E2* __restrict__ den0, const E2* __restrict__ den1,
-                                                      const u64* __restrict__ t0, const u64* __restrict__ t1, E2* __restrict__ partial) {
-  __shared__ u64 sh[4][NP * 2];
+                                                      const E2* __restrict__ xden0, const E2* __restrict__ xden1,
+                                                      E2* __restrict__ partial) {
+  __shared__ u64 sh[4][BARY_COLS][NP * 2];
   const size_t h = size_t(1) << log_h;
   const size_t base = blockIdx.x * size_t(256 * BARY_ROWS);
-  E2 cs[BARY_ROWS][NP];
+  const u32 c0 = blockIdx.y * BARY_COLS;
+  const u32 nc = w - c0 < (u32)BARY_COLS ? w - c0 : (u32)BARY_COLS;
+  const u64* __restrict__ col0 = mat + size_t(c0) * mat_h;
+  GlAcc acc[BARY_COLS][NP * 2];
 #pragma unroll
+  for (int c = 0; c < BARY_COLS; c++)
+#pragma unroll
+    for (int j = 0; j < NP * 2; j++) acc_init(acc[c][j]);
   for (int k = 0; k < BARY_ROWS; k++) {
-    size_t i = base + size_t(k) * 256 + threadIdx.x;
-    if (i < h) {
-      u64 x = coset_point(t0, t1, (u32)i, log_h);
-      cs[k][0] = e2_mul_base(den0[i], x);
-      if (NP == 2) cs[k][1] = e2_mul_base(den1[i], x);
-    } else {
-      cs[k][0] = e2(0);
-      if (NP == 2) cs[k][1] = e2(0);
+    const size_t i = base + size_t(k) * 256 + threadIdx.x;
+    if (i >= h) break;
+    E2 xd[NP];
+    xd[0] = xden0[i];
+    if (NP == 2) xd[1] = xden1[i];
+    u64 v[BARY_COLS];
+#pragma unroll
+    for (int c = 0; c < BARY_COLS; c++) v[c] = (u32)c < nc ? col0[size_t(c) * mat_h + i] : 0;
+#pragma unroll
+    for (int c = 0; c < BARY_COLS; c++) {
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        acc_mad(acc[c][2 * p], xd[p].c0, v[c]);
+        acc_mad(acc[c][2 * p + 1], xd[p].c1, v[c]);
+      }
     }
   }
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (u32 c = 0; c < w; c++) {
-    const u64* col = mat + size_t(c) * mat_h;
-    GlAcc acc[NP * 2];
 #pragma unroll
-    for (int j = 0; j < NP * 2; j++) acc_init(acc[j]);
+  for (int c = 0; c < BARY_COLS; c++) {
 #pragma unroll
-    for (int k = 0; k < BARY_ROWS; k++) {
-      size_t i = base + size_t(k) * 256 + threadIdx.x;
-      u64 v = i < h ? col[i] : 0;
-#pragma unroll
-      for (int p = 0; p < NP; p++) {
-        acc_mad(acc[2 * p], cs[k][p].c0, v);
-        acc_mad(acc[2 * p + 1], cs[k][p].c1, v);
-      }
+    for (int j = 0; j < NP * 2; j++) {
+      u64 a = wave_sum(acc_reduce(acc[c][j]));
+      if (lane == 0) sh[wave][c][j] = a;
     }
-    u64 a[NP * 2];
-#pragma unroll
-    for (int j = 0; j < NP * 2; j++) a[j] = acc_reduce(acc[j]);
-#pragma unroll
-    for (int j = 0; j < NP * 2; j++) a[j] = wave_sum(a[j]);
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < NP * 2; j++) sh[wave][j] = a[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < NP * 2) {
-      u64 s = gl_add(gl_add(sh[0][threadIdx.x], sh[1][threadIdx.x]), gl_add(sh[2][threadIdx.x], sh[3][threadIdx.x]));
-      u64* dst = reinterpret_cast<u64*>(partial + (size_t(blockIdx.x) * w + c) * NP);
-      dst[threadIdx.x] = s;
-    }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (threadIdx.x < nc * NP * 2) {
+    const u32 c = threadIdx.x / (NP * 2), j = threadIdx.x % (NP * 2);
+    u64 s = gl_add(gl_add(sh[0][c][j], sh[1][c][j]), gl_add(sh[2][c][j], sh[3][c][j]));
+    u64* dst = reinterpret_cast<u64*>(partial + (size_t(blockIdx.x) * w + c0 + c) * NP);
+    dst[j] = s;
   }
 }
 // one wave per output (c, p): strided sum over the blocks' partials, then a wave reduction
@@ -126,20 +132,23 @@ struct DeepParams {
   const DeepMat* mats;
   u32 nmats;
   const E2* apow;
-  const E2* const* den;
+  DeepPoints pts;
   E2* ro;
   size_t height;
-  int accumulate;
 };
+// ro[i] = sum_q den_q[i] * (K_q - sum_m coeff_{m,q} * s_m[i]),  s_m[i] = sum_c alpha^c m[i][c]
+// (= sum over matrices and points of coeff * (red_z - s_m[i]) / (z_q - x_i), regrouped by point so that the
+// extension-field products with the inverse denominators happen once per point, not once per matrix and point;
+// the products with the constant coeff go through the lazy accumulators like the column sums)
 __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
   // two consecutive rows per thread: every column access is one 16-byte load
   const size_t i = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * 2;
   if (i >= p.height) return;
-  E2 acc0 = e2(0), acc1 = e2(0);
-  if (p.accumulate) {
-    acc0 = p.ro[i];
-    acc1 = p.ro[i + 1];
-  }
+  GlAcc T[2][4];  // [point][row * 2 + coordinate]
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc_init(T[q][j]);
   for (u32 m = 0; m < p.nmats; m++) {
     const DeepMat& dm = p.mats[m];
     // sum_c alpha^c * m[i][c]: base x ext terms, accumulated unreduced (one reduction per coordinate)
@@ -151,12 +160,12 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
     const u64* __restrict__ md = dm.d + i;
     const u32 mw = dm.w;
     u32 c = 0;
-    for (; c + 4 <= mw; c += 4) {
-      ulonglong2 v[4];
+    for (; c + 8 <= mw; c += 8) {  // eight 16-byte loads in flight per lane before the first use
+      ulonglong2 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const ulonglong2*>(md + size_t(c + u) * p.height);
+      for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const ulonglong2*>(md + size_t(c + u) * p.height);
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 8; u++) {
         const E2 a = p.apow[c + u];
         acc_mad(a00, a.c0, v[u].x);
         acc_mad(a01, a.c1, v[u].x);
@@ -173,16 +182,38 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
       acc_mad(a11, a.c1, v.y);
     }
     const u64 s00 = acc_reduce(a00), s01 = acc_reduce(a01), s10 = acc_reduce(a10), s11 = acc_reduce(a11);
-    for (u32 q = 0; q < dm.npoints; q++) {
-      const E2* den = p.den[dm.inv_idx[q]];
-      E2 d0 = e2(gl_sub(dm.red_z[q].c0, s00), gl_sub(dm.red_z[q].c1, s01));
-      E2 d1 = e2(gl_sub(dm.red_z[q].c0, s10), gl_sub(dm.red_z[q].c1, s11));
-      acc0 = e2_add(acc0, e2_mul(e2_mul(dm.coeff[q], d0), den[i]));
-      acc1 = e2_add(acc1, e2_mul(e2_mul(dm.coeff[q], d1), den[i + 1]));
+    for (u32 k = 0; k < dm.npoints; k++) {
+      // (c0 + c1 X)(s0 + s1 X) = c0 s0 + 7 c1 s1 + (c0 s1 + c1 s0) X
+      const u64 c0 = dm.coeff[k].c0, c1 = dm.coeff[k].c1, c7 = dm.coeff7[k];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (dm.pt[k] == (u32)q) {  // uniform across the launch
+          acc_mad(T[q][0], c0, s00);
+          acc_mad(T[q][0], c7, s01);
+          acc_mad(T[q][1], c0, s01);
+          acc_mad(T[q][1], c1, s00);
+          acc_mad(T[q][2], c0, s10);
+          acc_mad(T[q][2], c7, s11);
+          acc_mad(T[q][3], c0, s11);
+          acc_mad(T[q][3], c1, s10);
+        }
+      }
     }
   }
-  p.ro[i] = acc0;
-  p.ro[i + 1] = acc1;
+  E2 r0 = e2(0), r1 = e2(0);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if ((u32)q < p.pts.n) {
+      const E2 K = p.pts.K[q];
+      const E2 t0 = e2(gl_sub(K.c0, acc_reduce(T[q][0])), gl_sub(K.c1, acc_reduce(T[q][1])));
+      const E2 t1 = e2(gl_sub(K.c0, acc_reduce(T[q][2])), gl_sub(K.c1, acc_reduce(T[q][3])));
+      const E2* __restrict__ den = p.pts.den[q];
+      r0 = e2_add(r0, e2_mul(t0, den[i]));
+      r1 = e2_add(r1, e2_mul(t1, den[i + 1]));
+    }
+  }
+  p.ro[i] = r0;
+  p.ro[i + 1] = r1;
 }
 
 // out[i] = (1/2 + pw) lo + (1/2 - pw) hi, pw = (beta/2) w_{2R}^{-bitrev(i)}; optional roll-in out[i] += f * in[i]
@@ -569,28 +600,31 @@ __global__ void gather_queries_k(const GatherSeg* __restrict__ segs, const u64* 
 
 }  // namespace
 
-void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out) {
+void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x) {
   if (log_h > TW_LOG) throw std::runtime_error("LDE height above 2^28 is not supported");
   size_t H = size_t(1) << log_h;
+  if (n_x > H) throw std::runtime_error("inv_denoms: weight vector longer than the domain");
   size_t threads = (H + DEN_CHUNK - 1) / DEN_CHUNK;
-  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, z, log_h, ctx.tw0, ctx.tw1, out);
+  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, z, log_h, ctx.tw0, ctx.tw1, out,
+                     xout, xout ? n_x : size_t(0));
   HIP_CHECK(hipGetLastError());
 }
 
 // launches only: raw sums sum_{i<h} col_c[i] x_i invden_p[i] into `out_dev` (w * npoints values, index c * np + p)
-void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* den0, const E2* den1, int npoints,
+void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* xden0, const E2* xden1, int npoints,
                      E2* out_dev) {
   if (npoints == 0) return;
   size_t h = size_t(1) << log_h;
   size_t nblk = (h + 256 * BARY_ROWS - 1) / (256 * BARY_ROWS);
+  size_t ngrp = (w + BARY_COLS - 1) / BARY_COLS;
+  if (ngrp > 65535) throw std::runtime_error("bary: matrix too wide");
   DBuf<E2> partial(ctx, nblk * w * npoints);  // stream-ordered reuse keeps it valid until bary_final_k has run
   hipEvent_t ev = ctx.prof_begin(K_BARY);
+  dim3 grid((unsigned)nblk, (unsigned)ngrp);
   if (npoints == 1)
-    hipLaunchKernelGGL(bary_partial_k<1>, dim3((unsigned)nblk), dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, den0, den0, ctx.tw0,
-                       ctx.tw1, partial.p);
+    hipLaunchKernelGGL(bary_partial_k<1>, grid, dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden0, partial.p);
   else
-    hipLaunchKernelGGL(bary_partial_k<2>, dim3((unsigned)nblk), dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, den0, den1, ctx.tw0,
-                       ctx.tw1, partial.p);
+    hipLaunchKernelGGL(bary_partial_k<2>, grid, dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden1, partial.p);
   size_t tot = w * npoints;
   hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, out_dev);
   ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
@@ -608,13 +642,15 @@ void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npo
   }
 }
 
-void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, size_t height, const E2* apow_dev, size_t n_alpha,
-                 const E2* const* den_dev, E2* ro, bool accumulate) {
-  (void)n_alpha;
+void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* apow_dev, E2* ro) {
+  if (pts.n > 2) throw std::runtime_error("deep_reduce: more than two opening points at one height");
+  for (auto& m : mats)
+    for (u32 k = 0; k < m.npoints; k++)
+      if (m.npoints > 2 || m.pt[k] >= pts.n) throw std::runtime_error("deep_reduce: bad point index");
   DBuf<DeepMat> dm(ctx, mats.size());
   ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
-  DeepParams p{dm.p, (u32)mats.size(), apow_dev, den_dev, ro, height, accumulate ? 1 : 0};
-  double bytes = 16.0 * height;
+  DeepParams p{dm.p, (u32)mats.size(), apow_dev, pts, ro, height};
+  double bytes = 16.0 * height * (1 + pts.n);
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);
   if (height < 2 || (height & 1)) throw std::runtime_error("deep_reduce: LDE height must be even");

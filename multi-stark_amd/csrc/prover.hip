@@ -514,10 +514,11 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         size_t k = point_index(z);
         uh[k] = std::max(uh[k], r.data->ldes[mi].h);
       }
-  std::vector<DBuf<E2>> dens(upts.size());
+  std::vector<DBuf<E2>> dens(upts.size()), xdens(upts.size());
   for (size_t k = 0; k < upts.size(); k++) {
     dens[k] = DBuf<E2>(ctx, uh[k]);
-    inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p);
+    xdens[k] = DBuf<E2>(ctx, uh[k] >> lb);  // weights of the trace-domain coset: a prefix in bit-reversed storage
+    inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p, xdens[k].p, uh[k] >> lb);
   }
 
   tr.mark("inv_denoms");
@@ -539,8 +540,8 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         auto& pts = r.points[mi];
         if (pts.empty()) continue;
         int np = (int)pts.size();
-        const E2* d0 = dens[point_index(pts[0])].p;
-        const E2* d1 = np == 2 ? dens[point_index(pts[1])].p : d0;
+        const E2* d0 = xdens[point_index(pts[0])].p;
+        const E2* d1 = np == 2 ? xdens[point_index(pts[1])].p : d0;
         bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off);
         off += np * m.w;
       }
@@ -577,15 +578,13 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
   DBuf<E2> d_apow(ctx, gw + 1);
   ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
-  std::vector<const E2*> denp(dens.size());
-  for (size_t k = 0; k < dens.size(); k++) denp[k] = dens[k].p;
-  DBuf<const E2*> d_denp(ctx, std::max<size_t>(dens.size(), 1));
-  ctx.h2d(d_denp.p, denp.data(), denp.size() * sizeof(E2*));
-
-  // reduced openings per LDE height
+  // reduced openings per LDE height; the opening points of one height are numbered locally (at most two)
   std::vector<size_t> num_reduced(33, 0);
   std::vector<std::vector<DeepMat>> lists(33);
+  std::vector<DeepPoints> hpts(33);
+  std::vector<std::vector<size_t>> hpt_global(33);
   std::vector<char> present(33, 0);
+  for (auto& hp : hpts) memset(&hp, 0, sizeof(hp));
   for (size_t ri = 0; ri < rounds.size(); ri++) {
     auto& r = rounds[ri];
     for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
@@ -600,12 +599,24 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       dm.w = (uint32_t)m.w;
       dm.npoints = (uint32_t)pts.size();
       for (size_t pi = 0; pi < pts.size(); pi++) {
-        dm.coeff[pi] = e2_pow(alpha, num_reduced[lh]);
+        const size_t gk = point_index(pts[pi]);
+        size_t local = 0;
+        while (local < hpt_global[lh].size() && hpt_global[lh][local] != gk) local++;
+        if (local == hpt_global[lh].size()) {
+          if (local == 2) throw std::runtime_error("pcs_open: more than two opening points at one LDE height");
+          hpt_global[lh].push_back(gk);
+          hpts[lh].den[local] = dens[gk].p;
+          hpts[lh].K[local] = e2(0);
+          hpts[lh].n = (uint32_t)(local + 1);
+        }
+        const E2 coeff = e2_pow(alpha, num_reduced[lh]);
         E2 rz = e2(0);
         const std::vector<E2>& ys = opened[ri][mi][pi];
         for (size_t c = 0; c < m.w; c++) rz = e2_add(rz, e2_mul(apow[c], ys[c]));
-        dm.red_z[pi] = rz;
-        dm.inv_idx[pi] = (uint32_t)point_index(pts[pi]);
+        dm.pt[pi] = (uint32_t)local;
+        dm.coeff[pi] = coeff;
+        dm.coeff7[pi] = gl_mul(coeff.c1, GL_EXT_W);
+        hpts[lh].K[local] = e2_add(hpts[lh].K[local], e2_mul(coeff, rz));
         num_reduced[lh] += m.w;
       }
       lists[lh].push_back(dm);
@@ -619,10 +630,11 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     if (lists[lh].empty())
       HIP_CHECK(hipMemsetAsync(ro.p, 0, h * sizeof(E2), ctx.stream));
     else
-      deep_reduce(ctx, lists[lh], h, d_apow.p, gw + 1, d_denp.p, ro.p, false);
+      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p);
     inputs.push_back(std::move(ro));
   }
   for (auto& d : dens) d.reset();
+  for (auto& d : xdens) d.reset();
   tr.mark("deep_reduce");
 
   // ---- FRI commit phase (prove_fri / commit_phase)
