@@ -318,6 +318,33 @@ GL_HD E2 e2_sqr(E2 a) {
   return e2(gl_add(v0, gl_mul_small(v1, (u32)GL_EXT_W)), gl_add(m, m));
 }
 GL_HD E2 e2_mul_base(E2 a, u64 b) { return e2(gl_mul(a.c0, b), gl_mul(a.c1, b)); }
+// In-place inverses of a[0 .. count) (count <= K, all non-zero) with ONE base-field inversion: 1/a = conj(a) / N(a),
+// N(a) = a0^2 - 7 a1^2 in the base field, and the norms are inverted together by Montgomery's trick. Per element
+// that is 7 base multiplications and 8-byte prefix products, against 3 extension multiplications (about 10 base
+// ones) and 16-byte prefixes for the same trick done in the extension field.
+template <int K>
+GL_HD void e2_batch_inverse(E2 (&a)[K], int count) {
+  u64 nrm[K], pre[K];
+  u64 acc = 1;
+#pragma unroll
+  for (int t = 0; t < K; t++) {
+    if (t < count) {
+      nrm[t] = gl_sub(gl_sqr(a[t].c0), gl_mul_small(gl_sqr(a[t].c1), (u32)GL_EXT_W));
+      pre[t] = acc;
+      acc = gl_mul(acc, nrm[t]);
+    }
+  }
+  u64 inv = gl_inv(acc);
+#pragma unroll
+  for (int t = K - 1; t >= 0; t--) {
+    if (t < count) {
+      const u64 ni = gl_mul(inv, pre[t]);
+      inv = gl_mul(inv, nrm[t]);
+      a[t] = e2(gl_mul(a[t].c0, ni), gl_mul(gl_neg(a[t].c1), ni));
+    }
+  }
+}
+
 GL_HD E2 e2_inv(E2 a) {
   u64 norm = gl_sub(gl_sqr(a.c0), gl_mul_small(gl_sqr(a.c1), (u32)GL_EXT_W));
   u64 ni = gl_inv(norm);

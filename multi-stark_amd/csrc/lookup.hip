@@ -8,8 +8,8 @@ namespace msamd {
 
 namespace {
 
-constexpr int INV_CHUNK = 8;    // Montgomery batch size per thread (one Ext2 inversion per chunk; 16 spills to scratch)
-constexpr int CLAIMS_CHUNK = 8;
+constexpr int INV_CHUNK = 16;   // messages inverted together per thread (one base-field inversion, see e2_batch_inverse)
+constexpr int CLAIMS_CHUNK = 16;
 constexpr int MAX_GPOW = 64;    // gamma powers kept in a kernel argument; longer argument lists fall back to Horner
 
 struct GammaPows {
@@ -44,27 +44,14 @@ template <class F>
 __device__ __forceinline__ void for_each_inverse(const u64* __restrict__ args_row, const u32* __restrict__ offs, u32 L, E2 beta,
                                                  E2 gamma, const GammaPows& gp, F&& f) {
   for (u32 j0 = 0; j0 < L; j0 += INV_CHUNK) {
-    E2 msg[INV_CHUNK], pre[INV_CHUNK];
-    E2 acc = e2(1);
+    E2 msg[INV_CHUNK];
+    const int cnt = (int)(L - j0 < (u32)INV_CHUNK ? L - j0 : (u32)INV_CHUNK);
 #pragma unroll
     for (int t = 0; t < INV_CHUNK; t++) {
       u32 j = j0 + t;
-      if (j < L) {
-        msg[t] = message(args_row + offs[j], offs[j + 1] - offs[j], beta, gamma, gp);
-        pre[t] = acc;
-        acc = e2_mul(acc, msg[t]);
-      }
+      if (j < L) msg[t] = message(args_row + offs[j], offs[j + 1] - offs[j], beta, gamma, gp);
     }
-    E2 inv = e2_inv(acc);
-#pragma unroll
-    for (int t = INV_CHUNK - 1; t >= 0; t--) {
-      u32 j = j0 + t;
-      if (j < L) {
-        E2 mi = e2_mul(inv, pre[t]);
-        inv = e2_mul(inv, msg[t]);
-        msg[t] = mi;  // now the inverse
-      }
-    }
+    e2_batch_inverse<INV_CHUNK>(msg, cnt);
 #pragma unroll
     for (int t = 0; t < INV_CHUNK; t++) {
       u32 j = j0 + t;
@@ -170,28 +157,23 @@ __global__ __launch_bounds__(256) void scan_add_k(E2* __restrict__ out, size_t n
 __global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n, E2 beta,
                                                     E2 gamma, GammaPows gp, E2* __restrict__ partial) {
   __shared__ E2 sh[256];
-  size_t base = (blockIdx.x * size_t(256) + threadIdx.x) * CLAIMS_CHUNK;
-  E2 msg[CLAIMS_CHUNK], pre[CLAIMS_CHUNK];
-  E2 acc = e2(1), sum = e2(0);
+  const size_t base = blockIdx.x * size_t(256 * CLAIMS_CHUNK) + threadIdx.x;  // claim t of this thread: base + t * 256
+  E2 msg[CLAIMS_CHUNK];
+  E2 sum = e2(0);
+  int cnt = 0;
 #pragma unroll
   for (int t = 0; t < CLAIMS_CHUNK; t++) {
-    size_t i = base + t;
+    size_t i = base + size_t(t) * 256;
     if (i < n) {
       msg[t] = message(data + offs[i], (u32)(offs[i + 1] - offs[i]), beta, gamma, gp);
-      pre[t] = acc;
-      acc = e2_mul(acc, msg[t]);
+      cnt = t + 1;
     }
   }
-  if (base < n) {
-    E2 inv = e2_inv(acc);
+  if (cnt) {
+    e2_batch_inverse<CLAIMS_CHUNK>(msg, cnt);
 #pragma unroll
-    for (int t = CLAIMS_CHUNK - 1; t >= 0; t--) {
-      size_t i = base + t;
-      if (i < n) {
-        sum = e2_add(sum, e2_mul(inv, pre[t]));
-        inv = e2_mul(inv, msg[t]);
-      }
-    }
+    for (int t = 0; t < CLAIMS_CHUNK; t++)
+      if (t < cnt) sum = e2_add(sum, msg[t]);
   }
   sh[threadIdx.x] = sum;
   __syncthreads();

@@ -17,35 +17,34 @@ __device__ __forceinline__ u64 coset_point(const u64* __restrict__ t0, const u64
   return gl_mul_small(gl_mul(t1[e >> TW_HALF], t0[e & ((1u << TW_HALF) - 1)]), 7);
 }
 
-constexpr int DEN_CHUNK = 8;
+constexpr int DEN_CHUNK = 16;
 // out[i] = 1 / (z - x_i) for i < H; xout[i] = x_i / (z - x_i) for i < n_x (the barycentric weights: only the
 // first H / blowup storage rows, i.e. the trace-domain coset, are ever used there)
 __global__ __launch_bounds__(256) void inv_denoms_k(E2 z, unsigned log_h, const u64* __restrict__ t0, const u64* __restrict__ t1,
                                                     E2* __restrict__ out, E2* __restrict__ xout, size_t n_x) {
   const size_t H = size_t(1) << log_h;
-  size_t base = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * DEN_CHUNK;
+  // element k of this thread is base + k * 256: lanes touch consecutive elements, so every store is coalesced
+  const size_t base = blockIdx.x * size_t(256 * DEN_CHUNK) + threadIdx.x;
   if (base >= H) return;
-  E2 d[DEN_CHUNK], pre[DEN_CHUNK];
+  E2 d[DEN_CHUNK];
   u64 x[DEN_CHUNK];
-  E2 acc = e2(1);
+  int cnt = 0;
 #pragma unroll
   for (int k = 0; k < DEN_CHUNK; k++) {
-    if (base + k < H) {
-      x[k] = coset_point(t0, t1, (u32)(base + k), log_h);
+    const size_t i = base + size_t(k) * 256;
+    if (i < H) {
+      x[k] = coset_point(t0, t1, (u32)i, log_h);
       d[k] = e2(gl_sub(z.c0, x[k]), z.c1);
-      pre[k] = acc;
-      acc = e2_mul(acc, d[k]);
+      cnt = k + 1;
     }
   }
-  E2 inv = e2_inv(acc);
-  const bool want_x = base < n_x;  // n_x is a multiple of the chunk or smaller than one (then guarded per element)
+  e2_batch_inverse<DEN_CHUNK>(d, cnt);
 #pragma unroll
-  for (int k = DEN_CHUNK - 1; k >= 0; k--) {
-    if (base + k < H) {
-      const E2 r = e2_mul(inv, pre[k]);
-      out[base + k] = r;
-      if (want_x && base + k < n_x) xout[base + k] = e2_mul_base(r, x[k]);
-      inv = e2_mul(inv, d[k]);
+  for (int k = 0; k < DEN_CHUNK; k++) {
+    const size_t i = base + size_t(k) * 256;
+    if (k < cnt) {
+      out[i] = d[k];
+      if (i < n_x) xout[i] = e2_mul_base(d[k], x[k]);
     }
   }
 }
@@ -604,8 +603,8 @@ void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x) {
   if (log_h > TW_LOG) throw std::runtime_error("LDE height above 2^28 is not supported");
   size_t H = size_t(1) << log_h;
   if (n_x > H) throw std::runtime_error("inv_denoms: weight vector longer than the domain");
-  size_t threads = (H + DEN_CHUNK - 1) / DEN_CHUNK;
-  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, z, log_h, ctx.tw0, ctx.tw1, out,
+  size_t blocks = (H + 256 * DEN_CHUNK - 1) / (256 * DEN_CHUNK);
+  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)blocks), dim3(256), 0, ctx.stream, z, log_h, ctx.tw0, ctx.tw1, out,
                      xout, xout ? n_x : size_t(0));
   HIP_CHECK(hipGetLastError());
 }
