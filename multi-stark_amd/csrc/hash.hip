@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "b3_dev.h"
+#include "b3_quad.h"
 #include "challenge_dev.h"
 #include "msamd.h"
 
@@ -246,49 +247,12 @@ __global__ __launch_bounds__(1024) void compress3_lds_k(const Digest* __restrict
   }
 }
 
-// every remaining level of a tree whose current layer has len <= 1024 digests (no injection), one workgroup
-__global__ __launch_bounds__(256) void tree_tail_k(Digest* __restrict__ layer, u32 len) {
-  __shared__ __attribute__((aligned(16))) u32 sh[1024 * 8];
-  const u32 t = threadIdx.x;
-  for (u32 i = t; i < len; i += 256) {
-    u32 d[8];
-    load_digest(layer + i, d);
-    lds_store_digest(sh, i, d);
-  }
-  __syncthreads();
-  Digest* out = layer + len;
-  for (u32 n = len >> 1; n >= 1; n >>= 1) {
-    u32 d0[8], d1[8];
-    const bool h0 = t < n, h1 = t + 256 < n;
-    if (h0) {
-      u32 l[8], r[8];
-      lds_load_digest(sh, 2 * t, l);
-      lds_load_digest(sh, 2 * t + 1, r);
-      b3_compress_pair_root(l, r, d0);
-    }
-    if (h1) {
-      u32 l[8], r[8];
-      lds_load_digest(sh, 2 * (t + 256), l);
-      lds_load_digest(sh, 2 * (t + 256) + 1, r);
-      b3_compress_pair_root(l, r, d1);
-    }
-    __syncthreads();
-    if (h0) {
-      lds_store_digest(sh, t, d0);
-      store_digest(out + t, d0);
-    }
-    if (h1) {
-      lds_store_digest(sh, t + 256, d1);
-      store_digest(out + t + 256, d1);
-    }
-    __syncthreads();
-    out += n;
-  }
-}
-
-// tree_tail_k for an FRI commit-phase tree, followed in the same launch by that round's challenger step: the root is
-// observed, the proof-of-work witness searched and beta sampled without the commitment leaving the device
-__global__ __launch_bounds__(1024) void tree_tail_challenge_k(Digest* __restrict__ layer, u32 len, FriChallenge fc) {
+// every remaining level of a tree whose current layer has len <= 1024 digests (no injection), one workgroup.
+// The levels are a chain of dependent compressions with ever fewer nodes, so each node is computed by a quad
+// (b3_quad.h): 256 nodes per pass of the 1024 threads. With CH the launch continues with that FRI round's
+// challenger step: the root is observed, the proof-of-work witness searched and beta sampled on the device.
+template <bool CH>
+__global__ __launch_bounds__(1024) void tree_tail_k(Digest* __restrict__ layer, u32 len, FriChallenge fc) {
   __shared__ __attribute__((aligned(16))) u32 sh[1024 * 8];
   __shared__ ChallengeShared cs;
   const u32 t = threadIdx.x;
@@ -297,33 +261,41 @@ __global__ __launch_bounds__(1024) void tree_tail_challenge_k(Digest* __restrict
     load_digest(layer + t, d);
     lds_store_digest(sh, t, d);
   }
-  if (t < 8) cs.st[t] = fc.state[t];
+  if (CH && t < 8) cs.st[t] = fc.state[t];
   __syncthreads();
-  Digest* out = layer + len;
+  u32* out = reinterpret_cast<u32*>(layer + len);
+  const u32 quad = t >> 2, c = t & 3;
   for (u32 n = len >> 1; n >= 1; n >>= 1) {
-    u32 d[8];
-    if (t < n) {
-      u32 l[8], r[8];
-      lds_load_digest(sh, 2 * t, l);
-      lds_load_digest(sh, 2 * t + 1, r);
-      b3_compress_pair_root(l, r, d);
+    u32 lo[2], hi[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const u32 q = quad + 256 * p;
+      if (q < n) b3_quad_parent(sh + 16 * q, lo[p], hi[p]);
     }
     __syncthreads();
-    if (t < n) {
-      lds_store_digest(sh, t, d);
-      store_digest(out + t, d);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const u32 q = quad + 256 * p;
+      if (q < n) {
+        sh[8 * q + c] = lo[p];
+        sh[8 * q + 4 + c] = hi[p];
+        out[8 * q + c] = lo[p];
+        out[8 * q + 4 + c] = hi[p];
+      }
     }
     __syncthreads();
-    out += n;
+    out += 8 * n;
   }
-  challenger_round<1024>(cs, sh, fc.pow_bits);
-  if (t < 8) {
-    fc.state[t] = cs.st[t];
-    fc.rec->root[t] = sh[t];
-  }
-  if (t == 0) {
-    fc.rec->witness = cs.wit;
-    fc.rec->beta = cs.beta;
+  if (CH) {
+    challenger_round<1024>(cs, sh, fc.pow_bits);
+    if (t < 8) {
+      fc.state[t] = cs.st[t];
+      fc.rec->root[t] = sh[t];
+    }
+    if (t == 0) {
+      fc.rec->witness = cs.wit;
+      fc.rec->beta = cs.beta;
+    }
   }
 }
 
@@ -439,9 +411,9 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
       const KernelId kid = fc ? K_OTHER : K_COMPRESS;  // the challenger step's grinding is not tree work
       hipEvent_t ev = ctx.prof_begin(kid);
       if (fc)
-        hipLaunchKernelGGL(tree_tail_challenge_k, dim3(1), dim3(1024), 0, ctx.stream, child, (u32)child_len, *fc);
+        hipLaunchKernelGGL(tree_tail_k<true>, dim3(1), dim3(1024), 0, ctx.stream, child, (u32)child_len, *fc);
       else
-        hipLaunchKernelGGL(tree_tail_k, dim3(1), dim3(256), 0, ctx.stream, child, (u32)child_len);
+        hipLaunchKernelGGL(tree_tail_k<false>, dim3(1), dim3(1024), 0, ctx.stream, child, (u32)child_len, FriChallenge{});
       ctx.prof_end(kid, ev, 96.0 * double(child_len));
       fc = nullptr;
       break;
@@ -476,7 +448,7 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
     li++;
   }
   if (fc && L == 1) {  // a single leaf is its own root
-    hipLaunchKernelGGL(tree_tail_challenge_k, dim3(1), dim3(1024), 0, ctx.stream, t.base(), 1u, *fc);
+    hipLaunchKernelGGL(tree_tail_k<true>, dim3(1), dim3(1024), 0, ctx.stream, t.base(), 1u, *fc);
     fc = nullptr;
   }
   if (fc) throw std::runtime_error("build_levels: the tree never reached the single-workgroup tail");

@@ -4,6 +4,7 @@
 // (rounds built at :540-579): interpolate_coset, the reduced-opening pass, prover::commit_phase fold_matrix,
 // and mmcs.open_batch for the queries. The transcript itself stays on the host (prover.hip).
 #include "b3_dev.h"
+#include "b3_quad.h"
 #include "challenge_dev.h"
 #include "msamd.h"
 
@@ -404,56 +405,52 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
   for (u32 r = 0; r < p.n_rounds; r++) {
     const u32 rows = len >> 1;
     const unsigned log_rows = 31 - __clz(rows);
-    // ---- leaf digests (ExtensionMmcs rows of two Ext2 values = 32 bytes)
-    if (t < rows) {
-      E2 lo = cur[2 * t], hi = cur[2 * t + 1];
-      u32 m[16];
-      m[0] = (u32)lo.c0;
-      m[1] = (u32)(lo.c0 >> 32);
-      m[2] = (u32)lo.c1;
-      m[3] = (u32)(lo.c1 >> 32);
-      m[4] = (u32)hi.c0;
-      m[5] = (u32)(hi.c0 >> 32);
-      m[6] = (u32)hi.c1;
-      m[7] = (u32)(hi.c1 >> 32);
+    // ---- leaf digests (ExtensionMmcs rows of two Ext2 values = 32 bytes) and tree levels, one node per quad
+    // (b3_quad.h): the whole round is a chain of dependent compressions over at most 1024 nodes
+    const u32 quad = t >> 2, qc = t & 3;
+    u32* gout = reinterpret_cast<u32*>(tout);
+    {
+      u32 lo[4], hi[4];
 #pragma unroll
-      for (int k = 8; k < 16; k++) m[k] = 0;
-      u32 cv[8];
-      b3_iv(cv);
-      b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-      uint4* q = reinterpret_cast<uint4*>(tree + t * 8);
-      q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-      q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-      uint4* g = reinterpret_cast<uint4*>(tout + t);
-      g[0] = q[0];
-      g[1] = q[1];
+      for (int ps = 0; ps < 4; ps++) {
+        const u32 q = quad + 256 * ps;
+        if (q < rows) b3_quad_row32(reinterpret_cast<const u32*>(&cur[2 * q]), lo[ps], hi[ps]);
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ps++) {
+        const u32 q = quad + 256 * ps;
+        if (q < rows) {
+          tree[8 * q + qc] = lo[ps];
+          tree[8 * q + 4 + qc] = hi[ps];
+          gout[8 * q + qc] = lo[ps];
+          gout[8 * q + 4 + qc] = hi[ps];
+        }
+      }
     }
     __syncthreads();
-    tout += rows;
-    // ---- tree levels
+    gout += 8 * rows;
     for (u32 n = rows >> 1; n >= 1; n >>= 1) {
-      u32 d[8];
-      if (t < n) {
-        u32 m[16];
-        const uint4* q = reinterpret_cast<const uint4*>(tree + 2 * t * 8);
-        uint4 a = q[0], b = q[1], c = q[2], e = q[3];
-        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
-        m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = e.x; m[13] = e.y; m[14] = e.z; m[15] = e.w;
-        b3_iv(d);
-        b3_compress(d, m, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      u32 lo[2], hi[2];
+#pragma unroll
+      for (int ps = 0; ps < 2; ps++) {
+        const u32 q = quad + 256 * ps;
+        if (q < n) b3_quad_parent(tree + 16 * q, lo[ps], hi[ps]);
       }
       __syncthreads();
-      if (t < n) {
-        uint4* q = reinterpret_cast<uint4*>(tree + t * 8);
-        q[0] = make_uint4(d[0], d[1], d[2], d[3]);
-        q[1] = make_uint4(d[4], d[5], d[6], d[7]);
-        uint4* g = reinterpret_cast<uint4*>(tout + t);
-        g[0] = q[0];
-        g[1] = q[1];
+#pragma unroll
+      for (int ps = 0; ps < 2; ps++) {
+        const u32 q = quad + 256 * ps;
+        if (q < n) {
+          tree[8 * q + qc] = lo[ps];
+          tree[8 * q + 4 + qc] = hi[ps];
+          gout[8 * q + qc] = lo[ps];
+          gout[8 * q + 4 + qc] = hi[ps];
+        }
       }
       __syncthreads();
-      tout += n;
+      gout += 8 * n;
     }
+    tout = reinterpret_cast<Digest*>(gout);
     // ---- challenger: observe the root, grind, sample beta
     challenger_round<1024>(cs, tree, p.pow_bits);
     if (t == 0) {
