@@ -188,18 +188,34 @@ __device__ __forceinline__ void lds_load_digest(const u32* sh, u32 idx, u32 cv[8
   cv[7] = b.w;
 }
 
-// three levels per launch, entirely in registers: thread i turns children [8i, 8i+8) into 4 + 2 + 1 ancestors
-// (no LDS, no barrier: full occupancy; the 256-byte child run of a lane stays in L1 across its 16 loads)
+// three levels per launch: thread i turns children [8i, 8i+8) into 4 + 2 + 1 ancestors in registers (no idle
+// lanes at any level). Its 256 bytes of children are fetched by the whole wave with coalesced 16-byte loads and
+// handed over through LDS (lane stride 272 bytes against bank conflicts): a lane reading its own run directly would
+// touch 64 cache lines per load instruction and depend on L1 keeping them for its next 15 loads.
 __global__ __launch_bounds__(256) void compress3_k(const Digest* __restrict__ child, Digest* __restrict__ l1, Digest* __restrict__ l2,
                                                    Digest* __restrict__ l3, size_t n3) {
-  const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (i >= n3) return;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][64 * 272];
+  const size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // n3 is a multiple of 256 (host-checked)
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(child + (i - lane) * 8);  // the wave's 512 digests
+    uint4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = src[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 piece = k * 64 + lane;  // 16-byte piece index within the wave's block
+      *reinterpret_cast<uint4*>(&stage[wave][(piece >> 4) * 272 + (piece & 15) * 16]) = v[k];
+    }
+  }
+  __syncthreads();
+  const uint4* mine = reinterpret_cast<const uint4*>(&stage[wave][lane * 272]);
   u32 a[4][8];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    u32 l[8], r[8];
-    load_digest(child + 8 * i + 2 * k, l);
-    load_digest(child + 8 * i + 2 * k + 1, r);
+    const uint4 p0 = mine[4 * k], p1 = mine[4 * k + 1], p2 = mine[4 * k + 2], p3 = mine[4 * k + 3];
+    const u32 l[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const u32 r[8] = {p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
     b3_compress_pair_root(l, r, a[k]);
     store_digest(l1 + 4 * i + k, a[k]);
   }
@@ -421,7 +437,7 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
     if (child_len >= 2048 && li + 2 < L && !inj[li].count && !inj[li + 1].count && !inj[li + 2].count) {
       hipEvent_t ev = ctx.prof_begin(K_COMPRESS);
       const size_t n3 = child_len / 8;
-      if (n3 >= (size_t(1) << 17))  // throughput-bound: registers only; below that the dependent chain is what costs
+      if (n3 >= (size_t(1) << 17) && n3 % 256 == 0)  // throughput-bound; below that the dependent chain is what costs
         hipLaunchKernelGGL(compress3_k, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, ctx.stream, (const Digest*)child,
                            t.base() + t.layer_off[li], t.base() + t.layer_off[li + 1], t.base() + t.layer_off[li + 2], n3);
       else
