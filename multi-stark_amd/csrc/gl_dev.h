@@ -170,9 +170,46 @@ __device__ __forceinline__ void gl_mul_wide(u64 a, u64 b, u32& l0, u32& l1, u32&
 
 GL_HD u64 gl_mul(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u32 l0, l1, h0, h1;
-  gl_mul_wide(a, b, l0, l1, h0, h1);
-  return gl_reduce_limbs(gl_pack(l0, l1), h0, h1);
+  // the four partial products, then limb sums and the reduction as ONE asm statement: the compiler pads every asm
+  // boundary with an s_nop (it cannot see which hazards a block leaves open), so fewer, longer blocks are cheaper
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p00, p01, p10, p11;
+  asm("v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+      "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+      "v_mad_u64_u32 %2, vcc, %5, %6, 0\n\t"
+      "v_mad_u64_u32 %3, vcc, %5, %7, 0"
+      : "=&v"(p00), "=&v"(p01), "=&v"(p10), "=&v"(p11)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "vcc");
+  u32 p00l = (u32)p00, p00h = (u32)(p00 >> 32), p01l = (u32)p01, p01h = (u32)(p01 >> 32);
+  u32 p10l = (u32)p10, p10h = (u32)(p10 >> 32), p11l = (u32)p11, p11h = (u32)(p11 >> 32);
+  u32 r0, r1, m, t0, t1, h0, h1;
+  asm("v_add_co_u32 %3, vcc, %8, %9\n\t"          // l1 = p00h + p01l
+      "v_addc_co_u32 %5, vcc, %10, %12, vcc\n\t"  // h0 = p01h + p10h + c
+      "v_addc_co_u32 %6, vcc, 0, %14, vcc\n\t"    // h1 = p11h + c
+      "v_add_co_u32 %3, vcc, %3, %11\n\t"         // l1 += p10l
+      "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"   // h0 += p11l + c
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"     // h1 += c
+      "v_sub_co_u32 %0, vcc, 0, %5\n\t"           // u = (h0 << 32) - h0
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %7, %0\n\t"          // A = (l1:l0) + u
+      "v_addc_co_u32 %1, vcc, %3, %1, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %6\n\t"          // C = A - h1
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_add_co_u32 %3, vcc, -1, %0\n\t"          // C >= p  <=>  C + (2^32 - 1) carries out
+      "v_addc_co_u32 %4, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %3, %0, %3, vcc\n\t"
+      "v_cndmask_b32 %4, %1, %4, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(m), "=&v"(t0), "=&v"(t1), "=&v"(h0), "=&v"(h1)
+      : "v"(p00l), "v"(p00h), "v"(p01l), "v"(p01h), "v"(p10l), "v"(p10h), "v"(p11l), "v"(p11h)
+      : "vcc");
+  return gl_pack(t0, t1);
 #else
   unsigned __int128 x = (unsigned __int128)a * b;
   return gl_reduce128((u64)x, (u64)(x >> 64));
