@@ -53,6 +53,8 @@ def main():
     if world != args.gpus and world > 1:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     n_gpus = world if world > 1 else 1
+    # rehearsal of the collective path with a single rank (RCCL initialises and gathers with world size 1)
+    force_dist = world == 1 and bool(os.environ.get("MSAMD_BENCH_FORCE_DIST")) and "RANK" in os.environ
 
     torch = None
     dist = None
@@ -61,10 +63,10 @@ def main():
 
         torch = _torch
     except Exception as e:  # torch is plumbing only (barrier/synchronize); never needed for the proof itself
-        if n_gpus > 1:
+        if n_gpus > 1 or force_dist:
             raise
         log("torch unavailable (%s): using the library's own stream synchronisation" % e)
-    if n_gpus > 1:
+    if n_gpus > 1 or force_dist:
         import torch.distributed as _dist
 
         dist = _dist
@@ -87,7 +89,7 @@ def main():
     # per-rank seeds; rank 0 is exactly the reference's bench witness
     a0, b0 = (0xDEADBEEF, 0xCAFEBABE)
     mgpu = None
-    if n_gpus > 1:
+    if n_gpus > 1 or force_dist:
         import importlib
 
         mgpu = importlib.import_module("multi_stark_amd.distributed")
@@ -99,8 +101,13 @@ def main():
     rows_per_proof = witness.rows
     log("[rank %d] witness ready in %.1fs: %d rows/proof" % (rank, time.time() - t, rows_per_proof))
 
+    gatherer = None
+    digests = []
+
     def sync_all():
         ctx.sync()
+        if gatherer is not None:
+            gatherer.finish()  # every submitted commitment set has been gathered and digested
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
@@ -108,12 +115,16 @@ def main():
             torch.cuda.synchronize()
 
     def step():
+        # the commitments of proof k are gathered by a worker thread while proof k + 1 runs (CommitmentGatherer);
+        # sync_all() waits for all of them, so the timed region contains every collective it started
+        nonlocal gatherer
         proof = system.prove_multiple_claims(witness)
         if dist is not None:
-            allc = mgpu.gather_commitments(mgpu.commitments_of(proof.to_bytes(), 2),
-                                           torch.device("cuda", local_rank) if args.backend == "nccl" else None)
-            if rank == 0:
-                mgpu.joint_digest(allc)
+            blob = mgpu.commitments_of(proof.to_bytes(), 2)
+            if gatherer is None:
+                gatherer = mgpu.CommitmentGatherer(len(blob), torch.device("cuda", local_rank) if args.backend == "nccl" else None,
+                                                   on_gathered=lambda allc: digests.append(mgpu.joint_digest(allc)))
+            gatherer.submit(blob)
         return proof
 
     # ---- warmup (untimed); the first warmup step is profiled per kernel class to pick the dominant kernel
@@ -202,6 +213,10 @@ def main():
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             result["cpu_baseline"] = cpu_baseline(fe, system.blob, args.cpu_log_adds)
+    if gatherer is not None:
+        gatherer.close()
+        if rank == 0:
+            log("gathered and digested %d commitment sets; last joint digest %s" % (len(digests), digests[-1].hex() if digests else "-"))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

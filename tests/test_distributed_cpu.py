@@ -36,6 +36,14 @@ def _worker(rank, world, port, q):
         mine = mgpu.commitments_of(proof, 2)
         allc = mgpu.gather_commitments(mine)
         assert len(allc) == world and allc[rank] == mine and all(len(c) == 96 for c in allc)
+        # the off-thread gatherer bench.py uses: submissions are gathered in order, finish() waits for all of them
+        g = mgpu.CommitmentGatherer(len(mine))
+        second = bytes(reversed(mine))
+        g.submit(mine)
+        g.submit(second)
+        got = g.finish()
+        assert got[0] == allc and got[1][rank] == second and g.finish() == []
+        g.close()
         q.put((rank, mine.hex(), mgpu.joint_digest(allc).hex()))
     finally:
         dist.barrier()
