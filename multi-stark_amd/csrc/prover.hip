@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <functional>
+
 #include "host.h"
 
 namespace msamd {
@@ -483,6 +485,28 @@ u64 grind(Ctx& ctx, Challenger& ch, unsigned bits) {
   return ch.grind(bits);
 }
 
+// shape of the input rounds' openings inside one query: per round the matrix widths and the number of siblings
+struct InputShape {
+  std::vector<std::vector<size_t>> widths;
+  std::vector<size_t> nsib;
+};
+typedef std::function<void(const std::vector<uint64_t>& indices, size_t qbytes, uint8_t* out)> InputGather;
+void add_gather_seg(std::vector<GatherSeg>& segs, size_t& out_off, const void* base, u64 stride, uint32_t count, uint32_t kind,
+                    uint32_t shift, uint32_t flip) {
+  GatherSeg q;
+  q.base = base;
+  q.stride = stride;
+  q.count = count;
+  q.kind = kind;
+  q.shift = shift;
+  q.flip = flip;
+  q.out_off = out_off;
+  segs.push_back(q);
+  out_off += kind == 0 ? size_t(count) * 8 : kind == 1 ? 32 : 16;
+}
+void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
+               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr);
+
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
 void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes) {
   Ctx& ctx = *sys.ctx;
@@ -637,6 +661,37 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   for (auto& d : xdens) d.reset();
   tr.mark("deep_reduce");
 
+  // ---- query-phase segments of the input rounds (what to read for ONE query), then FRI itself
+  InputShape shape;
+  std::vector<GatherSeg> segs;
+  size_t out_off = 0;
+  for (auto& r : rounds) {
+    const DTree& t = r.data->tree;
+    const unsigned lmh = log2_strict(t.max_height());
+    const unsigned sh0 = log_gmax - lmh;
+    std::vector<size_t> widths;
+    for (auto& m : r.data->ldes) {
+      add_gather_seg(segs, out_off, m.d(), m.h, (uint32_t)m.w, 0, sh0 + (lmh - log2_strict(m.h)), 0);
+      widths.push_back(m.w);
+    }
+    for (size_t i = 0; i < t.cap_layer(); i++) add_gather_seg(segs, out_off, t.base() + t.layer_off[i], 0, 1, 1, sh0 + (unsigned)i, 1);
+    shape.widths.push_back(std::move(widths));
+    shape.nsib.push_back(t.cap_layer());
+  }
+  fri_prove(sys, ch, inputs, log_gmax, segs, out_off, shape, nullptr, fri_bytes, tr);
+}
+
+// prove_fri (commit phase, final polynomial, query proof of work, query openings) over the reduced openings
+// `inputs` (descending height); serialises the FriProof into `fri_bytes`. The openings of the INPUT rounds are read
+// either by `input_segs` on this device (their per-query block of `input_qbytes` bytes laid out round by round:
+// every matrix row, then the sibling digests bottom-up) or, when the committed data is spread over ranks, by
+// `remote`, called with the sampled indices and filling the same layout.
+void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
+               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr) {
+  Ctx& ctx = *sys.ctx;
+  const Params& prm = sys.params;
+  const unsigned lb = (unsigned)prm.log_blowup;
+  (void)log_gmax;
   // ---- FRI commit phase (prove_fri / commit_phase)
   const size_t final_len = size_t(1) << prm.log_final_poly_len;
   const size_t stop = (size_t(1) << lb) * final_len;
@@ -781,31 +836,16 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   // ---- query phase, part 1: the segment list (what to read for ONE query) needs no challenge
   std::vector<GatherSeg> segs;
   size_t out_off = 0;
-  auto add_seg = [&](const void* base, u64 stride, uint32_t count, uint32_t kind, uint32_t shift, uint32_t flip) {
-    GatherSeg q;
-    q.base = base;
-    q.stride = stride;
-    q.count = count;
-    q.kind = kind;
-    q.shift = shift;
-    q.flip = flip;
-    q.out_off = out_off;
-    segs.push_back(q);
-    out_off += kind == 0 ? size_t(count) * 8 : kind == 1 ? 32 : 16;
-  };
-  auto n_siblings = [](const DTree& t) { return t.cap_layer(); };
-  for (auto& r : rounds) {
-    const DTree& t = r.data->tree;
-    const unsigned lmh = log2_strict(t.max_height());
-    const unsigned sh0 = log_gmax - lmh;
-    for (auto& m : r.data->ldes) add_seg(m.d(), m.h, (uint32_t)m.w, 0, sh0 + (lmh - log2_strict(m.h)), 0);
-    for (size_t i = 0; i < n_siblings(t); i++) add_seg(t.base() + t.layer_off[i], 0, 1, 1, sh0 + (unsigned)i, 1);
+  if (!remote) {
+    segs = input_segs;
+    out_off = input_qbytes;
   }
+  auto n_siblings = [](const DTree& t) { return t.cap_layer(); };
   for (size_t i = 0; i < trees.size(); i++) {
     // sibling value of round i sits at element (index >> i) ^ 1 of that round's vector
-    add_seg(layers[i], 0, 1, 2, (uint32_t)i, 1);
+    add_gather_seg(segs, out_off, layers[i], 0, 1, 2, (uint32_t)i, 1);
     const DTree& t = trees[i];
-    for (size_t l = 0; l < n_siblings(t); l++) add_seg(t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(i + 1 + l), 1);
+    for (size_t l = 0; l < n_siblings(t); l++) add_gather_seg(segs, out_off, t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(i + 1 + l), 1);
   }
   const size_t qbytes = out_off;
   const size_t nq = (size_t)prm.num_queries;
@@ -890,6 +930,14 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     tr.mark("query_gather");
   }
 
+  // ---- openings of the input rounds held elsewhere
+  std::vector<uint8_t> input_g;
+  if (remote) {
+    input_g.resize(input_qbytes * nq);
+    (*remote)(indices, input_qbytes, input_g.data());
+    tr.mark("remote_input_openings");
+  }
+
   // ---- FriProof bytes
   PW& w = fri_bytes;
   w.u64_(commits.size());
@@ -899,20 +947,21 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   w.u64_(indices.size());
   size_t pos = 0;
   for (size_t qi = 0; qi < indices.size(); qi++) {
-    w.u64_(rounds.size());
-    for (auto& r : rounds) {
-      const DTree& t = r.data->tree;
-      w.u64_(r.data->ldes.size());
-      for (auto& m : r.data->ldes) {
-        w.u64_(m.w);
-        w.raw(&g[pos], m.w * 8);
-        pos += m.w * 8;
+    const uint8_t* ip = remote ? &input_g[qi * input_qbytes] : &g[pos];
+    w.u64_(shape.widths.size());
+    for (size_t ri = 0; ri < shape.widths.size(); ri++) {
+      w.u64_(shape.widths[ri].size());
+      for (size_t mw : shape.widths[ri]) {
+        w.u64_(mw);
+        w.raw(ip, mw * 8);
+        ip += mw * 8;
       }
-      size_t ns = n_siblings(t);
+      const size_t ns = shape.nsib[ri];
       w.u64_(ns);
-      w.raw(&g[pos], ns * 32);
-      pos += ns * 32;
+      w.raw(ip, ns * 32);
+      ip += ns * 32;
     }
+    if (!remote) pos += input_qbytes;
     w.u64_(trees.size());
     for (size_t i = 0; i < trees.size(); i++) {
       w.u8(1);  // log_arity
