@@ -14,6 +14,7 @@
  *   ms_system_*    System::new + ProverKey                      src/system.rs:115-203 (preprocessed commit :190-195)
  *   ms_witness_*   SystemWitness / from_stage_1                 src/system.rs:225-328
  *   ms_prove       System::prove_multiple_claims                src/prover.rs:290-603
+ *   ms_prove_sharded   the same proof computed by several GPUs  src/prover.rs:290-603 (commit/open calls :350,419,526,580)
  *   ms_dft_batch   Radix2DitParallel::dft_batch                 src/prover.rs:650,716 (type fixed at :440)
  *   ms_coset_lde_batch  the LDE inside Pcs::commit              src/prover.rs:350,419; layout pinned by :975-999
  *   ms_quotient_lde     shifted_quotient_slices + lde_from_shifted_coefficients   src/prover.rs:631-717
@@ -85,6 +86,30 @@ void ms_witness_destroy(ms_witness* w);
  * the reference's span names (src/prover.rs:336-538). Returns MS_ERR_BUFFER with *proof_len = needed size if
  * cap is too small. */
 int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms);
+
+/* ---- One proof over several GPUs (one process per GPU; SURVEY §8e, BASELINE config 3). The reference has no such
+ * mode: this is System::prove_multiple_claims (src/prover.rs:290-603) with the Pcs::commit / Pcs::open calls
+ * (:350,419,526,580) spread over ranks, producing the same Proof bytes as ms_prove on one device.
+ * Every rank creates the SAME system and a witness that holds: the traces of the circuits it computes (its own
+ * "sharded" circuit and every replicated one; traces[i] = NULL with heights[i] > 0 marks a circuit computed elsewhere),
+ * the heights of all circuits, and all claims. owners[i] = rank that computes circuit i, or -1 = replicated on every
+ * rank (small tables). Exactly one sharded circuit per rank, all of one shape, the k-th of them owned by rank k; the
+ * number of ranks is a power of two.
+ * The library calls back for the two exchanges it needs; both take DEVICE pointers of this context's device, are
+ * called with the context's stream idle, and must have completed when they return (0 = ok):
+ *   all_to_all: send/recv hold `world` blocks of bytes_per_peer bytes; block k of send goes to rank k, block k of recv
+ *               comes from rank k (row ranges of the LDE matrices before leaf hashing);
+ *   all_gather: every rank contributes `bytes`, recv gets world * bytes ordered by rank (sub-tree roots, logUp totals,
+ *               opened values, reduced openings, query openings).
+ * With torch.distributed these are all_to_all_single / all_gather_into_tensor on RCCL (multi-stark_amd/sharded.py). */
+typedef struct ms_comm {
+  int32_t rank, world;
+  void* user;
+  int32_t (*all_to_all)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
+  int32_t (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes);
+} ms_comm;
+int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
+                         size_t* proof_len, double* stage_ms);
 
 /* ---- PCS-level entry points (host buffers in, host buffers out) */
 /* out[k] = sum_j in[j] w_h^{jk} per column (inverse != 0: the inverse transform incl. 1/h); natural order both sides */

@@ -43,7 +43,7 @@ def exported_symbols():
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create",
-            "ms_witness_destroy", "ms_prove", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
+            "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_stage2_trace", "ms_claims_accumulator",
             "ms_quotient_values", "ms_field_op"]
 
@@ -259,14 +259,16 @@ class System:
                 "max_constraint_degree", "quotient_degree", "args_width"]
         return dict(zip(keys, (int(x) for x in o)))
 
-    def witness(self, traces, claims_packed, lookups=None):
-        """`SystemWitness::from_stage_1` (lookups=None) or an explicit SystemWitness{traces, lookups}; uploads to HBM."""
+    def witness(self, traces, claims_packed, lookups=None, remote_heights=None):
+        """`SystemWitness::from_stage_1` (lookups=None) or an explicit SystemWitness{traces, lookups}; uploads to HBM.
+        remote_heights {circuit: height}: circuits another rank computes (prove_sharded): no trace here, height only."""
+        remote_heights = remote_heights or {}
         trs = [_u64(t) if t is not None and len(t) else np.zeros((0, 1), dtype=np.uint64) for t in traces]
         n = self.n_circuits
         if len(trs) != n:
             raise MstarkError("expected one trace per circuit")
-        tptr = (u64p * n)(*[_p(t) for t in trs])
-        hs = _u64([t.shape[0] for t in trs])
+        tptr = (u64p * n)(*[None if i in remote_heights else _p(t) for i, t in enumerate(trs)])
+        hs = _u64([remote_heights.get(i, t.shape[0]) for i, t in enumerate(trs)])
         mptr = aptr = None
         keep = []
         if lookups is not None:
@@ -300,6 +302,28 @@ class System:
             return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
 
     prove = prove_multiple_claims
+
+    def prove_sharded(self, witness, comm, owners, want_times=False):
+        """The same Proof computed by `comm.world` ranks (ms_prove_sharded; see multi-stark_amd/sharded.py for `comm`).
+        owners[i] = rank computing circuit i, -1 = replicated. Collective: every rank calls it; every rank gets the bytes."""
+        cap = getattr(self, "_proof_cap", 1 << 21)
+        times = np.zeros(6, dtype=np.float64)
+        own = np.ascontiguousarray(owners, dtype=np.int32)
+        if own.size != self.n_circuits:
+            raise MstarkError("expected one owner per circuit")
+        while True:
+            out = np.empty(cap, dtype=np.uint8)
+            n = C.c_size_t()
+            rc = lib().ms_prove_sharded(self.h, witness.h, C.byref(comm.struct), own.ctypes.data_as(C.POINTER(C.c_int32)), _b(out),
+                                        C.c_size_t(cap), C.byref(n), times.ctypes.data_as(C.POINTER(C.c_double)) if want_times else None)
+            comm.reraise()
+            if rc == -3:
+                cap = n.value
+                self._proof_cap = cap
+                continue
+            _check(rc)
+            keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]
+            return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
 
     def quotient_values(self, ci, publics8, log_n, log_q, pre_q, s1_q, s2_q, alpha):
         N = 1 << (log_n + log_q)

@@ -156,6 +156,20 @@ int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, 
   MS_CATCH
 }
 
+int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
+                         size_t* proof_len, double* stage_ms) {
+  MS_TRY StageMs st;
+  if (!comm || !owners || !comm->all_to_all || !comm->all_gather) throw std::runtime_error("ms_prove_sharded: incomplete ms_comm");
+  if (comm->rank < 0 || comm->rank >= comm->world) throw std::runtime_error("ms_prove_sharded: rank out of range");
+  std::vector<uint8_t> bytes = prove_sharded(*sys->sys, *w->w, comm, owners, stage_ms ? &st : nullptr);
+  if (stage_ms) memcpy(stage_ms, st.v, sizeof(st.v));
+  *proof_len = bytes.size();
+  if (bytes.size() > cap) return MS_ERR_BUFFER;
+  memcpy(proof_out, bytes.data(), bytes.size());
+  return MS_OK;
+  MS_CATCH
+}
+
 int32_t ms_dft_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, int32_t inverse, uint64_t* out) {
   MS_TRY Ctx& ctx = c->ctx;
   check_pow2(h);

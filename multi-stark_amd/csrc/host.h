@@ -5,6 +5,7 @@
 #include <memory>
 #include <vector>
 
+#include "../../include/mstark.h"
 #include "b3_dev.h"
 #include "msamd.h"
 #include "program.h"
@@ -91,7 +92,8 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
 struct HWitness {
   HSystem* sys = nullptr;
   std::vector<size_t> heights;
-  std::vector<DBuf<u64>> traces;  // row-major on device, as uploaded
+  std::vector<DBuf<u64>> traces;  // row-major on device, as uploaded (empty for circuits another rank computes)
+  bool has_remote = false;        // some active circuit has no trace here: only prove_sharded accepts the witness
   std::vector<DLookups> lookups;
   // claims: host copy (transcript for small inputs) and device copy
   std::vector<u64> claim_offsets, claim_data;
@@ -105,6 +107,9 @@ struct StageMs {
   double v[6] = {0, 0, 0, 0, 0, 0};
 };
 std::vector<uint8_t> prove(HSystem& sys, HWitness& w, StageMs* times);
+typedef ms_comm ms_comm_t;
+// the same proof computed by `comm->world` ranks (prover_sharded.inc)
+std::vector<uint8_t> prove_sharded(HSystem& sys, HWitness& w, const ms_comm_t* comm, const int32_t* owners, StageMs* times);
 
 void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out);
 void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out);

@@ -352,6 +352,10 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
     if (log2_strict(h) > NTT_MAX_LOG || log2_strict(h) + sys.params.log_blowup > TW_LOG)
       throw std::runtime_error("trace height exceeds the supported maximum");
     if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    if (!traces[ci]) {  // computed by another rank (ms_prove_sharded): only the height is known here
+      w->has_remote = true;
+      continue;
+    }
     size_t cnt = h * c.main_width;
     for (size_t i = 0; i < cnt; i++)
       if (traces[ci][i] >= GL_P) throw std::runtime_error("non-canonical trace value");
@@ -988,6 +992,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   const unsigned lb = (unsigned)prm.log_blowup;
   const size_t C = sys.circuits.size();
   if (wit.sys != &sys || wit.heights.size() != C) throw std::runtime_error("witness does not belong to this system");
+  if (wit.has_remote) throw std::runtime_error("this witness lacks traces that another rank computes: use ms_prove_sharded");
   double t_begin = now_ms(), t0;
   auto lap = [&](int slot) {
     if (times) {
@@ -1225,5 +1230,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   if (times) times->v[5] = now_ms() - t_begin;
   return std::move(w.b);
 }
+
+#include "prover_sharded.inc"
 
 }  // namespace msamd

@@ -1,0 +1,92 @@
+"""Transport for `System.prove_sharded` (ms_prove_sharded): the two exchanges the library asks for, on torch.distributed.
+
+`TorchComm` builds the `ms_comm` callback table of include/mstark.h. With backend "nccl" (= RCCL on ROCm) the device
+buffers the library hands over are wrapped as torch tensors in place (`__cuda_array_interface__`) and exchanged by
+`all_to_all_single` / `all_gather_into_tensor` over xGMI. With any other backend (gloo: tests and single-GPU
+rehearsals, where several ranks share one device) the buffers are staged through host memory. Torch is plumbing here:
+every byte that is exchanged was produced, and is consumed, by the library's own kernels."""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class MsComm(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB)]
+
+
+class _DevBytes:
+    """a device byte range as an object torch.as_tensor understands"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    def __init__(self, device_index=0, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device("cuda", device_index)
+        self.direct = dist.get_backend(group) == "nccl"
+        self.error = None
+        self.bytes_moved = 0
+        self._a2a = _CB(self._all_to_all)
+        self._ag = _CB(self._all_gather)
+        self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag)
+
+    def _view(self, ptr, nbytes):
+        return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException as e:  # never unwind into C
+            self.error = e
+            return -1
+
+    def reraise(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def _all_to_all(self, _user, send, recv, per_peer):
+        def run():
+            n = per_peer * self.world
+            s, r = self._view(send, n), self._view(recv, n)
+            self.bytes_moved += n
+            if self.direct:
+                dist.all_to_all_single(r, s, group=self.group)
+                torch.cuda.synchronize(self.device)
+            else:
+                hs = s.cpu()
+                parts = [torch.empty(n, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, hs, group=self.group)  # gloo has no all_to_all on every build: take my block of each
+                hr = torch.cat([p[self.rank * per_peer:(self.rank + 1) * per_peer] for p in parts])
+                r.copy_(hr)
+                torch.cuda.synchronize(self.device)
+
+        return self._guard(run)
+
+    def _all_gather(self, _user, send, recv, nbytes):
+        def run():
+            s, r = self._view(send, nbytes), self._view(recv, nbytes * self.world)
+            self.bytes_moved += nbytes * self.world
+            if self.direct:
+                dist.all_gather_into_tensor(r, s, group=self.group)
+                torch.cuda.synchronize(self.device)
+            else:
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, s.cpu(), group=self.group)
+                r.copy_(torch.cat(parts))
+                torch.cuda.synchronize(self.device)
+
+        return self._guard(run)
+
+
+def u32_add_owners(k):
+    """owners for the system [ByteTable, U32Add x k]: the byte table replicated, adder i on rank i."""
+    return [-1] + list(range(k))

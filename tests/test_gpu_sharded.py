@@ -1,0 +1,77 @@
+"""GPU parity of the multi-rank prover (ms_prove_sharded): `world` processes (gloo transport, the ranks share the one
+GPU of the test box) prove the system [ByteTable, U32Add x world] together; every rank must return exactly the bytes
+the single-GPU prover produces for the same system and witness, and the oracle verifier must accept them."""
+import hashlib
+import os
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, log_adds, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4", OMP_WAIT_POLICY="passive")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import importlib
+
+        import torch.distributed as dist
+        from __graft_entry__ import load_package
+
+        pkg = load_package()
+        fe = pkg.frontend
+        sharded = importlib.import_module("multi_stark_amd.sharded")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            ctx = pkg.Context(0)
+            system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+            traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
+            packed = fe.pack_claims(claims)
+            owners = sharded.u32_add_owners(world)
+            mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+            remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+            w = system.witness(mine, packed, remote_heights=remote)
+            comm = sharded.TorchComm(0)
+            proof = system.prove_sharded(w, comm, owners).to_bytes()
+            again = system.prove_sharded(w, comm, owners, want_times=True)
+            assert again.to_bytes() == proof and again.stage_ms["total"] > 0
+            if remote:
+                with pytest.raises(pkg.MstarkError):
+                    system.prove_multiple_claims(w)  # a witness with remote circuits is refused by the one-GPU prover
+            if rank == 0:
+                import oracle
+
+                full = system.witness(traces, packed)
+                want = system.prove_multiple_claims(full).to_bytes()
+                assert proof == want, "sharded proof differs from the single-GPU proof"
+                assert oracle.System(system.blob).verify(packed, proof) == 0
+            q.put((rank, hashlib.sha256(proof).hexdigest(), comm.bytes_moved))
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+    except BaseException as e:  # surface the failure in the parent instead of a queue timeout
+        q.put((rank, "ERROR: %r" % (e,), 0))
+        raise
+
+
+# 2^8 additions: the adders' LDE is as tall as the byte table's (same leaf group); 2^10: the byte table is injected
+@pytest.mark.parametrize("world,log_adds", [(1, 9), (2, 8), (2, 10), (4, 10)])
+def test_sharded_proof_equals_single_gpu_proof(world, log_adds):
+    port = 29600 + (os.getpid() % 1000) + 7 * world + log_adds
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, log_adds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert all(not str(r[1]).startswith("ERROR") for r in res), res
+    assert all(p.exitcode == 0 for p in procs)
+    assert len({r[1] for r in res}) == 1  # every rank holds the same proof bytes
+    if world > 1:
+        assert all(r[2] > 0 for r in res)
