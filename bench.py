@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path with several ranks sharing one GPU)")
+    ap.add_argument("--joint", action="store_true", help="N > 1: ONE proof of the system [ByteTable, U32Add x N] computed by all "
+                    "ranks together (ms_prove_sharded, BASELINE config 3) instead of one independent proof per rank")
     return ap.parse_args()
 
 
@@ -83,8 +85,7 @@ def main():
     fe = pkg.frontend
     ctx = pkg.Context(local_rank)
     params = fe.bench_params()
-    inputs = fe.u32_add_system_inputs()
-    system = pkg.System.new(ctx, params, inputs)
+    joint = args.joint and (n_gpus > 1 or force_dist)
     num_adds = 1 << args.log_adds
     # per-rank seeds; rank 0 is exactly the reference's bench witness
     a0, b0 = (0xDEADBEEF, 0xCAFEBABE)
@@ -96,10 +97,36 @@ def main():
         a0, b0 = mgpu.rank_seeds(rank)
     t = time.time()
     traces, claims = fe.u32_add_bench_witness(num_adds, a0, b0)
-    packed = fe.pack_claims(claims)
-    witness = system.witness(traces, packed)  # SystemWitness::from_stage_1 + upload: setup, untimed (criterion setup closure)
-    rows_per_proof = witness.rows
-    log("[rank %d] witness ready in %.1fs: %d rows/proof" % (rank, time.time() - t, rows_per_proof))
+    comm = owners = None
+    if joint:
+        # one system for everyone; rank k computes adder k. Setup (untimed, like the reference's criterion setup
+        # closure): the byte table's multiplicities are the sum over ranks (plain integer counts, far below 2^63) and
+        # every rank holds all claims, which the transcript absorbs in order
+        sharded = importlib.import_module("multi_stark_amd.sharded")
+        world_n = dist.get_world_size()
+        inputs = fe.multi_u32_add_system_inputs(world_n)
+        system = pkg.System.new(ctx, params, inputs)
+        dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+        byte = torch.from_numpy(traces[0].astype(np.int64)).to(dev)
+        dist.all_reduce(byte, op=dist.ReduceOp.SUM)
+        mine_claims = torch.from_numpy(np.ascontiguousarray(claims).view(np.int64)).to(dev)
+        parts = [torch.empty_like(mine_claims) for _ in range(world_n)]
+        dist.all_gather(parts, mine_claims)
+        all_claims = np.concatenate([p.cpu().numpy().view(np.uint64) for p in parts], axis=0)
+        packed = fe.pack_claims(all_claims)
+        owners = sharded.u32_add_owners(world_n)
+        tr = [byte.cpu().numpy().astype(np.uint64)] + [traces[1] if k == rank else None for k in range(world_n)]
+        remote = {1 + k: traces[1].shape[0] for k in range(world_n) if k != rank}
+        witness = system.witness(tr, packed, remote_heights=remote)
+        comm = sharded.TorchComm(local_rank)
+        rows_per_proof = 256 + world_n * traces[1].shape[0]
+    else:
+        inputs = fe.u32_add_system_inputs()
+        system = pkg.System.new(ctx, params, inputs)
+        packed = fe.pack_claims(claims)
+        witness = system.witness(traces, packed)  # SystemWitness::from_stage_1 + upload: setup, untimed (criterion setup closure)
+        rows_per_proof = witness.rows
+    log("[rank %d] witness ready in %.1fs: %d rows/proof%s" % (rank, time.time() - t, rows_per_proof, " (joint proof)" if joint else ""))
 
     gatherer = None
     digests = []
@@ -118,6 +145,8 @@ def main():
         # the commitments of proof k are gathered by a worker thread while proof k + 1 runs (CommitmentGatherer);
         # sync_all() waits for all of them, so the timed region contains every collective it started
         nonlocal gatherer
+        if joint:
+            return system.prove_sharded(witness, comm, owners)
         proof = system.prove_multiple_claims(witness)
         if dist is not None:
             blob = mgpu.commitments_of(proof.to_bytes(), 2)
@@ -166,12 +195,13 @@ def main():
         elapsed = float(tmax.item())
     dom = ctx.kernel_stats()[dominant]
     ctx.set_profile([])
-    stage = system.prove_multiple_claims(witness, want_times=True).stage_ms
+    stage = (system.prove_sharded(witness, comm, owners, want_times=True) if joint else
+             system.prove_multiple_claims(witness, want_times=True)).stage_ms
 
     result = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = rows_per_proof * n_gpus * args.steps / elapsed
+        value = rows_per_proof * (1 if joint else n_gpus) * args.steps / elapsed
         avg_ms = dom["ms"] / max(dom["launches"], 1)
         bytes_per_launch = dom["alg_bytes"] / max(dom["launches"], 1)
         achieved = bytes_per_launch / max(avg_ms, 1e-12) / 1e6  # GB/s
@@ -194,7 +224,8 @@ def main():
                             "witness resident in HBM, proof bytes returned to host" % args.log_adds,
                 "rows_per_proof": rows_per_proof,
                 "proof_bytes": proof_len,
-                "parallelism": "1 proof per GPU" if n_gpus > 1 else "single GPU",
+                "parallelism": ("one joint proof over %d GPUs (ms_prove_sharded)" % n_gpus) if joint else
+                               "1 proof per GPU" if n_gpus > 1 else "single GPU",
                 "stage_ms": {k: round(v, 3) for k, v in stage.items()},
                 "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows_per_proof / (elapsed / args.steps) / 1e9,
             },
