@@ -325,9 +325,9 @@ __device__ __forceinline__ u32 stream_byte(const uint8_t* __restrict__ prefix, s
 }
 
 __global__ __launch_bounds__(256) void chunk_cv_k(const uint8_t* __restrict__ prefix, size_t pl, const u64* __restrict__ words,
-                                                  size_t len, size_t nchunks, Digest* out) {
-  size_t ch = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (ch >= nchunks) return;
+                                                  size_t len, size_t nchunks, size_t c0, size_t c1, Digest* out) {
+  size_t ch = c0 + blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // chunks [c0, c1) of the stream's nchunks
+  if (ch >= c1) return;
   size_t off = ch * 1024;
   size_t clen = len - off < 1024 ? len - off : 1024;
   u32 nblocks = clen == 0 ? 1 : (u32)((clen + 63) / 64);
@@ -536,12 +536,24 @@ std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t) {
   return cap;
 }
 
-Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords) {
+size_t blake3_num_chunks(size_t prefix_len, size_t nwords) {
   size_t len = prefix_len + 8 * nwords;
-  size_t nchunks = len == 0 ? 1 : (len + 1023) / 1024;
-  DBuf<Digest> a(ctx, nchunks), b(ctx, (nchunks + 1) / 2);
-  hipLaunchKernelGGL(chunk_cv_k, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx.stream, d_prefix, prefix_len, d_words, len, nchunks, a.p);
-  Digest* cur = a.p;
+  return len == 0 ? 1 : (len + 1023) / 1024;
+}
+
+void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords, size_t c0, size_t c1,
+                      Digest* cvs) {
+  const size_t len = prefix_len + 8 * nwords, nchunks = blake3_num_chunks(prefix_len, nwords);
+  if (c1 > nchunks) c1 = nchunks;
+  if (c0 >= c1) return;
+  hipLaunchKernelGGL(chunk_cv_k, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, ctx.stream, d_prefix, prefix_len, d_words, len,
+                     nchunks, c0, c1, cvs);
+  HIP_CHECK(hipGetLastError());
+}
+
+Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks) {
+  DBuf<Digest> b(ctx, (nchunks + 1) / 2);
+  Digest* cur = cvs;
   Digest* nxt = b.p;
   size_t n = nchunks;
   while (n > 1) {
@@ -555,6 +567,13 @@ Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const
   Digest out;
   ctx.d2h(&out, cur, sizeof(Digest));
   return out;
+}
+
+Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords) {
+  const size_t nchunks = blake3_num_chunks(prefix_len, nwords);
+  DBuf<Digest> a(ctx, nchunks);
+  blake3_chunk_cvs(ctx, d_prefix, prefix_len, d_words, nwords, 0, nchunks, a.p);
+  return blake3_from_cvs(ctx, a.p, nchunks);
 }
 
 }  // namespace msamd

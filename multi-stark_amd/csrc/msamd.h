@@ -198,6 +198,12 @@ void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc = nullptr)
 std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t);  // D2H of the cap layer (synchronises)
 // BLAKE3 of the byte stream prefix (prefix_len bytes) || nwords little-endian u64 words; result to host
 Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords);
+// the same in two steps, so that ranks can split the chunk range: chaining values of chunks [c0, c1) into cvs[c0..c1),
+// then the tree over all nchunks values (overwrites cvs)
+size_t blake3_num_chunks(size_t prefix_len, size_t nwords);
+void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords, size_t c0, size_t c1,
+                      Digest* cvs);
+Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks);
 
 // ---------------------------------------------------------------- lookup.hip
 // device-resident LookupValues of one circuit (row-major as the reference stores them)
