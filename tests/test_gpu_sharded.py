@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, log_adds, q):
+def _worker(rank, world, port, log_adds, variant, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4", OMP_WAIT_POLICY="passive")
         sys.path.insert(0, ROOT)
@@ -28,7 +28,11 @@ def _worker(rank, world, port, log_adds, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         try:
             ctx = pkg.Context(0)
-            system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+            params = fe.bench_params()
+            if variant == "cap1":  # commitments are 2-digest caps, 4-coefficient final polynomial, host-driven FRI rounds
+                params = fe.Params(log_blowup=2, cap_height=1, log_final_poly_len=2, num_queries=20, commit_proof_of_work_bits=3,
+                                   query_proof_of_work_bits=5)
+            system = pkg.System.new(ctx, params, fe.multi_u32_add_system_inputs(world))
             traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
             packed = fe.pack_claims(claims)
             owners = sharded.u32_add_owners(world)
@@ -42,6 +46,10 @@ def _worker(rank, world, port, log_adds, q):
             if remote:
                 with pytest.raises(pkg.MstarkError):
                     system.prove_multiple_claims(w)  # a witness with remote circuits is refused by the one-GPU prover
+            if variant == "bad-owners" and world > 1:
+                # every rank passes the same wrong map, so all of them fail before the first exchange
+                with pytest.raises(pkg.MstarkError):
+                    system.prove_sharded(w, comm, [-1] + list(reversed(range(world))))
             if rank == 0:
                 import oracle
 
@@ -59,12 +67,13 @@ def _worker(rank, world, port, log_adds, q):
 
 
 # 2^8 additions: the adders' LDE is as tall as the byte table's (same leaf group); 2^10: the byte table is injected
-@pytest.mark.parametrize("world,log_adds", [(1, 9), (2, 8), (2, 10), (4, 10)])
-def test_sharded_proof_equals_single_gpu_proof(world, log_adds):
-    port = 29600 + (os.getpid() % 1000) + 7 * world + log_adds
+@pytest.mark.parametrize("world,log_adds,variant", [(1, 9, "bench"), (2, 8, "bench"), (2, 10, "bad-owners"), (4, 10, "bench"),
+                                                    (2, 9, "cap1")])
+def test_sharded_proof_equals_single_gpu_proof(world, log_adds, variant):
+    port = 29600 + (os.getpid() % 1000) + 7 * world + log_adds + (3 if variant == "cap1" else 0)
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, log_adds, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, log_adds, variant, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
