@@ -605,6 +605,56 @@ def multi_u32_add_witness(k, num_adds):
     return traces, np.concatenate(claims, axis=0)
 
 
+def byte_operations_inputs():
+    """ByteCS of src/test_circuits/byte_operations.rs:12-103: a 2^16-row preprocessed table [A, B, A^B, A&B, A|B], four
+    multiplicity columns, no AIR constraints, four pull lookups (xor / and / or with 4 arguments, the pair range check
+    with 3)."""
+    a = np.repeat(np.arange(256, dtype=np.uint64), 256)
+    b = np.tile(np.arange(256, dtype=np.uint64), 256)
+    pre = np.stack([a, b, a ^ b, a & b, a | b], axis=1)
+    var, pvar = Expr.main, Expr.preprocessed
+    lookups = [Lookup.pull(var(i), [Expr.const(i), pvar(0), pvar(1), pvar(2 + i)]) for i in range(3)]
+    lookups.append(Lookup.pull(var(3), [Expr.const(3), pvar(0), pvar(1)]))
+    return [lookup_air(4, None, lookups, pre)]
+
+
+def byte_operations_witness(calls):
+    """ByteCalls::witness (src/test_circuits/byte_operations.rs:106-122): calls = [(op, x, y)], op 0 xor / 1 and / 2 or /
+    3 pair range check. Returns ([trace], claims) with the claims of byte_test (:148-154), of ragged lengths."""
+    trace = np.zeros((65536, 4), dtype=np.uint64)
+    claims = []
+    for (op, x, y) in calls:
+        trace[256 * x + y, op] += 1
+        claims.append([op, x, y] + ([x ^ y, x & y, x | y][op:op + 1] if op < 3 else []))
+    return [trace], claims
+
+
+def squares_inputs():
+    """[RangeTable, Squares] of examples/preprocessed_proof.rs:27-88: a byte table pulled by its multiplicity column
+    (one-argument lookups, no circuit index) and a squaring circuit [x, x^2, low, high, mult] pushing both bytes."""
+    var = Expr.main
+    pre = np.arange(256, dtype=np.uint64).reshape(256, 1)
+    table = lookup_air(1, None, [Lookup.pull(var(0), [Expr.preprocessed(0)])], pre)
+
+    def ev(b):
+        local, _ = b.main()
+        x, sq, low, high = local[0], local[1], local[2], local[3]
+        b.assert_eq(sq, x * x)
+        b.assert_eq(sq, low + high * Expr.const(256))
+
+    squares = lookup_air(5, ev, [Lookup.push(var(4), [var(2)]), Lookup.push(var(4), [var(3)])])
+    return [table, squares]
+
+
+def squares_traces(n=16):
+    """examples/preprocessed_proof.rs:108-127: squares of 0..n (n a power of two, n <= 256 so x^2 fits two bytes)."""
+    x = np.arange(n, dtype=np.uint64)
+    sq = x * x
+    low, high = sq & np.uint64(0xFF), (sq >> np.uint64(8)) & np.uint64(0xFF)
+    mult = np.bincount(np.concatenate([low, high]).astype(np.int64), minlength=256).astype(np.uint64).reshape(256, 1)
+    return [mult, np.stack([x, sq, low, high, np.ones(n, dtype=np.uint64)], axis=1)]
+
+
 def pythagorean_inputs():
     """examples/simple_proof.rs:21-44."""
 

@@ -62,6 +62,18 @@ def test_u32_add_explicit_lookup_values(pkg, ctx, oracle, fe):
 
 
 # the bench workload (benches/multi_stark.rs) with bench_config(): 10-bit grinding, 100 queries, blowup 4
+# examples/preprocessed_proof.rs: preprocessed range table + squaring circuit, one-argument lookups, no claims
+@pytest.mark.parametrize("n", [16, 256])
+def test_preprocessed_squares_proof(pkg, ctx, oracle, fe, n):
+    _prove_both(pkg, ctx, oracle, fe, fe.squares_inputs(), fe.test_params(), fe.squares_traces(n), [])
+
+
+# src/test_circuits/byte_operations.rs:124-157: wide 2^16-row preprocessed trace, lookup-only circuit, ragged claims
+def test_byte_operations_proof(pkg, ctx, oracle, fe):
+    traces, claims = fe.byte_operations_witness([(0, 10, 5), (1, 30, 20), (2, 100, 40), (3, 200, 100)])
+    _prove_both(pkg, ctx, oracle, fe, fe.byte_operations_inputs(), fe.test_params(), traces, claims)
+
+
 @pytest.mark.parametrize("log_adds", [6, 10, 14])
 def test_bench_workload(pkg, ctx, oracle, fe, log_adds):
     traces, claims = fe.u32_add_bench_witness(1 << log_adds)

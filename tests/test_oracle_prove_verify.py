@@ -108,6 +108,32 @@ def test_u32_add_proof(oracle, fe):
     assert s.verify(fe.pack_claims(bad), proof) != 0
 
 
+# src/test_circuits/byte_operations.rs:124-157 (byte_test): 2^16-row preprocessed table of width 5, no AIR constraints,
+# lookups with 4 and 3 arguments, claims of different lengths
+def test_byte_operations_proof(oracle, fe):
+    s, _, _ = _system(oracle, fe, fe.byte_operations_inputs(), fe.test_params())
+    calls = [(0, 10, 5), (1, 30, 20), (2, 100, 40), (3, 200, 100)]
+    traces, claims = fe.byte_operations_witness(calls)
+    assert claims == [[0, 10, 5, 15], [1, 30, 20, 20], [2, 100, 40, 108], [3, 200, 100]]
+    packed = fe.pack_claims(claims)
+    proof = s.prove(traces, packed)
+    assert s.verify(packed, proof) == 0
+    wrong = fe.pack_claims([[0, 10, 5, 14]] + claims[1:])
+    assert s.verify(wrong, proof) != 0
+
+
+# examples/preprocessed_proof.rs: preprocessed range table + squaring circuit, one-argument lookups, no claims
+@pytest.mark.parametrize("n", [16, 256])
+def test_preprocessed_squares_proof(oracle, fe, n):
+    s, _, _ = _system(oracle, fe, fe.squares_inputs(), fe.test_params())
+    traces = fe.squares_traces(n)
+    packed = fe.pack_claims([])
+    proof = s.prove(traces, packed)
+    assert s.verify(packed, proof) == 0
+    traces[1][3, 1] += 1  # x^2 off by one: the AIR constraint fails, the verifier rejects
+    assert s.verify(packed, s.prove(traces, packed)) != 0
+
+
 def test_bench_workload_small(oracle, fe):
     s, blob, comp = _system(oracle, fe, fe.u32_add_system_inputs(), fe.bench_params())
     traces, claims = fe.u32_add_bench_witness(1 << 8)
