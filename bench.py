@@ -35,7 +35,6 @@ def parse_args():
     ap.add_argument("--log-adds", type=int, default=20, help="log2 of U32 additions per proof (BASELINE: 20)")
     ap.add_argument("--cpu-log-adds", type=int, default=16, help="bounded sample for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-all", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path with several ranks sharing one GPU)")
     ap.add_argument("--joint", action="store_true", help="N > 1: ONE proof of the system [ByteTable, U32Add x N] computed by all "
@@ -175,7 +174,7 @@ def main():
             ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
             if ranked and ranked[0][1]["ms"] > 0:
                 dominant = ranked[0][0]
-            if rank == 0 and (args.profile_all or True):
+            if rank == 0:
                 log("per-kernel-class device time of one proof (HIP events, profiled warmup step):")
                 for n, s in ranked:
                     if s["launches"]:

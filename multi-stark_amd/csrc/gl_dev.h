@@ -4,10 +4,17 @@
 // BinomialExtensionField<Val, 2>); W recovered as X^D in src/system.rs:334-349.
 // All values are kept canonical (< p) in memory; 2^64 = 2^32 - 1 and 2^96 = -1 (mod p) drive the reduction.
 #pragma once
+#if !defined(__HIPCC_RTC__)  // hiprtc (quotient_jit.hip) has no standard library headers; its built-ins declare these
 #include <cstddef>
 #include <cstdint>
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+typedef unsigned long uint64_t;  // LP64, as <cstdint> has it
+typedef unsigned int uint32_t;
+typedef unsigned long size_t;
+#define GL_HD __device__ __forceinline__
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GL_HD __host__ __device__ __forceinline__
 #else

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void scan_block_k(const E2* __restrict__ in, E
   }
   sh[threadIdx.x] = t;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
+  for (u32 d = 1; d < 256; d <<= 1) {
     E2 x = threadIdx.x >= d ? sh[threadIdx.x - d] : e2(0);
     __syncthreads();
     sh[threadIdx.x] = e2_add(sh[threadIdx.x], x);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void scan_totals_k(E2* __restrict__ tot, size_
     E2 v = i < nb ? tot[i] : e2(0);
     sh[threadIdx.x] = v;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
+    for (u32 d = 1; d < 256; d <<= 1) {
       E2 x = threadIdx.x >= d ? sh[threadIdx.x - d] : e2(0);
       __syncthreads();
       sh[threadIdx.x] = e2_add(sh[threadIdx.x], x);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data
   }
   sh[threadIdx.x] = sum;
   __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
+  for (u32 d = 128; d > 0; d >>= 1) {
     if (threadIdx.x < d) sh[threadIdx.x] = e2_add(sh[threadIdx.x], sh[threadIdx.x + d]);
     __syncthreads();
   }

@@ -226,8 +226,24 @@ size_t claims_transcript_words(Ctx& ctx, const u64* d_claim_data, const u64* d_c
                                size_t total_elems, u64* d_words);
 
 // ---------------------------------------------------------------- quotient.hip
+// a circuit's quotient kernel compiled with hiprtc at System::new (quotient_jit.hip); empty = use the interpreter
+struct JitKernel {
+  void* module = nullptr;    // hipModule_t
+  void* function = nullptr;  // hipFunction_t
+  JitKernel() {}
+  JitKernel(const JitKernel&) = delete;
+  JitKernel& operator=(const JitKernel&) = delete;
+  JitKernel(JitKernel&& o) noexcept : module(o.module), function(o.function) { o.module = o.function = nullptr; }
+  JitKernel& operator=(JitKernel&& o) noexcept {
+    std::swap(module, o.module);
+    std::swap(function, o.function);
+    return *this;
+  }
+  ~JitKernel();
+};
 struct DProgram {
   // register-allocated straight-line program for one circuit (see quotient.hip)
+  JitKernel jit;
   DBuf<uint32_t> code;      // 4 words per instruction
   DBuf<u64> consts;
   size_t n_instr = 0, n_slots = 0;

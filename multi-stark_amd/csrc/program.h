@@ -19,6 +19,12 @@ struct PNode {
 void build_program(Ctx& ctx, const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
                    const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, DProgram& out);
 
+// quotient_jit.hip: compile (or fetch from the cache) the circuit's own quotient kernel; launch it
+struct QParams;
+void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out);
+void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq);
+
 // lookup values of SystemWitness::from_stage_1 on the device; false = prefix too large for the LDS slot file
 bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, const u64* d_pre, size_t h, size_t main_w,
                           size_t pre_w, size_t args_w, u64* d_mult, u64* d_args);

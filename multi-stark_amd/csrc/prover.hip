@@ -257,6 +257,7 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
     if (c.quotient_degree() > (size_t(1) << p.log_blowup))  // src/system.rs:171-178
       throw std::runtime_error("circuit " + std::to_string(ci) + ": constraint degree needs a quotient degree beyond the blowup");
     build_program(ctx, c.nodes, c.zeros, c.lookups, c.prog);
+    quotient_jit_build(c.nodes, c.zeros, c.lookups, c.prog.jit);  // the circuit's own kernel, from hiprtc or the cache
     {
       // the lookup prefix may only read trace columns and row selectors (src/graph.rs: Stage2InBaseContext; publics
       // do not exist at witness time); anything else keeps the host sweep, which reports the error

@@ -11,40 +11,13 @@
 
 #include "msamd.h"
 #include "program.h"
+#include "quotient_params.h"
 
 namespace msamd {
 
 namespace {
 
-struct QParams {
-  const u64 *pre, *s1, *s2;
-  size_t pre_h, s1_h, s2_h;
-  unsigned log_n, log_q;
-  u64 publics[8];
-  u64 delta_scaled[2];
-  u64 g_inv;          // inverse of the trace-domain generator
-  const u64* zh;      // q entries: Z_H on the coset, x^n - 1
-  const u64* zh_inv;  // q entries
-  const E2* alpha_rev;  // constraint_count reversed powers
-  const uint32_t* code;
-  const u64* consts;
-  const uint32_t* zero_slots;
-  const uint32_t* lookup_slots;
-  uint32_t n_instr, n_zeros, n_lookups, n_slots;
-  const u64* t0;
-  const u64* t1;
-  u64* out;
-  u64* scratch;       // global slot storage (when !LDS)
-  size_t row0, rows;  // batch of storage rows handled by this launch
-  E2 gpow[32];        // gamma^0 .. gamma^31: fingerprints as unreduced base x ext dot products
-};
-
-__device__ __forceinline__ void mul2(u64 a0, u64 a1, u64 b0, u64 b1, u64& c0, u64& c1) {
-  u64 v0 = gl_mul(a0, b0), v1 = gl_mul(a1, b1);
-  u64 cross = gl_sub(gl_sub(gl_mul(gl_add(a0, a1), gl_add(b0, b1)), v0), v1);
-  c0 = gl_add(v0, gl_mul_small(v1, (u32)GL_EXT_W));
-  c1 = cross;
-}
+static_assert(TW_LOG == 28 && TW_HALF == 14, "quotient_params.h repeats these for the hiprtc build");
 
 template <bool LDS>
 __global__ __launch_bounds__(256) void quotient_k(QParams p) {
@@ -435,7 +408,13 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
   const double bytes = double(nq) * 8.0 * (2.0 * (prog.main_w + prog.s2_w + prog.pre_w) + 2.0);
   unsigned threads = 256;
   while (threads > 64 && prog.n_slots * threads * 8 > 64 * 1024) threads >>= 1;
-  if (prog.n_slots * threads * 8 <= 64 * 1024) {
+  if (prog.jit.function) {
+    p.row0 = 0;
+    p.rows = nq;
+    hipEvent_t ev = ctx.prof_begin(K_QUOTIENT);
+    quotient_jit_launch(ctx, prog.jit, p, nq);
+    ctx.prof_end(K_QUOTIENT, ev, bytes);
+  } else if (prog.n_slots * threads * 8 <= 64 * 1024) {
     p.row0 = 0;
     p.rows = nq;
     hipEvent_t ev = ctx.prof_begin(K_QUOTIENT);

@@ -1,0 +1,292 @@
+// Per-circuit quotient kernels compiled at System::new (program compilation cache keyed by the program).
+// The reference interprets the node vector for every row (ConstraintGraph::sweep_range, /root/reference/src/eval.rs:67-106)
+// and so does quotient_k (quotient.hip), paying an instruction fetch, a switch and two LDS round trips per node. Here
+// the compiled circuit is printed as straight-line HIP - one local per node, the logUp constraints
+// (src/lookup.rs:152-208) and the alpha fold (src/prover.rs:866-962) unrolled with literal column indices - and compiled
+// for gfx950 with hiprtc; the register allocator then does what the slot file did by hand. hiprtc is loaded with
+// dlopen: without it, or when a program is too large to be worth compiling, the interpreter kernel keeps doing the
+// job (same results either way; MSAMD_NO_JIT=1 forces it). Code objects are cached per process by source hash and,
+// across processes, in MSAMD_JIT_CACHE (default: .jit_cache next to the library).
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <sstream>
+
+#include "host.h"
+#include "quotient_params.h"
+
+namespace msamd {
+
+namespace {
+
+std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                           const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups) {
+  const size_t nn = nodes.size();
+  std::vector<char> needed(nn, 0);
+  for (auto z : zeros) needed[z] = 1;
+  for (auto& l : lookups) {
+    needed[l.first] = 1;
+    for (auto a : l.second) needed[a] = 1;
+  }
+  for (size_t i = nn; i-- > 0;) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    if (n.kind == OP_ADD || n.kind == OP_SUB || n.kind == OP_MUL) needed[n.a] = needed[n.b] = 1;
+    if (n.kind == OP_NEG) needed[n.a] = 1;
+  }
+  std::ostringstream o;
+  o << "#include \"quotient_params.h\"\nusing namespace msamd;\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void quotient_jit(QParams p) {\n"
+       "  const size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x;\n"
+       "  const unsigned lognq = p.log_n + p.log_q;\n"
+       "  const size_t nq = size_t(1) << lognq;\n"
+       "  if (t >= nq) return;\n"
+       "  const u32 i = bitrev32((u32)t, lognq);\n"
+       "  const u32 inext = (i + (1u << p.log_q)) & (u32)(nq - 1);\n"
+       "  const size_t tn = bitrev32(inext, lognq);\n"
+       "  const u32 e = i << (TW_LOG - lognq);\n"
+       "  const u64 x = gl_mul_small(gl_mul(p.t1[e >> TW_HALF], p.t0[e & ((1u << TW_HALF) - 1)]), 7);\n"
+       "  const u32 qi = i & ((1u << p.log_q) - 1);\n"
+       "  const u64 zh = p.zh[qi];\n"
+       "  const u64 d_first = gl_sub(x, 1), d_last = gl_sub(x, p.g_inv);\n"
+       "  const u64 inv_both = gl_inv(gl_mul(d_first, d_last));\n"
+       "  const u64 is_first = gl_mul(zh, gl_mul(inv_both, d_last));\n"
+       "  const u64 is_last = gl_mul(zh, gl_mul(inv_both, d_first));\n"
+       "  const u64 is_trans = d_last;\n"
+       "  (void)is_first; (void)is_last; (void)is_trans; (void)tn;\n";
+  for (size_t i = 0; i < nn; i++) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    o << "  const u64 v" << i << " = ";
+    switch (n.kind) {
+      case OP_CONST: o << n.a << "ULL"; break;
+      case OP_VAR: {
+        const char* src = n.source == 1 ? "s1" : n.source == 0 ? "pre" : "s2";
+        o << "p." << src << "[size_t(" << n.a << ") * p." << src << "_h + " << (n.offset ? "tn" : "t") << "]";
+        break;
+      }
+      case OP_PUBLIC: o << "p.publics[" << n.a << "]"; break;
+      case OP_IS_FIRST: o << "is_first"; break;
+      case OP_IS_LAST: o << "is_last"; break;
+      case OP_IS_TRANS: o << "is_trans"; break;
+      case OP_ADD: o << "gl_add(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_SUB: o << "gl_sub(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_MUL: o << "gl_mul(v" << n.a << ", v" << n.b << ")"; break;
+      default: o << "gl_neg(v" << n.a << ")"; break;
+    }
+    o << ";\n";
+  }
+  o << "  GlAcc fa0, fa1;\n  acc_init(fa0);\n  acc_init(fa1);\n";
+  size_t ci = 0;
+  for (auto z : zeros) {
+    o << "  { const E2 a = p.alpha_rev[" << ci << "]; acc_mad(fa0, v" << z << ", a.c0); acc_mad(fa1, v" << z << ", a.c1); }\n";
+    ci++;
+  }
+  o << "  const u64 beta0 = p.publics[0], beta1 = p.publics[1];\n"
+       "  const u64 inj0 = gl_mul(is_last, p.delta_scaled[0]), inj1 = gl_mul(is_last, p.delta_scaled[1]);\n"
+       "  (void)beta0; (void)beta1;\n";
+  auto fold2 = [&](const std::string& c0, const std::string& c1) {
+    o << "  { const E2 a = p.alpha_rev[" << ci << "], b = p.alpha_rev[" << ci + 1 << "];\n"
+      << "    acc_mad(fa0, " << c0 << ", a.c0); acc_mad(fa0, " << c1 << ", b.c0);\n"
+      << "    acc_mad(fa1, " << c0 << ", a.c1); acc_mad(fa1, " << c1 << ", b.c1); }\n";
+    ci += 2;
+  };
+  const size_t L = lookups.size();
+  if (L == 0) {
+    o << "  const u64 pt0 = gl_add(gl_sub(p.s2[tn], p.s2[t]), inj0);\n"
+         "  const u64 pt1 = gl_add(gl_sub(p.s2[p.s2_h + tn], p.s2[p.s2_h + t]), inj1);\n";
+    fold2("pt0", "pt1");
+  } else {
+    o << "  const u64 acc0_0 = p.s2[t], acc1_0 = p.s2[p.s2_h + t];\n";
+    for (size_t j = 0; j < L; j++) {
+      const auto& l = lookups[j];
+      // running-sum columns: source = column pair j, target = pair j + 1, or the next row's first pair (+ injection)
+      if (j + 1 < L)
+        o << "  const u64 acc0_" << j + 1 << " = p.s2[size_t(" << 2 * j + 2 << ") * p.s2_h + t], acc1_" << j + 1 << " = p.s2[size_t("
+          << 2 * j + 3 << ") * p.s2_h + t];\n";
+      else
+        o << "  const u64 acc0_" << j + 1 << " = gl_add(p.s2[tn], inj0), acc1_" << j + 1 << " = gl_add(p.s2[p.s2_h + tn], inj1);\n";
+      const size_t na = l.second.size();
+      o << "  u64 f0_" << j << ", f1_" << j << ";\n  {\n";
+      if (na <= 32) {
+        o << "    GlAcc g0, g1;\n    acc_init(g0);\n    acc_init(g1);\n";
+        for (size_t k = 0; k < na; k++)
+          o << "    acc_mad(g0, v" << l.second[k] << ", p.gpow[" << k << "].c0); acc_mad(g1, v" << l.second[k] << ", p.gpow[" << k
+            << "].c1);\n";
+        o << "    f0_" << j << " = acc_reduce(g0);\n    f1_" << j << " = acc_reduce(g1);\n";
+      } else {
+        o << "    u64 h0 = 0, h1 = 0, g0, g1;\n";
+        for (size_t k = na; k-- > 0;)
+          o << "    mul2(h0, h1, p.publics[2], p.publics[3], g0, g1); h0 = gl_add(g0, v" << l.second[k] << "); h1 = g1;\n";
+        o << "    f0_" << j << " = h0;\n    f1_" << j << " = h1;\n";
+      }
+      o << "  }\n  u64 c0_" << j << ", c1_" << j << ";\n"
+        << "  mul2(gl_add(f0_" << j << ", beta0), gl_add(f1_" << j << ", beta1), gl_sub(acc0_" << j + 1 << ", acc0_" << j << "), gl_sub(acc1_"
+        << j + 1 << ", acc1_" << j << "), c0_" << j << ", c1_" << j << ");\n";
+      std::ostringstream c0;
+      c0 << "gl_sub(c0_" << j << ", v" << l.first << ")";
+      std::ostringstream c1;
+      c1 << "c1_" << j;
+      fold2(c0.str(), c1.str());
+    }
+  }
+  o << "  const u64 iv = p.zh_inv[qi];\n"
+       "  p.out[t] = gl_mul(acc_reduce(fa0), iv);\n"
+       "  p.out[nq + t] = gl_mul(acc_reduce(fa1), iv);\n}\n";
+  return o.str();
+}
+
+u64 fnv1a(const std::string& s, u64 h) {
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ULL;
+  }
+  return h;
+}
+
+// ---- hiprtc through dlopen (no link-time dependency: a box without it still runs the interpreter)
+struct Rtc {
+  void* lib = nullptr;
+  int (*create)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*compile)(void*, int, const char**) = nullptr;
+  int (*log_size)(void*, size_t*) = nullptr;
+  int (*get_log)(void*, char*) = nullptr;
+  int (*code_size)(void*, size_t*) = nullptr;
+  int (*get_code)(void*, char*) = nullptr;
+  int (*destroy)(void**) = nullptr;
+  bool ok = false;
+  Rtc() {
+    for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return;
+    create = (decltype(create))dlsym(lib, "hiprtcCreateProgram");
+    compile = (decltype(compile))dlsym(lib, "hiprtcCompileProgram");
+    log_size = (decltype(log_size))dlsym(lib, "hiprtcGetProgramLogSize");
+    get_log = (decltype(get_log))dlsym(lib, "hiprtcGetProgramLog");
+    code_size = (decltype(code_size))dlsym(lib, "hiprtcGetCodeSize");
+    get_code = (decltype(get_code))dlsym(lib, "hiprtcGetCode");
+    destroy = (decltype(destroy))dlsym(lib, "hiprtcDestroyProgram");
+    ok = create && compile && log_size && get_log && code_size && get_code && destroy;
+  }
+};
+
+std::string library_dir() {
+  Dl_info info;
+  if (dladdr((void*)&fnv1a, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+  }
+  return ".";
+}
+
+std::mutex g_mu;
+std::map<u64, std::vector<char>> g_code;  // source hash -> code object (empty = compilation failed, do not retry)
+
+bool read_file(const std::string& path, std::vector<char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+const std::vector<char>* code_object(const std::string& src) {
+  static Rtc rtc;
+  const std::string dir = library_dir();
+  // the headers are part of the program: a change to the field arithmetic must not reuse old code objects
+  u64 h = fnv1a(src, 1469598103934665603ULL);
+  for (const char* hdr : {"/csrc/gl_dev.h", "/csrc/quotient_params.h"}) {
+    std::vector<char> t;
+    if (read_file(dir + hdr, t)) h = fnv1a(std::string(t.begin(), t.end()), h);
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_code.find(h);
+  if (it != g_code.end()) return it->second.empty() ? nullptr : &it->second;
+  std::vector<char>& slot = g_code[h];
+  const char* env = getenv("MSAMD_JIT_CACHE");
+  const std::string cache_dir = env ? env : dir + "/.jit_cache";
+  char name[64];
+  snprintf(name, sizeof(name), "/q_%016llx.co", (unsigned long long)h);
+  const std::string path = cache_dir + name;
+  if (read_file(path, slot)) return &slot;
+  slot.clear();
+  if (!rtc.ok) return nullptr;
+  void* prog = nullptr;
+  if (rtc.create(&prog, src.c_str(), "quotient_jit.hip", 0, nullptr, nullptr) != 0) return nullptr;
+  const std::string inc = "-I" + dir + "/csrc";
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+  const int rc = rtc.compile(prog, 4, opts);
+  if (rc != 0) {
+    size_t ls = 0;
+    rtc.log_size(prog, &ls);
+    std::string log(ls, 0);
+    if (ls) rtc.get_log(prog, &log[0]);
+    fprintf(stderr, "[msamd] hiprtc could not compile a quotient kernel (the interpreter kernel is used instead):\n%s\n", log.c_str());
+    rtc.destroy(&prog);
+    return nullptr;
+  }
+  size_t cs = 0;
+  rtc.code_size(prog, &cs);
+  slot.resize(cs);
+  rtc.get_code(prog, slot.data());
+  rtc.destroy(&prog);
+  // best-effort disk cache: write to a private name, then rename (several ranks may compile the same program)
+  mkdir(cache_dir.c_str(), 0755);
+  const std::string tmp = path + "." + std::to_string((long)getpid());
+  if (FILE* f = fopen(tmp.c_str(), "wb")) {
+    const bool ok = fwrite(slot.data(), 1, slot.size(), f) == slot.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+  }
+  return &slot;
+}
+
+}  // namespace
+
+JitKernel::~JitKernel() {
+  if (module) (void)hipModuleUnload((hipModule_t)module);
+}
+
+// Compiles (or fetches) the circuit's kernel; leaves `out` empty when the interpreter should be used.
+void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out) {
+  if (getenv("MSAMD_NO_JIT")) return;
+  if (nodes.size() > 6000) return;  // compile time grows faster than the interpreter's overhead is worth
+  const std::string src = circuit_source(nodes, zeros, lookups);
+  const std::vector<char>* co = code_object(src);
+  if (!co) return;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, co->data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (hipModuleGetFunction(&fn, mod, "quotient_jit") != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipModuleUnload(mod);
+    return;
+  }
+  out.module = mod;
+  out.function = fn;
+}
+
+void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq) {
+  QParams copy = p;
+  size_t size = sizeof(QParams);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((nq + 255) / 256), 1, 1, 256, 1, 1, 0, ctx.stream, nullptr, config));
+}
+
+}  // namespace msamd
