@@ -63,6 +63,7 @@ struct HCircuit {
   DBuf<u64> d_preprocessed;       // same, on the device (witness preparation)
   DProgram prog;
   DProgram prefix_prog;           // lookup-expression prefix only (SystemWitness::from_stage_1)
+  JitKernel stage2_jit;           // stage-2 terms kernel specialised to this circuit's lookups (quotient_jit.hip)
   bool prefix_on_device = false;
   size_t quotient_degree() const {
     size_t d = (max_constraint_degree > 2 ? max_constraint_degree : 2) - 1, q = 1;

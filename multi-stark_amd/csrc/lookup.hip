@@ -2,7 +2,9 @@
 // Replaces LookupValues::stage_2_traces (/root/reference/src/lookup.rs:472-555: messages, batch inverse, the
 // serial running sum) and the serial claims loop of src/prover.rs:382-387. All sums are exact field sums, so a
 // parallel scan / tree reduction gives bit-identical values to the reference's serial loops.
+#include "lookup_params.h"
 #include "msamd.h"
+#include "program.h"
 
 namespace msamd {
 
@@ -10,13 +12,6 @@ namespace {
 
 constexpr int INV_CHUNK = 16;   // messages inverted together per thread (one base-field inversion, see e2_batch_inverse)
 constexpr int CLAIMS_CHUNK = 16;
-constexpr int MAX_GPOW = 64;    // gamma powers kept in a kernel argument; longer argument lists fall back to Horner
-
-struct GammaPows {
-  E2 g[MAX_GPOW];
-  u32 n;  // number of valid powers (gamma^0 .. gamma^(n-1))
-};
-
 // m = beta + sum_i args[i] gamma^i (src/lookup.rs:375-384). With the powers precomputed every term is a
 // base x ext product accumulated unreduced; otherwise Horner over the reversed args.
 __device__ __forceinline__ E2 message(const u64* __restrict__ a, u32 n, E2 beta, E2 gamma, const GammaPows& gp) {
@@ -220,7 +215,7 @@ static GammaPows gamma_pows(E2 gamma, size_t max_args) {
   return gp;
 }
 
-void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, E2* total_dev) {
+void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, E2* total_dev, const JitKernel* jit) {
   size_t n = lk.height;
   if (lk.num_lookups == 0) {
     // pass-through accumulator column: zeros (src/lookup.rs:517-521)
@@ -234,8 +229,20 @@ void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* ou
   dim3 grid((unsigned)((n + 255) / 256));
   GammaPows gp = gamma_pows(gamma, MAX_GPOW);
   hipEvent_t ev = ctx.prof_begin(K_STAGE2);
-  hipLaunchKernelGGL(stage2_terms_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma, gp,
-                     terms.p, rowsum.p);
+  if (jit && jit->function) {  // the circuit's own kernel: argument offsets are literals, the row is loaded up front
+    Stage2Params sp;
+    sp.mult = lk.mult.p;
+    sp.args = lk.args.p;
+    sp.n = n;
+    sp.beta = beta;
+    sp.gp = gp;
+    sp.terms = terms.p;
+    sp.rowsum = rowsum.p;
+    stage2_jit_launch(ctx, *jit, sp);
+  } else {
+    hipLaunchKernelGGL(stage2_terms_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma, gp,
+                       terms.p, rowsum.p);
+  }
   ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw));
   scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev);
   ev = ctx.prof_begin(K_STAGE2);
@@ -244,9 +251,9 @@ void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* ou
   HIP_CHECK(hipGetLastError());
 }
 
-E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out) {
+E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, const JitKernel* jit) {
   DBuf<E2> tot(ctx, 1);
-  stage2_build_async(ctx, lk, beta, gamma, out, tot.p);
+  stage2_build_async(ctx, lk, beta, gamma, out, tot.p, jit);
   E2 total;
   ctx.d2h(&total, tot.p, sizeof(E2));
   return total;

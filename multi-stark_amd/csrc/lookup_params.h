@@ -1,0 +1,25 @@
+// Argument types of the stage-2 kernels, shared by lookup.hip and by the per-circuit stage-2 kernel that
+// quotient_jit.hip generates (this header is on hiprtc's include path).
+#pragma once
+#include "gl_dev.h"
+
+namespace msamd {
+
+constexpr int MAX_GPOW = 64;    // gamma powers kept in a kernel argument; longer argument lists fall back to Horner
+
+struct GammaPows {
+  E2 g[MAX_GPOW];
+  u32 n;  // number of valid powers (gamma^0 .. gamma^(n-1))
+};
+
+struct Stage2Params {
+  const u64* mult;   // n x L row-major
+  const u64* args;   // n x args_width row-major
+  size_t n;
+  E2 beta;
+  GammaPows gp;
+  E2* terms;         // n x L: mult / message
+  E2* rowsum;        // n
+};
+
+}  // namespace msamd

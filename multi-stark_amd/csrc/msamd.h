@@ -206,6 +206,7 @@ void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, cons
 Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks);
 
 // ---------------------------------------------------------------- lookup.hip
+struct JitKernel;
 // device-resident LookupValues of one circuit (row-major as the reference stores them)
 struct DLookups {
   size_t height = 0, num_lookups = 0, args_width = 0;
@@ -214,9 +215,10 @@ struct DLookups {
 };
 // stage-2 trace of one circuit: writes column-major (n x max(L,1)*2) with rows bit-reversed (ready for the
 // inverse DIT); returns the circuit's total contribution sum_{r,j} mult/msg
-E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev);
+E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev, const JitKernel* jit = nullptr);
 // launches only: the contribution is left in *total_dev (device memory)
-void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev);
+void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev,
+                        const JitKernel* jit = nullptr);
 void claims_accumulator_async(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma,
                               E2* out_dev);
 E2 claims_accumulator(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma);

@@ -24,6 +24,10 @@ struct QParams;
 void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
                         const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out);
 void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq);
+// the circuit's stage-2 terms kernel (messages, batch inverse, mult / message) for its list of argument counts
+struct Stage2Params;
+void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out);
+void stage2_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2Params& p);
 
 // lookup values of SystemWitness::from_stage_1 on the device; false = prefix too large for the LDS slot file
 bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, const u64* d_pre, size_t h, size_t main_w,

@@ -259,6 +259,11 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
     build_program(ctx, c.nodes, c.zeros, c.lookups, c.prog);
     quotient_jit_build(c.nodes, c.zeros, c.lookups, c.prog.jit);  // the circuit's own kernel, from hiprtc or the cache
     {
+      std::vector<uint32_t> counts;
+      for (auto& l : c.lookups) counts.push_back((uint32_t)l.second.size());
+      stage2_jit_build(counts, c.stage2_jit);
+    }
+    {
       // the lookup prefix may only read trace columns and row selectors (src/graph.rs: Stage2InBaseContext; publics
       // do not exist at witness time); anything else keeps the host sweep, which reports the error
       bool ok = !c.lookups.empty();
@@ -1097,7 +1102,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     const HCircuit& c = sys.circuits[ci];
     size_t n = wit.heights[ci];
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
-    stage2_build_async(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
+    stage2_build_async(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos, &c.stage2_jit);
   }
   lap(1);
   t0 = now_ms();

@@ -18,6 +18,7 @@
 #include <sstream>
 
 #include "host.h"
+#include "lookup_params.h"
 #include "quotient_params.h"
 
 namespace msamd {
@@ -207,7 +208,7 @@ const std::vector<char>* code_object(const std::string& src) {
   const std::string dir = library_dir();
   // the headers are part of the program: a change to the field arithmetic must not reuse old code objects
   u64 h = fnv1a(src, 1469598103934665603ULL);
-  for (const char* hdr : {"/csrc/gl_dev.h", "/csrc/quotient_params.h"}) {
+  for (const char* hdr : {"/csrc/gl_dev.h", "/csrc/quotient_params.h", "/csrc/lookup_params.h"}) {
     std::vector<char> t;
     if (read_file(dir + hdr, t)) h = fnv1a(std::string(t.begin(), t.end()), h);
   }
@@ -233,7 +234,7 @@ const std::vector<char>* code_object(const std::string& src) {
     rtc.log_size(prog, &ls);
     std::string log(ls, 0);
     if (ls) rtc.get_log(prog, &log[0]);
-    fprintf(stderr, "[msamd] hiprtc could not compile a quotient kernel (the interpreter kernel is used instead):\n%s\n", log.c_str());
+    fprintf(stderr, "[msamd] hiprtc could not compile a circuit kernel (the generic kernel is used instead):\n%s\n", log.c_str());
     rtc.destroy(&prog);
     return nullptr;
   }
@@ -259,13 +260,9 @@ JitKernel::~JitKernel() {
   if (module) (void)hipModuleUnload((hipModule_t)module);
 }
 
-// Compiles (or fetches) the circuit's kernel; leaves `out` empty when the interpreter should be used.
-void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
-                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out) {
-  if (getenv("MSAMD_NO_JIT")) return;
-  if (nodes.size() > 6000) return;  // compile time grows faster than the interpreter's overhead is worth
-  const std::string src = circuit_source(nodes, zeros, lookups);
-  const std::vector<char>* co = code_object(src);
+namespace {
+// module + function from a code object; leaves `out` empty on any failure
+void load_kernel(const std::vector<char>* co, const char* name, JitKernel& out) {
   if (!co) return;
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
@@ -273,13 +270,91 @@ void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint3
     (void)hipGetLastError();
     return;
   }
-  if (hipModuleGetFunction(&fn, mod, "quotient_jit") != hipSuccess) {
+  if (hipModuleGetFunction(&fn, mod, name) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipModuleUnload(mod);
     return;
   }
   out.module = mod;
   out.function = fn;
+}
+
+// Stage-2 terms pass (LookupValues::stage_2_traces, /root/reference/src/lookup.rs:472-543, up to the running sum) for one
+// list of argument counts: the row's multiplicities and arguments are loaded up front (16-byte loads where the row
+// stride allows), every fingerprint is an unrolled lazy dot product with the gamma powers, the messages are inverted
+// 16 at a time with one base-field inversion.
+std::string stage2_source(const std::vector<uint32_t>& counts) {
+  const size_t L = counts.size();
+  size_t aw = 0;
+  for (auto c : counts) aw += c;
+  std::ostringstream o;
+  o << "#include \"lookup_params.h\"\nusing namespace msamd;\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void stage2_terms_jit(Stage2Params p) {\n"
+       "  const size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;\n"
+       "  if (r >= p.n) return;\n"
+    << "  const u64* __restrict__ a = p.args + r * " << aw << ";\n"
+    << "  const u64* __restrict__ m = p.mult + r * " << L << ";\n";
+  if (aw % 2 == 0) {
+    for (size_t k = 0; k < aw; k += 2)
+      o << "  const ulonglong2 q" << k << " = reinterpret_cast<const ulonglong2*>(a)[" << k / 2 << "]; const u64 a" << k << " = q" << k
+        << ".x, a" << k + 1 << " = q" << k << ".y;\n";
+  } else {
+    for (size_t k = 0; k < aw; k++) o << "  const u64 a" << k << " = a[" << k << "];\n";
+  }
+  for (size_t j = 0; j < L; j++) o << "  const u64 m" << j << " = m[" << j << "];\n";
+  o << "  E2 s = e2(0);\n  E2* __restrict__ trow = p.terms + r * " << L << ";\n";
+  size_t off = 0;
+  std::vector<size_t> offs;
+  for (auto c : counts) {
+    offs.push_back(off);
+    off += c;
+  }
+  for (size_t j0 = 0; j0 < L; j0 += 16) {
+    const size_t cnt = std::min<size_t>(16, L - j0);
+    o << "  {\n    E2 msg[16];\n";
+    for (size_t t = 0; t < cnt; t++) {
+      const size_t j = j0 + t;
+      o << "    { GlAcc g0, g1; acc_init(g0); acc_init(g1);\n";
+      for (size_t k = 0; k < counts[j]; k++)
+        o << "      acc_mad(g0, a" << offs[j] + k << ", p.gp.g[" << k << "].c0); acc_mad(g1, a" << offs[j] + k << ", p.gp.g[" << k << "].c1);\n";
+      o << "      msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.beta.c0), gl_add(acc_reduce(g1), p.beta.c1)); }\n";
+    }
+    o << "    e2_batch_inverse<16>(msg, " << cnt << ");\n";
+    for (size_t t = 0; t < cnt; t++) {
+      const size_t j = j0 + t;
+      o << "    { const E2 v = e2_mul_base(msg[" << t << "], m" << j << "); trow[" << j << "] = v; s = e2_add(s, v); }\n";
+    }
+    o << "  }\n";
+  }
+  o << "  p.rowsum[r] = s;\n}\n";
+  return o.str();
+}
+}  // namespace
+
+// Compiles (or fetches) the circuit's kernel; leaves `out` empty when the interpreter should be used.
+void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out) {
+  if (getenv("MSAMD_NO_JIT")) return;
+  if (nodes.size() > 6000) return;  // compile time grows faster than the interpreter's overhead is worth
+  load_kernel(code_object(circuit_source(nodes, zeros, lookups)), "quotient_jit", out);
+}
+
+void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out) {
+  if (getenv("MSAMD_NO_JIT") || arg_counts.empty() || arg_counts.size() > 256) return;
+  size_t aw = 0;
+  for (auto c : arg_counts) {
+    if (c > (uint32_t)MAX_GPOW) return;  // the generic kernel's Horner path handles very long argument lists
+    aw += c;
+  }
+  if (aw > 1024) return;
+  load_kernel(code_object(stage2_source(arg_counts)), "stage2_terms_jit", out);
+}
+
+void stage2_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2Params& p) {
+  Stage2Params copy = p;
+  size_t size = sizeof(Stage2Params);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((p.n + 255) / 256), 1, 1, 256, 1, 1, 0, ctx.stream, nullptr, config));
 }
 
 void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq) {
