@@ -65,10 +65,27 @@ __device__ __forceinline__ void hash_row(const MatRef* g, size_t H, size_t row, 
   u32 stack_len = 0;
   u64 chunk = 0;
   u32 nvalid = 0;
+  // software pipeline: the loads of block b + 1 are issued before block b is compressed
+  u64 nxt[8];
+  {
+    const u32 nv = total_w < 8 ? total_w : 8;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) nxt[j] = j < nv ? it.next() : 0;
+  }
   for (u32 base = 0; base < total_w; base += 8) {
-    if (base > 0) {
+    nvalid = total_w - base < 8 ? total_w - base : 8;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+      m[2 * j] = (u32)nxt[j];
+      m[2 * j + 1] = (u32)(nxt[j] >> 32);
+    }
+    if (base + 8 < total_w) {
+      const u32 rem = total_w - base - 8;
+      const u32 nv = rem < 8 ? rem : 8;
+#pragma unroll
+      for (u32 j = 0; j < 8; j++) nxt[j] = j < nv ? it.next() : 0;
       // the block in m is full and more input follows
-      u32 bic = ((base >> 3) - 1) & 15;  // index of that block within its chunk
+      u32 bic = (base >> 3) & 15;  // index of this block within its chunk
       u32 flags = bic == 0 ? B3_CHUNK_START : 0;
       if (MULTI && bic == 15) {
         b3_compress(cv, m, chunk, 64, flags | B3_CHUNK_END);
@@ -91,13 +108,6 @@ __device__ __forceinline__ void hash_row(const MatRef* g, size_t H, size_t row, 
       } else {
         b3_compress(cv, m, chunk, 64, flags);
       }
-    }
-    nvalid = total_w - base < 8 ? total_w - base : 8;
-#pragma unroll
-    for (u32 j = 0; j < 8; j++) {
-      u64 v = j < nvalid ? it.next() : 0;
-      m[2 * j] = (u32)v;
-      m[2 * j + 1] = (u32)(v >> 32);
     }
   }
   u32 nblocks = (total_w + 7) >> 3;

@@ -80,11 +80,21 @@ __global__ __launch_bounds__(256) void stage2_write_k(const E2* __restrict__ ter
   if (rr >= n) return;
   const size_t r = bitrev64(rr, logn);
   E2 run = rowprefix[r];
-  const E2* trow = terms + r * L;
-  for (u32 j = 0; j < L; j++) {
-    out[size_t(2 * j) * n + rr] = run.c0;
-    out[size_t(2 * j + 1) * n + rr] = run.c1;
-    run = e2_add(run, trow[j]);
+  const E2* __restrict__ trow = terms + r * L;
+  // eight terms in flight per thread: the row sits at a scattered address, so its loads must not wait for the sums
+  for (u32 j0 = 0; j0 < L; j0 += 8) {
+    E2 tv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) tv[k] = j0 + k < L ? trow[j0 + k] : e2(0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32 j = j0 + k;
+      if (j < L) {
+        out[size_t(2 * j) * n + rr] = run.c0;
+        out[size_t(2 * j + 1) * n + rr] = run.c1;
+        run = e2_add(run, tv[k]);
+      }
+    }
   }
 }
 
