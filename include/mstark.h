@@ -14,6 +14,7 @@
  *   ms_system_*    System::new + ProverKey                      src/system.rs:115-203 (preprocessed commit :190-195)
  *   ms_witness_*   SystemWitness / from_stage_1                 src/system.rs:225-328
  *   ms_prove       System::prove_multiple_claims                src/prover.rs:290-603
+ *   ms_verify      System::verify_multiple_claims               src/verifier.rs:208-532
  *   ms_prove_sharded   the same proof computed by several GPUs  src/prover.rs:290-603 (commit/open calls :350,419,526,580)
  *   ms_dft_batch   Radix2DitParallel::dft_batch                 src/prover.rs:650,716 (type fixed at :440)
  *   ms_coset_lde_batch  the LDE inside Pcs::commit              src/prover.rs:350,419; layout pinned by :975-999
@@ -86,6 +87,20 @@ void ms_witness_destroy(ms_witness* w);
  * the reference's span names (src/prover.rs:336-538). Returns MS_ERR_BUFFER with *proof_len = needed size if
  * cap is too small. */
 int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms);
+
+/* ---- System::verify_multiple_claims (src/verifier.rs:208-532; shape checks :536-695) on the bytes ms_prove wrote.
+ * Returns MS_OK when the check ran; *verdict = 0 if the proof is accepted, else the reference's VerificationError
+ * variant (src/verifier.rs:176-192): 2 InvalidOpeningArgument, 3 InvalidProofShape, 4 InvalidSystem,
+ * 5 OodEvaluationMismatch, 6 UnbalancedChannel. Claims as in ms_witness_create. The claims part (transcript hash and
+ * initial accumulator) runs on the device, the rest on the host. */
+#define MS_VERDICT_ACCEPT 0
+#define MS_VERDICT_INVALID_OPENING 2
+#define MS_VERDICT_INVALID_SHAPE 3
+#define MS_VERDICT_INVALID_SYSTEM 4
+#define MS_VERDICT_OOD_MISMATCH 5
+#define MS_VERDICT_UNBALANCED 6
+int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets, const uint64_t* claim_data,
+                  const uint8_t* proof, size_t proof_len, int32_t* verdict);
 
 /* ---- One proof over several GPUs (one process per GPU; SURVEY §8e, BASELINE config 3). The reference has no such
  * mode: this is System::prove_multiple_claims (src/prover.rs:290-603) with the Pcs::commit / Pcs::open calls

@@ -43,7 +43,7 @@ def exported_symbols():
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create",
-            "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
+            "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_stage2_trace", "ms_claims_accumulator",
             "ms_quotient_values", "ms_field_op"]
 
@@ -302,6 +302,19 @@ class System:
             return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
 
     prove = prove_multiple_claims
+
+    def verify_multiple_claims(self, claims_packed, proof) -> int:
+        """`System::verify_multiple_claims`: 0 = accepted, else the VerificationError code (2 opening, 3 shape, 4 system,
+        5 out-of-domain mismatch, 6 unbalanced channel). `proof`: bytes or a Proof."""
+        data = proof.to_bytes() if isinstance(proof, Proof) else bytes(proof)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        offs, cd = claims_packed
+        cd = cd if cd.size else np.zeros(1, dtype=np.uint64)
+        verdict = C.c_int32(-1)
+        _check(lib().ms_verify(self.h, C.c_size_t(len(offs) - 1), _p(offs), _p(cd), _b(buf), C.c_size_t(len(data)), C.byref(verdict)))
+        return int(verdict.value)
+
+    verify = verify_multiple_claims
 
     def prove_sharded(self, witness, comm, owners, want_times=False):
         """The same Proof computed by `comm.world` ranks (ms_prove_sharded; see multi-stark_amd/sharded.py for `comm`).

@@ -170,6 +170,15 @@ int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, con
   MS_CATCH
 }
 
+int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets, const uint64_t* claim_data, const uint8_t* proof,
+                  size_t proof_len, int32_t* verdict) {
+  MS_TRY if (!verdict || !proof || !claim_offsets) throw std::runtime_error("ms_verify: null argument");
+  if (claim_offsets[0] != 0) throw std::runtime_error("claim offsets must start at 0");
+  *verdict = verify(*sys->sys, n_claims, claim_offsets, claim_data, proof, proof_len);
+  return MS_OK;
+  MS_CATCH
+}
+
 int32_t ms_dft_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, int32_t inverse, uint64_t* out) {
   MS_TRY Ctx& ctx = c->ctx;
   check_pow2(h);

@@ -112,6 +112,9 @@ typedef ms_comm ms_comm_t;
 // the same proof computed by `comm->world` ranks (prover_sharded.inc)
 std::vector<uint8_t> prove_sharded(HSystem& sys, HWitness& w, const ms_comm_t* comm, const int32_t* owners, StageMs* times);
 
+// System::verify_multiple_claims (verifier.hip): 0 = accepted, otherwise the VerificationError code of include/mstark.h
+int verify(HSystem& sys, size_t n_claims, const u64* claim_offsets, const u64* claim_data, const uint8_t* proof, size_t proof_len);
+
 void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out);
 void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out);
 

@@ -19,6 +19,7 @@ def _prove_both(pkg, ctx, oracle, fe, inputs, params, traces, claims, lookups_fr
     w = g.witness(traces, packed, lookups)
     proof = g.prove_multiple_claims(w).to_bytes()
     assert o.verify(packed, proof) == 0
+    assert g.verify_multiple_claims(packed, proof) == 0  # the product's own verifier (ms_verify) agrees
     want = o.prove(traces, packed)
     assert proof == want
     return g, o, packed, proof
@@ -147,3 +148,39 @@ def test_config5_two_pow_26_verifies(pkg, ctx, oracle, fe):
     assert o.verify(packed, proof) == 0
     del w
     ctx.trim()
+
+
+# ms_verify against the oracle verifier: same verdict on the untouched proof, on wrong claims and on corrupted bytes
+# all over the proof (commitments, accumulators, FRI data, opened values)
+def test_product_verifier_agrees_with_oracle(pkg, ctx, oracle, fe):
+    traces, claims = fe.u32_add_bench_witness(1 << 9)
+    g, o, packed, proof = _prove_both(pkg, ctx, oracle, fe, fe.u32_add_system_inputs(), fe.bench_params(), traces, claims)
+    bad = claims.copy()
+    bad[7, 2] ^= 1
+    assert g.verify(fe.pack_claims(bad), proof) == o.verify(fe.pack_claims(bad), proof) != 0
+    assert g.verify(fe.pack_claims(claims[:-1]), proof) != 0
+    rng = np.random.default_rng(5)
+    n = len(proof)
+    spots = [8, 10 + 8 + 5, 10 + 48 + 8 + 3, 150, n - 5, n // 2, n // 3] + [int(x) for x in rng.integers(0, n, 40)]
+    rejected = 0
+    for pos in spots:
+        t = bytearray(proof)
+        t[pos] ^= 1 << int(rng.integers(0, 8))
+        a, b = g.verify(packed, bytes(t)), o.verify(packed, bytes(t))
+        assert (a == 0) == (b == 0), (pos, a, b)
+        rejected += a != 0
+    assert rejected == len(spots)  # every single-bit corruption of these proofs is caught
+    assert g.verify(packed, proof[:-1]) == 3 and g.verify(packed, proof + b"\x00") == 3  # InvalidProofShape
+    assert g.verify(packed, b"") == 3
+
+
+# verification at the full bench size: the claims (42 MB of transcript, 2^20 inversions) are handled on the device
+def test_product_verifier_full_size(pkg, ctx, oracle, fe):
+    traces, claims = fe.u32_add_bench_witness(1 << 20)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    proof = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    assert g.verify(packed, proof) == 0
+    bad = claims.copy()
+    bad[99999, 1] ^= 4
+    assert g.verify(fe.pack_claims(bad), proof) != 0

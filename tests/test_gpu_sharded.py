@@ -57,6 +57,7 @@ def _worker(rank, world, port, log_adds, variant, q):
                 want = system.prove_multiple_claims(full).to_bytes()
                 assert proof == want, "sharded proof differs from the single-GPU proof"
                 assert oracle.System(system.blob).verify(packed, proof) == 0
+                assert system.verify_multiple_claims(packed, proof) == 0
             q.put((rank, hashlib.sha256(proof).hexdigest(), comm.bytes_moved))
         finally:
             dist.barrier()
