@@ -80,6 +80,10 @@ int32_t ms_system_circuit_info(const ms_system* sys, size_t circuit, uint64_t ou
 int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights,
                           const uint64_t* const* mult, const uint64_t* const* args, size_t n_claims,
                           const uint64_t* claim_offsets, const uint64_t* claim_data, ms_witness** out);
+/* The bench workload's witness and claims generated in HBM for the system [ByteTable, U32Add]: build_witness +
+ * build_claims of benches/multi_stark.rs:171-238 (two xorshift32 streams from a0, b0; the reference uses 0xdeadbeef,
+ * 0xcafebabe) followed by from_stage_1 on the device. Nothing crosses PCIe. */
+int32_t ms_witness_u32_add_bench(ms_system* sys, size_t num_adds, uint32_t a0, uint32_t b0, ms_witness** out);
 void ms_witness_destroy(ms_witness* w);
 
 /* ---- System::prove_multiple_claims (src/prover.rs:290-603). Writes Proof::to_bytes (src/prover.rs:241-248).

@@ -43,7 +43,7 @@ def exported_symbols():
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create",
-            "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
+            "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_stage2_trace", "ms_claims_accumulator",
             "ms_quotient_values", "ms_field_op"]
 
@@ -284,6 +284,13 @@ class System:
         h = C.c_void_p()
         _check(lib().ms_witness_create(self.h, tptr, _p(hs), mptr, aptr, C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(h)))
         return SystemWitness(h, int(hs.sum()), self)
+
+    def bench_witness_on_device(self, num_adds, a0=0xDEADBEEF, b0=0xCAFEBABE):
+        """The bench workload's witness and claims generated in HBM (benches/multi_stark.rs:171-238) for [ByteTable, U32Add]."""
+        h = C.c_void_p()
+        _check(lib().ms_witness_u32_add_bench(self.h, C.c_size_t(num_adds), C.c_uint32(a0), C.c_uint32(b0), C.byref(h)))
+        height = max(1, 1 << (num_adds - 1).bit_length())
+        return SystemWitness(h, 256 + height, self)
 
     def prove_multiple_claims(self, witness, want_times=False):
         cap = getattr(self, "_proof_cap", 1 << 21)

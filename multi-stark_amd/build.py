@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmstark_hip.so")
-SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "prover.hip", "verifier.hip", "capi.hip"]
+SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "prover.hip", "verifier.hip", "witness_gen.hip", "capi.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -143,6 +143,14 @@ int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const u
   return MS_OK;
   MS_CATCH
 }
+int32_t ms_witness_u32_add_bench(ms_system* sys, size_t num_adds, uint32_t a0, uint32_t b0, ms_witness** out) {
+  *out = nullptr;
+  MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
+  w->w = witness_u32_add_bench(*sys->sys, num_adds, a0, b0);
+  *out = w.release();
+  return MS_OK;
+  MS_CATCH
+}
 void ms_witness_destroy(ms_witness* w) { delete w; }
 
 int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms) {

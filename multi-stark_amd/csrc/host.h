@@ -104,6 +104,11 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
                                          const u64* const* args, size_t n_claims, const u64* claim_offsets,
                                          const u64* claim_data);
 
+// traces / claims already resident in HBM (from_stage_1 on the device); and the bench workload generated there
+std::unique_ptr<HWitness> witness_from_device(HSystem& sys, std::vector<DBuf<u64>>&& traces, const std::vector<size_t>& heights,
+                                              DBuf<u64>&& d_claim_offsets, DBuf<u64>&& d_claim_data, size_t n_claims, size_t claim_elems);
+std::unique_ptr<HWitness> witness_u32_add_bench(HSystem& sys, size_t num_adds, u32 a0, u32 b0);
+
 struct StageMs {
   double v[6] = {0, 0, 0, 0, 0, 0};
 };

@@ -341,6 +341,50 @@ void sweep_prefix(const HCircuit& c, const u64* pre_cur, const u64* pre_next, co
 }
 }  // namespace
 
+// A witness whose traces and claims are already in HBM (witness_gen.hip): SystemWitness::from_stage_1 runs on the device.
+std::unique_ptr<HWitness> witness_from_device(HSystem& sys, std::vector<DBuf<u64>>&& traces, const std::vector<size_t>& heights,
+                                              DBuf<u64>&& d_claim_offsets, DBuf<u64>&& d_claim_data, size_t n_claims, size_t claim_elems) {
+  Ctx& ctx = *sys.ctx;
+  const size_t C = sys.circuits.size();
+  if (traces.size() != C || heights.size() != C) throw std::runtime_error("expected one trace per circuit");
+  std::unique_ptr<HWitness> w(new HWitness());
+  w->sys = &sys;
+  w->heights = heights;
+  w->traces = std::move(traces);
+  w->lookups.resize(C);
+  for (size_t ci = 0; ci < C; ci++) {
+    const HCircuit& c = sys.circuits[ci];
+    const size_t h = heights[ci];
+    if (h == 0) continue;
+    if (h & (h - 1)) throw std::runtime_error("trace height must be a power of two");
+    if (log2_strict(h) > NTT_MAX_LOG || log2_strict(h) + sys.params.log_blowup > TW_LOG)
+      throw std::runtime_error("trace height exceeds the supported maximum");
+    if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    DLookups& lk = w->lookups[ci];
+    lk.height = h;
+    lk.num_lookups = c.num_lookups;
+    lk.args_width = c.args_width;
+    if (c.num_lookups == 0) continue;
+    std::vector<uint32_t> offs(1, 0);
+    for (auto& l : c.lookups) offs.push_back(offs.back() + (uint32_t)l.second.size());
+    lk.arg_offsets = DBuf<uint32_t>(ctx, offs.size());
+    ctx.h2d(lk.arg_offsets.p, offs.data(), offs.size() * 4);
+    lk.mult = DBuf<u64>(ctx, h * c.num_lookups);
+    lk.args = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
+    if (!c.prefix_on_device || !lookup_values_device(ctx, c.prefix_prog, w->traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h,
+                                                     c.main_width, c.pre_width, c.args_width, lk.mult.p, lk.args.p))
+      throw std::runtime_error("device-resident witness: this circuit's lookup prefix does not fit the device sweep");
+    ctx.sync();
+  }
+  w->claim_offsets.resize(n_claims + 1);
+  w->claim_data.resize(claim_elems);
+  ctx.d2h(w->claim_offsets.data(), d_claim_offsets.p, (n_claims + 1) * 8);
+  if (claim_elems) ctx.d2h(w->claim_data.data(), d_claim_data.p, claim_elems * 8);
+  w->d_claim_offsets = std::move(d_claim_offsets);
+  w->d_claim_data = std::move(d_claim_data);
+  return w;
+}
+
 std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces, const u64* heights, const u64* const* mult,
                                          const u64* const* args, size_t n_claims, const u64* claim_offsets, const u64* claim_data) {
   Ctx& ctx = *sys.ctx;
