@@ -189,6 +189,7 @@ int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets
 
 int32_t ms_dft_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, int32_t inverse, uint64_t* out) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   check_pow2(h);
   if (w == 0) return MS_OK;
   unsigned logn = log2_strict(h);
@@ -202,6 +203,7 @@ int32_t ms_dft_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, int32_t 
 
 int32_t ms_coset_lde_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, uint32_t log_blowup, uint64_t* out) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   check_pow2(h);
   if (w == 0) return MS_OK;
   unsigned logn = log2_strict(h);
@@ -217,6 +219,7 @@ int32_t ms_coset_lde_batch(ms_ctx* c, const uint64_t* in, size_t h, size_t w, ui
 int32_t ms_quotient_lde(ms_ctx* c, const uint64_t* in, uint32_t log_n, uint32_t log_q, uint32_t log_blowup, size_t D,
                         uint64_t* out) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   size_t nq = size_t(1) << (log_n + log_q);
   if (log_n + log_q > NTT_MAX_LOG || log_n + log_blowup > TW_LOG) throw std::runtime_error("matrix too tall");
   DBuf<u64> col = upload_colmajor(ctx, in, nq, D, true);  // storage (bit-reversed) order, as the quotient kernel writes
@@ -232,6 +235,7 @@ int32_t ms_mmcs_commit(ms_ctx* c, size_t n, const uint64_t* const* mats, const u
                        uint32_t cap_height, uint8_t* cap_out, ms_mmcs** out) {
   *out = nullptr;
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   std::unique_ptr<ms_mmcs> m(new ms_mmcs());
   m->ctx = &ctx;
   std::vector<DMat> ms;
@@ -282,6 +286,7 @@ void ms_mmcs_destroy(ms_mmcs* m) { delete m; }
 
 int32_t ms_blake3(ms_ctx* c, const uint8_t* bytes, size_t len, uint8_t out32[32]) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   size_t pl = len & 7, nw = len >> 3;
   DBuf<uint8_t> pre(ctx, 8);
   DBuf<u64> words(ctx, std::max<size_t>(nw, 1));
@@ -297,6 +302,7 @@ int32_t ms_stage2_trace(ms_ctx* c, size_t height, size_t L, const uint64_t* mult
                         const uint64_t* args, const uint64_t beta[2], const uint64_t gamma[2], const uint64_t acc_in[2],
                         uint64_t* trace_out, uint64_t acc_out[2]) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   check_pow2(height);
   DLookups lk;
   lk.height = height;
@@ -324,6 +330,7 @@ int32_t ms_stage2_trace(ms_ctx* c, size_t height, size_t L, const uint64_t* mult
 int32_t ms_claims_accumulator(ms_ctx* c, size_t n_claims, const uint64_t* offs, const uint64_t* data, const uint64_t beta[2],
                               const uint64_t gamma[2], uint64_t acc_out[2]) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   size_t tot = n_claims ? offs[n_claims] : 0;
   DBuf<u64> d_offs(ctx, n_claims + 1), d_data(ctx, std::max<size_t>(tot, 1));
   ctx.h2d(d_offs.p, offs, (n_claims + 1) * 8);
@@ -365,6 +372,7 @@ int32_t ms_quotient_values(ms_system* sys, size_t ci, const uint64_t publics8[8]
 
 int32_t ms_field_op(ms_ctx* c, int32_t op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
   MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   size_t words = op >= 4 ? 2 * n : n;
   DBuf<u64> da(ctx, words), db(ctx, words), dout(ctx, words);
   ctx.h2d(da.p, a, words * 8);

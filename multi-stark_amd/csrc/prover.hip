@@ -152,6 +152,7 @@ static DMat lde_of_host_matrix(Ctx& ctx, const u64* rowmajor_dev, size_t h, size
 }
 
 std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t len) {
+  HIP_CHECK(hipSetDevice(ctx.device));  // kernels, modules and pool blocks of this system belong to the context's device
   Reader rd{blob, len};
   if (rd.word() != BLOB_MAGIC) throw std::runtime_error("bad system blob magic");
   std::unique_ptr<HSystem> sys(new HSystem());
@@ -388,6 +389,7 @@ std::unique_ptr<HWitness> witness_from_device(HSystem& sys, std::vector<DBuf<u64
 std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces, const u64* heights, const u64* const* mult,
                                          const u64* const* args, size_t n_claims, const u64* claim_offsets, const u64* claim_data) {
   Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
   std::unique_ptr<HWitness> w(new HWitness());
   w->sys = &sys;
   size_t C = sys.circuits.size();
