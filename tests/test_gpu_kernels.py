@@ -129,7 +129,8 @@ def _systems(pkg, ctx, oracle, fe, inputs, params):
     return g, oracle.System(g.blob)
 
 
-@pytest.mark.parametrize("which,log_n", [("pyth", 2), ("pyth", 6), ("evenodd", 2), ("evenodd", 5), ("u32", 3), ("u32", 8), ("u32", 12)])
+@pytest.mark.parametrize("which,log_n", [("pyth", 2), ("pyth", 6), ("evenodd", 2), ("evenodd", 5), ("u32", 3), ("u32", 8), ("u32", 12),
+                                         ("u32", 20)])
 def test_quotient_values(pkg, ctx, oracle, fe, which, log_n):
     rng = np.random.default_rng(log_n)
     inputs = {"pyth": fe.pythagorean_inputs, "evenodd": fe.even_odd_inputs, "u32": fe.u32_add_system_inputs}[which]()
@@ -149,3 +150,35 @@ def test_quotient_values(pkg, ctx, oracle, fe, which, log_n):
         want = oracle.quotient_values(o, ci, publics, ln, lq, pre, s1, s2, alpha)
         got = g.quotient_values(ci, publics, ln, lq, pre, s1, s2, alpha)
         assert np.array_equal(got, want)
+
+
+# ---- the same entry points at the bench's full sizes (config 2: 2^20-row traces, 2^22-row LDEs), still bit-exact against
+# the oracle: these are the launches bench.py times
+def test_full_size_coset_lde(ctx, oracle):
+    rng = np.random.default_rng(2020)
+    m = rand_field(rng, (1 << 20, 2))
+    assert np.array_equal(ctx.coset_lde_batch(m, 2), oracle.coset_lde_bitrev(m, 2))
+
+
+def test_full_size_merkle_tree(pkg, ctx, oracle):
+    rng = np.random.default_rng(2022)
+    mats = [rng.integers(0, P, (1 << 22, 14), dtype=np.uint64), rng.integers(0, P, (1024, 1), dtype=np.uint64)]
+    g = pkg.Mmcs(ctx, mats, 0)
+    o = oracle.Mmcs(mats, 0)
+    assert g.cap == o.cap
+    for index in (0, 1, (1 << 22) - 1, 1234567, 3 << 20):
+        gv, gp = g.open(index)
+        ov, op = o.open(index)
+        assert np.array_equal(gv, ov) and gp == op and len(gp) == 22 * 32
+
+
+def test_full_size_stage2_trace(ctx, oracle):
+    rng = np.random.default_rng(2021)
+    h, widths = 1 << 20, [4] + [2] * 12
+    offs = np.concatenate([[0], np.cumsum(widths)]).astype(np.uint64)
+    mult = rng.integers(0, 2, (h, 13), dtype=np.uint64)
+    args = rng.integers(0, 1 << 32, (h, int(offs[-1])), dtype=np.uint64)
+    beta, gamma = [int(x) for x in rng.integers(2, P, 2, dtype=np.uint64)], [int(x) for x in rng.integers(2, P, 2, dtype=np.uint64)]
+    gt, ga = ctx.stage2_trace(mult, offs, args, beta, gamma, [3, 9])
+    ot, oa = oracle.stage2_trace(mult, offs, args, beta, gamma, [3, 9])
+    assert ga == oa and np.array_equal(gt, ot)
