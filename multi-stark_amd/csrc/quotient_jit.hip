@@ -335,7 +335,7 @@ std::string stage2_source(const std::vector<uint32_t>& counts) {
 void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
                         const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out) {
   if (getenv("MSAMD_NO_JIT")) return;
-  if (nodes.size() > 6000) return;  // compile time grows faster than the interpreter's overhead is worth
+  if (nodes.size() > 3000) return;  // ~15 s of hiprtc and 200 KB of straight-line code: the interpreter is the better deal
   load_kernel(code_object(circuit_source(nodes, zeros, lookups)), "quotient_jit", out);
 }
 
