@@ -232,13 +232,17 @@ size_t claims_transcript_words(Ctx& ctx, const u64* d_claim_data, const u64* d_c
 struct JitKernel {
   void* module = nullptr;    // hipModule_t
   void* function = nullptr;  // hipFunction_t
+  bool inline_tables = false;  // quotient kernel: reads zh / zh_inv / alpha powers from the argument block
   JitKernel() {}
   JitKernel(const JitKernel&) = delete;
   JitKernel& operator=(const JitKernel&) = delete;
-  JitKernel(JitKernel&& o) noexcept : module(o.module), function(o.function) { o.module = o.function = nullptr; }
+  JitKernel(JitKernel&& o) noexcept : module(o.module), function(o.function), inline_tables(o.inline_tables) {
+    o.module = o.function = nullptr;
+  }
   JitKernel& operator=(JitKernel&& o) noexcept {
     std::swap(module, o.module);
     std::swap(function, o.function);
+    std::swap(inline_tables, o.inline_tables);
     return *this;
   }
   ~JitKernel();
@@ -288,7 +292,10 @@ struct DeepPoints {
   E2 K[2];              // sum over matrices opened at z_q of coeff * (sum_c alpha^c y_q[c])
 };
 // ro[i] = sum over matrices/points of coeff * (red_z - sum_c alpha^c m[i][c]) / (z - x_i)
-void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro);
+constexpr uint32_t DEEP_INLINE_MATS = 12, DEEP_INLINE_APOW = 64;
+// alpha_pows_host (optional): the same powers on the host; short lists then travel inside the kernel's argument block
+void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro,
+                 const E2* alpha_pows_host = nullptr);
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
 void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out);
 // Merkle tree of one FRI layer: leaf i = BLAKE3 of the 32-byte row (cur[2i], cur[2i+1]) (ExtensionMmcs flattening)

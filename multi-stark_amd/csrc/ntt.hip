@@ -12,6 +12,8 @@
 // final contiguous pass of <= 11 bits. The coset LDE is B independent size-n transforms of the coefficient
 // vector scaled by (g w_N^k0)^j / n (the first log2(B) stages of the zero-padded size-Bn transform are trivial),
 // with the scaling fused into the first pass' loads.
+#include <cstring>
+
 #include "msamd.h"
 
 namespace msamd {
@@ -529,9 +531,12 @@ __global__ void transpose_out_k(const u64* __restrict__ in, u64* __restrict__ ou
 
 // quotient: DFT output S (natural order, nq x D) -> per coset block b, slice k: pre-scaled coefficients
 //   lde[(k*D + c) * Bn + b*n + r] = S[c][(N - (k n + r)) mod N] * w_k * w_{Bn}^{bitrev_B(b) * r}
+struct WkTab {
+  u64 w[16];  // the q slice weights inside the argument block (q <= 16), so that no upload precedes the launch
+};
 __global__ void quotient_slice_k(const u64* __restrict__ S, u64* __restrict__ lde, unsigned logn, unsigned logq,
                                  unsigned lb, unsigned D, const u64* __restrict__ t0, const u64* __restrict__ t1,
-                                 const u64* __restrict__ wk /* q weights */) {
+                                 WkTab tab, const u64* __restrict__ wk /* q weights in device memory when q > 16, else null */) {
   const size_t n = size_t(1) << logn, N = n << logq, Bn = n << lb;
   size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // over r + n*(b + B*k)
   if (i >= (n << (lb + logq))) return;
@@ -543,7 +548,7 @@ __global__ void quotient_slice_k(const u64* __restrict__ S, u64* __restrict__ ld
   u32 k0 = bitrev32(b, lb);
   // w_{Bn}^{k0 r}: exponent modulo Bn, scaled to the order-2^26 table
   u64 e = (u64(k0) * r) & (Bn - 1);
-  u64 f = gl_mul(wk[k], tw_lookup(t0, t1, (u32)(e << (TW_LOG - logn - lb))));
+  u64 f = gl_mul(wk ? wk[k] : tab.w[k & 15], tw_lookup(t0, t1, (u32)(e << (TW_LOG - logn - lb))));
   for (unsigned c = 0; c < D; c++) lde[(size_t(k) * D + c) * Bn + (size_t(b) << logn) + r] = gl_mul(S[c * N + srcrow], f);
 }
 
@@ -618,11 +623,18 @@ void quotient_lde(Ctx& ctx, u64* qvals_bitrev, u64* lde, unsigned logn, unsigned
     wk[k] = gl_mul(cur, n_inv);
     cur = gl_mul(cur, step);
   }
-  DBuf<u64> dwk(ctx, q);
-  ctx.h2d(dwk.p, wk.data(), q * 8);
+  WkTab tab;
+  memset(&tab, 0, sizeof(tab));
+  DBuf<u64> dwk;
+  if (q <= 16) {
+    for (size_t k = 0; k < q; k++) tab.w[k] = wk[k];
+  } else {
+    dwk = DBuf<u64>(ctx, q);
+    ctx.h2d(dwk.p, wk.data(), q * 8);
+  }
   size_t total = n << (log_blowup + logq);
   hipLaunchKernelGGL(quotient_slice_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx.stream, qvals_bitrev, lde,
-                     logn, logq, log_blowup, (unsigned)D, ctx.tw0, ctx.tw1, dwk.p);
+                     logn, logq, log_blowup, (unsigned)D, ctx.tw0, ctx.tw1, tab, (const u64*)dwk.p);
   HIP_CHECK(hipGetLastError());
   // B independent size-n transforms per output column (q*D columns), src/prover.rs:716
   ntt_dif(ctx, lde, logn, (q * D) << log_blowup, false, nullptr, 1);

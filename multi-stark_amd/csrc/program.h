@@ -22,7 +22,7 @@ void build_program(Ctx& ctx, const std::vector<PNode>& nodes, const std::vector<
 // quotient_jit.hip: compile (or fetch from the cache) the circuit's own quotient kernel; launch it
 struct QParams;
 void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
-                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out);
+                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, size_t quotient_degree, JitKernel& out);
 void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq);
 // the circuit's stage-2 terms kernel (messages, batch inverse, mult / message) for its list of argument counts
 struct Stage2Params;

@@ -258,7 +258,7 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
     if (c.quotient_degree() > (size_t(1) << p.log_blowup))  // src/system.rs:171-178
       throw std::runtime_error("circuit " + std::to_string(ci) + ": constraint degree needs a quotient degree beyond the blowup");
     build_program(ctx, c.nodes, c.zeros, c.lookups, c.prog);
-    quotient_jit_build(c.nodes, c.zeros, c.lookups, c.prog.jit);  // the circuit's own kernel, from hiprtc or the cache
+    quotient_jit_build(c.nodes, c.zeros, c.lookups, c.quotient_degree(), c.prog.jit);  // the circuit's own kernel, from hiprtc or the cache
     {
       std::vector<uint32_t> counts;
       for (auto& l : c.lookups) counts.push_back((uint32_t)l.second.size());
@@ -656,8 +656,11 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   std::vector<E2> apow(gw + 1);
   apow[0] = e2(1);
   for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
-  DBuf<E2> d_apow(ctx, gw + 1);
-  ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
+  DBuf<E2> d_apow;  // only matrices wider than the kernel's inline table need the powers in device memory
+  if (gw > DEEP_INLINE_APOW) {
+    d_apow = DBuf<E2>(ctx, gw + 1);
+    ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
+  }
   // reduced openings per LDE height; the opening points of one height are numbered locally (at most two)
   std::vector<size_t> num_reduced(33, 0);
   std::vector<std::vector<DeepMat>> lists(33);
@@ -710,7 +713,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     if (lists[lh].empty())
       HIP_CHECK(hipMemsetAsync(ro.p, 0, h * sizeof(E2), ctx.stream));
     else
-      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p);
+      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p, apow.data());
     inputs.push_back(std::move(ro));
   }
   for (auto& d : dens) d.reset();

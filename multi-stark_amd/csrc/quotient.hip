@@ -361,11 +361,17 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
     arev[k - 1 - i] = ap;
     ap = e2_mul(ap, a.alpha);
   }
-  DBuf<u64> dzh(ctx, 2 * q);
-  DBuf<E2> darev(ctx, k);
-  ctx.h2d(dzh.p, zh.data(), q * 8);
-  ctx.h2d(dzh.p + q, zhi.data(), q * 8);
-  ctx.h2d(darev.p, arev.data(), k * sizeof(E2));
+  // the per-circuit kernels read these small tables from their argument block; the interpreter from device memory
+  const bool inl = prog.jit.function && prog.jit.inline_tables && q <= 8 && k <= QP_INLINE_ALPHA;
+  DBuf<u64> dzh;
+  DBuf<E2> darev;
+  if (!inl) {
+    dzh = DBuf<u64>(ctx, 2 * q);
+    darev = DBuf<E2>(ctx, std::max<size_t>(k, 1));
+    ctx.h2d(dzh.p, zh.data(), q * 8);
+    ctx.h2d(dzh.p + q, zhi.data(), q * 8);
+    ctx.h2d(darev.p, arev.data(), k * sizeof(E2));
+  }
 
   QParams p;
   p.pre = a.pre;
@@ -383,8 +389,18 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
   p.delta_scaled[1] = gl_mul(gl_sub(a.publics[7], a.publics[5]), inj_norm);
   p.g_inv = gl_inv(g);
   p.zh = dzh.p;
-  p.zh_inv = dzh.p + q;
+  p.zh_inv = dzh.p ? dzh.p + q : nullptr;
   p.alpha_rev = darev.p;
+  memset(p.zh_in, 0, sizeof(p.zh_in));
+  memset(p.zh_inv_in, 0, sizeof(p.zh_inv_in));
+  memset(p.alpha_rev_in, 0, sizeof(p.alpha_rev_in));
+  if (inl) {
+    for (size_t j = 0; j < 8; j++) {  // period q: any lane index masked with 7 lands on the right entry
+      p.zh_in[j] = zh[j % q];
+      p.zh_inv_in[j] = zhi[j % q];
+    }
+    for (size_t i = 0; i < k; i++) p.alpha_rev_in[i] = arev[i];
+  }
   p.code = prog.code.p;
   p.consts = prog.consts.p;
   p.zero_slots = prog.zero_slots.p;

@@ -25,9 +25,15 @@ namespace msamd {
 
 namespace {
 
+bool inline_tables_fit(size_t n_zeros, size_t n_lookups, size_t quotient_degree) {
+  // constraint count = user roots + 2 per lookup (2 for the pass-through when there is none): src/lookup.rs:90-99
+  return n_zeros + 2 * std::max<size_t>(n_lookups, 1) <= QP_INLINE_ALPHA && quotient_degree <= 8;
+}
+
 std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
-                           const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups) {
+                           const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, bool inl) {
   const size_t nn = nodes.size();
+  const char* AR = inl ? "p.alpha_rev_in" : "p.alpha_rev";
   std::vector<char> needed(nn, 0);
   for (auto z : zeros) needed[z] = 1;
   for (auto& l : lookups) {
@@ -53,7 +59,7 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
        "  const u32 e = i << (TW_LOG - lognq);\n"
        "  const u64 x = gl_mul_small(gl_mul(p.t1[e >> TW_HALF], p.t0[e & ((1u << TW_HALF) - 1)]), 7);\n"
        "  const u32 qi = i & ((1u << p.log_q) - 1);\n"
-       "  const u64 zh = p.zh[qi];\n"
+    << (inl ? "  const u64 zh = p.zh_in[qi & 7];\n" : "  const u64 zh = p.zh[qi];\n") <<
        "  const u64 d_first = gl_sub(x, 1), d_last = gl_sub(x, p.g_inv);\n"
        "  const u64 inv_both = gl_inv(gl_mul(d_first, d_last));\n"
        "  const u64 is_first = gl_mul(zh, gl_mul(inv_both, d_last));\n"
@@ -85,14 +91,14 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
   o << "  GlAcc fa0, fa1;\n  acc_init(fa0);\n  acc_init(fa1);\n";
   size_t ci = 0;
   for (auto z : zeros) {
-    o << "  { const E2 a = p.alpha_rev[" << ci << "]; acc_mad(fa0, v" << z << ", a.c0); acc_mad(fa1, v" << z << ", a.c1); }\n";
+    o << "  { const E2 a = " << AR << "[" << ci << "]; acc_mad(fa0, v" << z << ", a.c0); acc_mad(fa1, v" << z << ", a.c1); }\n";
     ci++;
   }
   o << "  const u64 beta0 = p.publics[0], beta1 = p.publics[1];\n"
        "  const u64 inj0 = gl_mul(is_last, p.delta_scaled[0]), inj1 = gl_mul(is_last, p.delta_scaled[1]);\n"
        "  (void)beta0; (void)beta1;\n";
   auto fold2 = [&](const std::string& c0, const std::string& c1) {
-    o << "  { const E2 a = p.alpha_rev[" << ci << "], b = p.alpha_rev[" << ci + 1 << "];\n"
+    o << "  { const E2 a = " << AR << "[" << ci << "], b = " << AR << "[" << ci + 1 << "];\n"
       << "    acc_mad(fa0, " << c0 << ", a.c0); acc_mad(fa0, " << c1 << ", b.c0);\n"
       << "    acc_mad(fa1, " << c0 << ", a.c1); acc_mad(fa1, " << c1 << ", b.c1); }\n";
     ci += 2;
@@ -136,7 +142,8 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
       fold2(c0.str(), c1.str());
     }
   }
-  o << "  const u64 iv = p.zh_inv[qi];\n"
+  o << (inl ? "  const u64 iv = p.zh_inv_in[qi & 7];\n" : "  const u64 iv = p.zh_inv[qi];\n")
+    <<
        "  p.out[t] = gl_mul(acc_reduce(fa0), iv);\n"
        "  p.out[nq + t] = gl_mul(acc_reduce(fa1), iv);\n}\n";
   return o.str();
@@ -333,10 +340,12 @@ std::string stage2_source(const std::vector<uint32_t>& counts) {
 
 // Compiles (or fetches) the circuit's kernel; leaves `out` empty when the interpreter should be used.
 void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
-                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out) {
+                        const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, size_t quotient_degree, JitKernel& out) {
   if (getenv("MSAMD_NO_JIT")) return;
   if (nodes.size() > 3000) return;  // ~15 s of hiprtc and 200 KB of straight-line code: the interpreter is the better deal
-  load_kernel(code_object(circuit_source(nodes, zeros, lookups)), "quotient_jit", out);
+  const bool inl = inline_tables_fit(zeros.size(), lookups.size(), quotient_degree);
+  load_kernel(code_object(circuit_source(nodes, zeros, lookups, inl)), "quotient_jit", out);
+  out.inline_tables = out.function && inl;
 }
 
 void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out) {

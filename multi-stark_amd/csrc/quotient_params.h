@@ -32,7 +32,12 @@ struct QParams {
   u64* scratch;       // global slot storage (when !LDS)
   size_t row0, rows;  // batch of storage rows handled by this launch
   E2 gpow[32];        // gamma^0 .. gamma^31: fingerprints as unreduced base x ext dot products
+  // the same three tables inside the argument block (no upload, scalar loads with literal offsets): what the
+  // per-circuit kernels read when the circuit has at most QP_INLINE_ALPHA constraints and quotient degree <= 8
+  u64 zh_in[8], zh_inv_in[8];
+  E2 alpha_rev_in[64];
 };
+constexpr unsigned QP_INLINE_ALPHA = 64;
 
 __device__ __forceinline__ void mul2(u64 a0, u64 a1, u64 b0, u64 b1, u64& c0, u64& c1) {
   u64 v0 = gl_mul(a0, b0), v1 = gl_mul(a1, b1);
