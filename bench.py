@@ -30,8 +30,8 @@ ALG_BYTES_PER_ROW = 5512
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-adds", type=int, default=20, help="log2 of U32 additions per proof (BASELINE: 20)")
     ap.add_argument("--cpu-log-adds", type=int, default=16, help="bounded sample for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -292,7 +292,6 @@ struct DeepPoints {
   E2 K[2];              // sum over matrices opened at z_q of coeff * (sum_c alpha^c y_q[c])
 };
 // ro[i] = sum over matrices/points of coeff * (red_z - sum_c alpha^c m[i][c]) / (z - x_i)
-constexpr uint32_t DEEP_INLINE_MATS = 12, DEEP_INLINE_APOW = 64;
 // alpha_pows_host (optional): the same powers on the host; short lists then travel inside the kernel's argument block
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro,
                  const E2* alpha_pows_host = nullptr);

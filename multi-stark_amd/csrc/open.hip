@@ -129,15 +129,12 @@ __global__ __launch_bounds__(64) void bary_final_k(const E2* __restrict__ partia
 }
 
 struct DeepParams {
-  const DeepMat* mats;  // device list, or null: mats_in
+  const DeepMat* mats;
   u32 nmats;
-  const E2* apow;       // device alpha powers, or null: apow_in
+  const E2* apow;
   DeepPoints pts;
   E2* ro;
   size_t height;
-  // the same two tables inside the argument block when they fit (no upload before the launch)
-  DeepMat mats_in[DEEP_INLINE_MATS];
-  E2 apow_in[DEEP_INLINE_APOW];
 };
 // ro[i] = sum_q den_q[i] * (K_q - sum_m coeff_{m,q} * s_m[i]),  s_m[i] = sum_c alpha^c m[i][c]
 // (= sum over matrices and points of coeff * (red_z - s_m[i]) / (z_q - x_i), regrouped by point so that the
@@ -152,9 +149,9 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
   for (int q = 0; q < 2; q++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc_init(T[q][j]);
-  const E2* __restrict__ apow = p.apow ? p.apow : p.apow_in;
+  const E2* __restrict__ apow = p.apow;
   for (u32 m = 0; m < p.nmats; m++) {
-    const DeepMat& dm = p.mats ? p.mats[m] : p.mats_in[m];
+    const DeepMat& dm = p.mats[m];
     // sum_c alpha^c * m[i][c]: base x ext terms, accumulated unreduced (one reduction per coordinate)
     GlAcc a00, a01, a10, a11;
     acc_init(a00);
@@ -648,28 +645,13 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
   for (auto& m : mats)
     for (u32 k = 0; k < m.npoints; k++)
       if (m.npoints > 2 || m.pt[k] >= pts.n) throw std::runtime_error("deep_reduce: bad point index");
-  DeepParams p;
-  memset(&p, 0, sizeof(p));
-  p.nmats = (u32)mats.size();
-  p.pts = pts;
-  p.ro = ro;
-  p.height = height;
-  size_t maxw = 0;
-  for (auto& m : mats) maxw = std::max<size_t>(maxw, m.w);
-  DBuf<DeepMat> dm;
-  if (mats.size() <= DEEP_INLINE_MATS) {
-    for (size_t i = 0; i < mats.size(); i++) p.mats_in[i] = mats[i];
-  } else {
-    dm = DBuf<DeepMat>(ctx, mats.size());
-    ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
-    p.mats = dm.p;
-  }
-  if (apow_host && maxw <= DEEP_INLINE_APOW) {
-    for (size_t i = 0; i < maxw; i++) p.apow_in[i] = apow_host[i];
-  } else {
-    if (!apow_dev) throw std::runtime_error("deep_reduce: alpha powers missing");
-    p.apow = apow_dev;
-  }
+  // (the matrix list and the alpha powers stay in device memory: indexed by a loop variable inside the kernel's
+  // argument block they cost more than the two small uploads save)
+  (void)apow_host;
+  if (!apow_dev) throw std::runtime_error("deep_reduce: alpha powers missing");
+  DBuf<DeepMat> dm(ctx, mats.size());
+  ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
+  DeepParams p{dm.p, (u32)mats.size(), apow_dev, pts, ro, height};
   double bytes = 16.0 * height * (1 + pts.n);
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);

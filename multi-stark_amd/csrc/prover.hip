@@ -656,11 +656,8 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   std::vector<E2> apow(gw + 1);
   apow[0] = e2(1);
   for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
-  DBuf<E2> d_apow;  // only matrices wider than the kernel's inline table need the powers in device memory
-  if (gw > DEEP_INLINE_APOW) {
-    d_apow = DBuf<E2>(ctx, gw + 1);
-    ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
-  }
+  DBuf<E2> d_apow(ctx, gw + 1);
+  ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
   // reduced openings per LDE height; the opening points of one height are numbered locally (at most two)
   std::vector<size_t> num_reduced(33, 0);
   std::vector<std::vector<DeepMat>> lists(33);
