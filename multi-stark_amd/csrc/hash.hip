@@ -403,6 +403,49 @@ __global__ __launch_bounds__(256) void cv_level_k(const Digest* __restrict__ pre
   }
 }
 
+// the last levels of the left-full tree (n <= 2048 chaining values) in one workgroup, one parent per quad: replaces a
+// dozen launches of cv_level_k whose grids have shrunk to a few hundred threads
+__global__ __launch_bounds__(1024) void cv_tail_k(const Digest* __restrict__ prev, Digest* __restrict__ out, u32 n) {
+  __shared__ __attribute__((aligned(16))) u32 sh[2048 * 8];
+  const u32 t = threadIdx.x;
+  for (u32 i = t; i < n; i += 1024) {
+    u32 d[8];
+    load_digest(prev + i, d);
+    lds_store_digest(sh, i, d);
+  }
+  __syncthreads();
+  const u32 quad = t >> 2, c = t & 3;
+  while (n > 1) {
+    const u32 nn = (n + 1) / 2;
+    const u32 flags = B3_PARENT | (n == 2 ? (u32)B3_ROOT : 0u);
+    u32 lo[4], hi[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      const u32 q = quad + 256 * ps;
+      if (q < nn) {
+        if (2 * q + 1 < n) {
+          b3_quad_compress_iv<false>(sh + 16 * q, 64, flags, lo[ps], hi[ps]);
+        } else {  // an odd last value moves up unchanged
+          lo[ps] = sh[16 * q + c];
+          hi[ps] = sh[16 * q + 4 + c];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+      const u32 q = quad + 256 * ps;
+      if (q < nn) {
+        sh[8 * q + c] = lo[ps];
+        sh[8 * q + 4 + c] = hi[ps];
+      }
+    }
+    __syncthreads();
+    n = nn;
+  }
+  if (t < 8) reinterpret_cast<u32*>(out)[t] = sh[t];
+}
+
 }  // namespace
 
 void merkle_alloc(Ctx& ctx, DTree& t, size_t maxh) {
@@ -567,6 +610,11 @@ Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks) {
   Digest* nxt = b.p;
   size_t n = nchunks;
   while (n > 1) {
+    if (n <= 2048) {  // the rest in one launch
+      hipLaunchKernelGGL(cv_tail_k, dim3(1), dim3(1024), 0, ctx.stream, (const Digest*)cur, nxt, (u32)n);
+      std::swap(cur, nxt);
+      break;
+    }
     size_t nn = (n + 1) / 2;
     hipLaunchKernelGGL(cv_level_k, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx.stream, cur, nxt, n,
                        n == 2 ? (u32)B3_ROOT : 0u);
