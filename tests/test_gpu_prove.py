@@ -201,3 +201,26 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
     assert got == want
     # padding rows push twelve zero bytes nobody pulls (true of the reference's generator too): only full traces balance
     assert g.verify(packed, got) == (0 if num_adds & (num_adds - 1) == 0 else 6)
+
+
+# every alternative code path selectable by environment variable must give the same proof bytes: host-driven FRI rounds,
+# host-side query step, no single-workgroup FRI tail, host sweep for the lookup values, interpreter kernels instead of
+# the hiprtc-compiled ones (the library reads these variables at call time)
+@pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT"])
+def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
+    import os
+
+    traces, claims = fe.u32_add_bench_witness(1 << 13)   # 2^15-row LDEs: FRI rounds above and inside the tail kernel
+    packed = fe.pack_claims(claims)
+    inputs, params = fe.u32_add_system_inputs(), fe.bench_params()
+    g = pkg.System.new(ctx, params, inputs)
+    want = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    assert oracle.System(g.blob).verify(packed, want) == 0
+    assert var not in os.environ
+    os.environ[var] = "1"
+    try:
+        g2 = pkg.System.new(ctx, params, inputs)           # MSAMD_NO_JIT acts at System::new
+        got = g2.prove_multiple_claims(g2.witness(traces, packed)).to_bytes()
+    finally:
+        del os.environ[var]
+    assert got == want
