@@ -1091,20 +1091,21 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
   }
-  std::vector<Digest> s1_cap = merkle_cap(ctx, s1.tree);
-  lap(0);
-
-  if (sys.has_pre) ch.observe_cap(sys.pre_commit);
-  ch.observe_cap(s1_cap);
-  for (unsigned ld : log_degrees) ch.observe(ld);
   // claims, length-prefixed (src/prover.rs:369-373). Large claim sets are hashed on the device: the transcript
   // since the last sample is `ch.input || words`, and the next operation is a sample, so the digest is all
-  // the challenger needs.
+  // the challenger needs. The stage-1 commitment is part of that prefix; it is patched in on the device, so the
+  // commitment and the digest come back in ONE synchronisation.
   const size_t n_claims = wit.claim_offsets.size() - 1;
   const size_t claim_elems = wit.claim_data.size();
   const size_t claim_words = 1 + n_claims + claim_elems;
   const bool device_claims = claim_words > 8192;
+  std::vector<Digest> s1_cap;
   if (!device_claims) {
+    s1_cap = merkle_cap(ctx, s1.tree);
+    lap(0);
+    if (sys.has_pre) ch.observe_cap(sys.pre_commit);
+    ch.observe_cap(s1_cap);
+    for (unsigned ld : log_degrees) ch.observe(ld);
     ch.observe((u64)n_claims);
     for (size_t i = 0; i < n_claims; i++) {
       size_t a = wit.claim_offsets[i], b = wit.claim_offsets[i + 1];
@@ -1112,11 +1113,21 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
       for (size_t k = a; k < b; k++) ch.observe(wit.claim_data[k]);
     }
   } else {
+    lap(0);
+    const size_t cl = s1.tree.cap_layer(), ncap = s1.tree.layer_len[cl];
+    const Digest* d_cap = s1.tree.base() + s1.tree.layer_off[cl];
+    s1_cap.assign(ncap, Digest());
+    if (sys.has_pre) ch.observe_cap(sys.pre_commit);
+    const size_t cap_off = ch.input.size();
+    ch.observe_cap(s1_cap);  // placeholder bytes: the real digests are copied over them on the device
+    for (unsigned ld : log_degrees) ch.observe(ld);
     DBuf<uint8_t> d_prefix(ctx, ch.input.size());
     ctx.h2d(d_prefix.p, ch.input.data(), ch.input.size());
+    HIP_CHECK(hipMemcpyAsync(d_prefix.p + cap_off, d_cap, ncap * sizeof(Digest), hipMemcpyDeviceToDevice, ctx.stream));
     DBuf<u64> d_words(ctx, claim_words);
     claims_transcript_words(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, claim_elems, d_words.p);
-    Digest d = blake3_device(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words);
+    ctx.d2h_queue(s1_cap.data(), d_cap, ncap * sizeof(Digest));
+    Digest d = blake3_device(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words);  // synchronises: s1_cap has arrived too
     ch.flush_with(d);
   }
   const E2 beta = ch.sample_ext();
