@@ -8,7 +8,9 @@
  * value is two consecutive u64 (c0, c1) — the layout `flatten_to_base` produces (src/prover.rs:417,495);
  * matrices cross the ABI row-major (what `RowMajorMatrix.values` holds); digests are 32 raw bytes.
  * The caller owns every host buffer for the duration of a call; the library owns device memory behind the
- * opaque handles below. A ms_ctx is bound to one HIP device and is not thread-safe.
+ * opaque handles below. A ms_ctx is bound to one HIP device and is not thread-safe. Handles may be destroyed in any
+ * order: a system keeps its context alive, a witness its system, an mmcs its context (the memory is released when the
+ * last dependent handle is destroyed).
  *
  * What each group replaces in /root/reference:
  *   ms_system_*    System::new + ProverKey                      src/system.rs:115-203 (preprocessed commit :190-195)

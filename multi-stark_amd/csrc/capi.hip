@@ -6,18 +6,38 @@
 
 using namespace msamd;
 
+// Handles keep what they depend on alive: a system holds a reference on its context, a witness on its system, an
+// mmcs on its context. Destroying a handle drops the owner's reference; the object goes away when the last dependent
+// is gone, so handles may be destroyed in any order (a garbage collector gives none). A context is single-threaded by
+// contract, so the counts are plain integers.
 struct ms_ctx {
   Ctx ctx;
+  int refs = 1;
   explicit ms_ctx(int dev) : ctx(dev) {}
 };
+static void ctx_unref(ms_ctx* c) {
+  if (c && --c->refs == 0) delete c;
+}
 struct ms_system {
+  ms_ctx* owner = nullptr;
   std::unique_ptr<HSystem> sys;
+  int refs = 1;
 };
+static void system_unref(ms_system* s) {
+  if (s && --s->refs == 0) {
+    ms_ctx* c = s->owner;
+    s->sys.reset();  // device buffers go back to the context's pool before the context may be deleted
+    delete s;
+    ctx_unref(c);
+  }
+}
 struct ms_witness {
+  ms_system* owner = nullptr;
   std::unique_ptr<HWitness> w;
 };
 struct ms_mmcs {
-  Ctx* ctx;
+  ms_ctx* owner = nullptr;
+  Ctx* ctx = nullptr;
   PcsData data;
 };
 
@@ -71,7 +91,7 @@ int32_t ms_ctx_create(int32_t device, ms_ctx** out) {
     return MS_ERR_NO_DEVICE;
   }
 }
-void ms_ctx_destroy(ms_ctx* ctx) { delete ctx; }
+void ms_ctx_destroy(ms_ctx* ctx) { ctx_unref(ctx); }
 int32_t ms_ctx_sync(ms_ctx* ctx) {
   MS_TRY ctx->ctx.sync();
   return MS_OK;
@@ -109,11 +129,13 @@ int32_t ms_system_create(ms_ctx* ctx, const uint8_t* blob, size_t len, ms_system
   *out = nullptr;
   MS_TRY std::unique_ptr<ms_system> s(new ms_system());
   s->sys = system_from_blob(ctx->ctx, blob, len);
+  s->owner = ctx;
+  ctx->refs++;
   *out = s.release();
   return MS_OK;
   MS_CATCH
 }
-void ms_system_destroy(ms_system* sys) { delete sys; }
+void ms_system_destroy(ms_system* sys) { system_unref(sys); }
 int32_t ms_system_preprocessed_commit(const ms_system* sys, uint8_t* out, size_t cap, size_t* n_digests) {
   MS_TRY const HSystem& s = *sys->sys;
   *n_digests = s.has_pre ? s.pre_commit.size() : 0;
@@ -139,6 +161,8 @@ int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const u
   *out = nullptr;
   MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
   w->w = witness_create(*sys->sys, traces, heights, mult, args, n_claims, claim_offsets, claim_data);
+  w->owner = sys;
+  sys->refs++;
   *out = w.release();
   return MS_OK;
   MS_CATCH
@@ -147,11 +171,19 @@ int32_t ms_witness_u32_add_bench(ms_system* sys, size_t num_adds, uint32_t a0, u
   *out = nullptr;
   MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
   w->w = witness_u32_add_bench(*sys->sys, num_adds, a0, b0);
+  w->owner = sys;
+  sys->refs++;
   *out = w.release();
   return MS_OK;
   MS_CATCH
 }
-void ms_witness_destroy(ms_witness* w) { delete w; }
+void ms_witness_destroy(ms_witness* w) {
+  if (!w) return;
+  ms_system* s = w->owner;
+  w->w.reset();
+  delete w;
+  system_unref(s);
+}
 
 int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms) {
   MS_TRY StageMs st;
@@ -250,6 +282,8 @@ int32_t ms_mmcs_commit(ms_ctx* c, size_t n, const uint64_t* const* mats, const u
   commit_matrices(ctx, std::move(ms), cap_height, m->data);
   std::vector<Digest> cap = merkle_cap(ctx, m->data.tree);
   for (size_t i = 0; i < cap.size(); i++) memcpy(cap_out + 32 * i, cap[i].b, 32);
+  m->owner = c;
+  c->refs++;
   *out = m.release();
   return MS_OK;
   MS_CATCH
@@ -282,7 +316,13 @@ int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proo
   return MS_OK;
   MS_CATCH
 }
-void ms_mmcs_destroy(ms_mmcs* m) { delete m; }
+void ms_mmcs_destroy(ms_mmcs* m) {
+  if (!m) return;
+  ms_ctx* c = m->owner;
+  m->data = PcsData();
+  delete m;
+  ctx_unref(c);
+}
 
 int32_t ms_blake3(ms_ctx* c, const uint8_t* bytes, size_t len, uint8_t out32[32]) {
   MS_TRY Ctx& ctx = c->ctx;

@@ -224,3 +224,23 @@ def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     finally:
         del os.environ[var]
     assert got == want
+
+
+# handles may die in any order (a garbage collector gives none): the library keeps a context alive while systems or
+# witnesses built on it exist
+def test_handles_survive_out_of_order_destruction(pkg, fe):
+    import gc
+
+    c = pkg.Context(0)
+    g = pkg.System.new(c, fe.bench_params(), fe.u32_add_system_inputs())
+    w = g.bench_witness_on_device(1 << 8)
+    want = g.prove_multiple_claims(w).to_bytes()
+    c.close()                      # the owner lets go of the context first
+    assert g.prove_multiple_claims(w).to_bytes() == want
+    h = w.h
+    w.h = None                     # detach so that the wrapper's own ordering cannot help
+    sysh = g.h
+    g.h = None
+    pkg.lib().ms_system_destroy(sysh)   # system before its witness
+    pkg.lib().ms_witness_destroy(h)     # last dependent: system and context are released here
+    gc.collect()
