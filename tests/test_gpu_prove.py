@@ -244,3 +244,51 @@ def test_handles_survive_out_of_order_destruction(pkg, fe):
     pkg.lib().ms_system_destroy(sysh)   # system before its witness
     pkg.lib().ms_witness_destroy(h)     # last dependent: system and context are released here
     gc.collect()
+
+
+# the reference's panics become error codes with a message (include/mstark.h), and the library stays usable afterwards:
+# src/prover.rs:323-326 (all circuits inactive), src/system.rs:249-264 (height mismatches), src/system.rs:171-178
+# (constraint degree above the blow-up), malformed blobs, non-canonical inputs, a too-small proof buffer
+def test_error_paths_return_codes_not_crashes(pkg, ctx, fe):
+    inputs, params = fe.u32_add_system_inputs(), fe.bench_params()
+    g = pkg.System.new(ctx, params, inputs)
+    traces, claims = fe.u32_add_bench_witness(1 << 6)
+    packed = fe.pack_claims(claims)
+    want = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    # every circuit inactive
+    empty = [np.zeros((0, 1), dtype=np.uint64), np.zeros((0, 14), dtype=np.uint64)]
+    with pytest.raises(pkg.MstarkError, match="deactivated"):
+        g.prove_multiple_claims(g.witness(empty, fe.pack_claims([])))
+    # preprocessed circuit with a trace of the wrong height; height not a power of two
+    with pytest.raises(pkg.MstarkError, match="preprocessed"):
+        g.witness([np.zeros((128, 1), dtype=np.uint64), traces[1]], packed)
+    with pytest.raises(pkg.MstarkError, match="power of two"):
+        g.witness([traces[0], traces[1][:48]], packed)
+    # non-canonical field elements in traces and claims
+    bad = traces[1].copy()
+    bad[3, 2] = np.uint64(0xFFFFFFFF00000001)
+    with pytest.raises(pkg.MstarkError, match="canonical"):
+        g.witness([traces[0], bad], packed)
+    offs, data = packed
+    badc = data.copy()
+    badc[5] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with pytest.raises(pkg.MstarkError, match="canonical"):
+        g.witness(traces, (offs, badc))
+    # malformed system blobs
+    blob = g.blob
+    for mutilated in (blob[:40], b"\x00" * 64, blob[:-8]):
+        with pytest.raises(pkg.MstarkError):
+            pkg.System(ctx, mutilated, 2)
+    # x^5 = y needs quotient degree 4 > blow-up 2 (src/system.rs:404-445)
+    def ev(b):
+        local, _ = b.main()
+        x = local[0]
+        b.assert_eq(x * x * x * x * x, local[1])
+    with pytest.raises(pkg.MstarkError, match="degree"):
+        pkg.System.new(ctx, fe.test_params(), [fe.lookup_air(2, ev, [])])
+    # a proof buffer that is too small is reported with the needed size and the call is repeated
+    g._proof_cap = 1000
+    assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
+    assert g._proof_cap == len(want)
+    # and nothing above left the library in a bad state
+    assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
