@@ -751,6 +751,11 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   // ---- FRI commit phase (prove_fri / commit_phase)
   const size_t final_len = size_t(1) << prm.log_final_poly_len;
   const size_t stop = (size_t(1) << lb) * final_len;
+  // p3-fri's prove_fri asserts, when the final polynomial has more than one coefficient, that even the shortest input
+  // is taller than blowup * final length: the reference panics there, this returns an error
+  if (prm.log_final_poly_len > 0)
+    for (auto& in : inputs)
+      if (in.n <= stop) throw std::runtime_error("FRI: a committed matrix is not taller than blowup * final polynomial length");
   std::vector<DBuf<E2>> layer_bufs;   // owners of the folded vectors kept for the query phase
   std::vector<const E2*> layers;      // input vector of every commit-phase round
   std::vector<DTree> trees;

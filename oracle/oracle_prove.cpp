@@ -538,6 +538,13 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
   size_t next_in = 1;
   unsigned log_max_height = log2_strict(folded.size());
   proof = FriProof();
+  // [UPSTREAM-RECALL p3-fri prove_fri] with log_final_poly_len > 0 the prover asserts that the SHORTEST input is taller
+  // than blowup * final length (a shorter one could never be folded into the final polynomial); refuse likewise
+  if (prm.log_final_poly_len > 0) {
+    size_t min_h = folded.size();
+    for (size_t k = 1; k < inputs.size(); k++) min_h = std::min(min_h, inputs[k].size());
+    if (min_h <= stop) throw std::runtime_error("FRI: a committed matrix is not taller than blowup * final polynomial length");
+  }
   while (folded.size() > stop) {
     size_t rows = folded.size() / 2;
     Mat leaves(rows, 4);  // ExtensionMmcs: width-2 extension rows flattened to 4 base columns

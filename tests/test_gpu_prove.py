@@ -292,3 +292,24 @@ def test_error_paths_return_codes_not_crashes(pkg, ctx, fe):
     assert g._proof_cap == len(want)
     # and nothing above left the library in a bad state
     assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
+
+
+# a seeded slice of tools/fuzz_parity.py: random systems (constraint graphs, lookups, preprocessed traces, inactive
+# circuits, ragged claims, PCS / FRI parameters); identical proof bytes and agreeing verifiers
+def test_random_systems_differential(pkg, ctx, oracle, fe):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+
+    os.environ["MSAMD_NO_JIT"] = "1"   # a new circuit per case: skip the hiprtc compile, the interpreter is the subject
+    try:
+        rng = np.random.default_rng(2026)
+        tally = {}
+        for case in range(120):
+            r = fuzz_parity.one_case(pkg, fe, oracle, ctx, np.random.default_rng(rng.integers(0, 1 << 62)), case)
+            tally[r] = tally.get(r, 0) + 1
+    finally:
+        del os.environ["MSAMD_NO_JIT"]
+    assert tally.get("proved", 0) + tally.get("verified", 0) >= 60, tally

@@ -1,0 +1,151 @@
+"""Differential fuzzing of the whole path: random systems (random constraint graphs, lookups, preprocessed traces,
+heights, inactive circuits, ragged claims, PCS/FRI parameters) proved by the HIP library and by the oracle; the proof
+bytes must be identical and the two verifiers must agree. The witnesses are random, so most proofs do not verify - that
+is irrelevant for parity: both provers must still emit the same bytes, and both verifiers the same verdict class.
+
+usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips the hiprtc compile of every new circuit)
+The oracle is used only as the checker."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from __graft_entry__ import load_package  # noqa: E402
+
+P = 0xFFFFFFFF00000001
+
+
+def rand_field(rng, shape):
+    v = rng.integers(0, P, shape, dtype=np.uint64)
+    edge = np.array([0, 1, 2, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1], dtype=np.uint64)
+    mask = rng.random(shape) < 0.15
+    return np.where(mask, edge[rng.integers(0, len(edge), shape)], v)
+
+
+def random_expr(rng, fe, atoms, depth, max_degree):
+    """(expr, degree) with degree <= max_degree"""
+    E = fe.Expr
+    if depth == 0 or rng.random() < 0.25:
+        k = rng.integers(0, len(atoms) + 1)
+        if k == len(atoms):
+            return E.const(int(rng.integers(0, P, dtype=np.uint64))), 0
+        return atoms[k], 1
+    op = rng.integers(0, 4)
+    a, da = random_expr(rng, fe, atoms, depth - 1, max_degree)
+    if op == 3:
+        return -a, da
+    b, db = random_expr(rng, fe, atoms, depth - 1, max_degree)
+    if op == 2:
+        if da + db <= max_degree:
+            return a * b, da + db
+        return a + b, max(da, db)
+    return (a + b, max(da, db)) if op == 0 else (a - b, max(da, db))
+
+
+def random_circuit(rng, fe, log_blowup):
+    E = fe.Expr
+    w = int(rng.integers(1, 7))
+    pw = int(rng.integers(0, 4)) if rng.random() < 0.4 else 0
+    h = 1 << int(rng.integers(0, 11))
+    pre = rand_field(rng, (h, pw)) if pw else None
+    atoms = [E.main(i) for i in range(w)] + [E.main_next(i) for i in range(w)]
+    atoms += [E.var(fe.SRC_PRE, 0, i) for i in range(pw)] + [E.var(fe.SRC_PRE, 1, i) for i in range(pw)]
+    max_deg = min(3, (1 << log_blowup) + 1)
+
+    def ev(b):
+        for _ in range(int(rng.integers(0, 4))):
+            e, _d = random_expr(rng, fe, atoms, 3, max_deg - (1 if rng.random() < 0.3 else 0))
+            r = rng.random()
+            if r < 0.2:
+                b.when_transition().assert_zero(e) if _d < max_deg else b.assert_zero(e)
+            elif r < 0.3 and _d < max_deg:
+                b.when_first_row().assert_zero(e)
+            elif r < 0.4 and _d < max_deg:
+                b.when_last_row().assert_zero(e)
+            else:
+                b.assert_zero(e)
+
+    # lookup expressions may only use the current row of the main and preprocessed traces
+    latoms = [E.main(i) for i in range(w)] + [E.var(fe.SRC_PRE, 0, i) for i in range(pw)]
+    lookups = []
+    for _ in range(int(rng.integers(0, 5))):
+        m, _ = random_expr(rng, fe, latoms, 1, 1)
+        args = [random_expr(rng, fe, latoms, 2, 2)[0] for _ in range(int(rng.integers(0, 6)))]
+        lookups.append(fe.Lookup.push(m, args) if rng.random() < 0.5 else fe.Lookup.pull(m, args))
+    return fe.lookup_air(w, ev, lookups, pre), w, h if pw else None
+
+
+def one_case(pkg, fe, oracle, ctx, rng, case):
+    lb = int(rng.integers(1, 4))
+    params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, 3)), log_final_poly_len=int(rng.choice([0, 0, 0, 1, 2])),
+                       num_queries=int(rng.integers(1, 24)), commit_proof_of_work_bits=int(rng.integers(0, 7)),
+                       query_proof_of_work_bits=int(rng.integers(0, 7)))
+    circuits, traces = [], []
+    for _ in range(int(rng.integers(1, 4))):
+        ci, w, fixed_h = random_circuit(rng, fe, lb)
+        circuits.append(ci)
+        h = fixed_h if fixed_h else 1 << int(rng.integers(0, 11))
+        if rng.random() < 0.12:
+            h = 0  # inactive circuit
+        traces.append(rand_field(rng, (h, w)))
+    if all(t.shape[0] == 0 for t in traces):
+        traces[0] = rand_field(rng, (circuits[0].preprocessed.shape[0] if circuits[0].preprocessed is not None else 4, traces[0].shape[1]))
+    claims = [[int(x) for x in rand_field(rng, int(rng.integers(0, 6)))] for _ in range(int(rng.integers(0, 5)))]
+    packed = fe.pack_claims(claims)
+    try:
+        compiled = [fe.compile_circuit(c) for c in circuits]
+    except fe.CompileError:
+        return "front-end-rejected"  # e.g. a constraint that folded to a non-zero constant (src/graph.rs)
+    try:
+        g = pkg.System(ctx, fe.system_blob(params, compiled), len(compiled))
+    except pkg.MstarkError as e:
+        o_failed = False
+        try:
+            oracle.System(fe.system_blob(params, compiled))
+        except Exception:
+            o_failed = True
+        assert o_failed, "library rejected a system the oracle accepts: %s" % e
+        return "rejected-by-both"
+    o = oracle.System(g.blob)
+    try:
+        want = o.prove(traces, packed)
+    except RuntimeError as oe:
+        # inputs the reference would panic on (e.g. a trace shorter than the final FRI layer): both sides must refuse
+        try:
+            g.prove_multiple_claims(g.witness(traces, packed))
+        except pkg.MstarkError:
+            return "prove-refused-by-both"
+        raise AssertionError("case %d: the oracle refused (%s) but the library produced a proof" % (case, oe))
+    got = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    assert got == want, "case %d: proof bytes differ (len %d vs %d)" % (case, len(got), len(want))
+    a, b = g.verify(packed, got), o.verify(packed, got)
+    assert (a == 0) == (b == 0), "case %d: verifier verdicts differ: library %d, oracle %d" % (case, a, b)
+    return "verified" if a == 0 else "proved"
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    pkg = load_package()
+    fe = pkg.frontend
+    import oracle
+
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    tally = {}
+    for case in range(n):
+        sub = np.random.default_rng(rng.integers(0, 1 << 62))
+        r = one_case(pkg, fe, oracle, ctx, sub, case)
+        tally[r] = tally.get(r, 0) + 1
+        if (case + 1) % 20 == 0:
+            print("[fuzz %6.1fs] %d cases: %s" % (time.time() - t0, case + 1, tally), flush=True)
+    print("OK: %d random systems, byte-identical proofs, agreeing verifiers: %s" % (n, tally))
+
+
+if __name__ == "__main__":
+    main()
