@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from __graft_entry__ import load_package  # noqa: E402
 
 P = 0xFFFFFFFF00000001
+BIG = bool(os.environ.get("FUZZ_BIG"))  # wider / taller systems: rows over one BLAKE3 chunk, > 16 lookups, 2^15 rows
 
 
 def rand_field(rng, shape):
@@ -48,9 +49,9 @@ def random_expr(rng, fe, atoms, depth, max_degree):
 
 def random_circuit(rng, fe, log_blowup):
     E = fe.Expr
-    w = int(rng.integers(1, 7))
+    w = int(rng.integers(1, 150 if BIG and rng.random() < 0.3 else 7))
     pw = int(rng.integers(0, 4)) if rng.random() < 0.4 else 0
-    h = 1 << int(rng.integers(0, 11))
+    h = 1 << int(rng.integers(0, 16 if BIG else 11))
     pre = rand_field(rng, (h, pw)) if pw else None
     atoms = [E.main(i) for i in range(w)] + [E.main_next(i) for i in range(w)]
     atoms += [E.var(fe.SRC_PRE, 0, i) for i in range(pw)] + [E.var(fe.SRC_PRE, 1, i) for i in range(pw)]
@@ -72,9 +73,9 @@ def random_circuit(rng, fe, log_blowup):
     # lookup expressions may only use the current row of the main and preprocessed traces
     latoms = [E.main(i) for i in range(w)] + [E.var(fe.SRC_PRE, 0, i) for i in range(pw)]
     lookups = []
-    for _ in range(int(rng.integers(0, 5))):
+    for _ in range(int(rng.integers(0, 40 if BIG and rng.random() < 0.3 else 5))):
         m, _ = random_expr(rng, fe, latoms, 1, 1)
-        args = [random_expr(rng, fe, latoms, 2, 2)[0] for _ in range(int(rng.integers(0, 6)))]
+        args = [random_expr(rng, fe, latoms, 2, 2)[0] for _ in range(int(rng.integers(0, 70 if BIG and rng.random() < 0.1 else 6)))]
         lookups.append(fe.Lookup.push(m, args) if rng.random() < 0.5 else fe.Lookup.pull(m, args))
     return fe.lookup_air(w, ev, lookups, pre), w, h if pw else None
 
@@ -88,7 +89,7 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
     for _ in range(int(rng.integers(1, 4))):
         ci, w, fixed_h = random_circuit(rng, fe, lb)
         circuits.append(ci)
-        h = fixed_h if fixed_h else 1 << int(rng.integers(0, 11))
+        h = fixed_h if fixed_h else 1 << int(rng.integers(0, 16 if BIG else 11))
         if rng.random() < 0.12:
             h = 0  # inactive circuit
         traces.append(rand_field(rng, (h, w)))
