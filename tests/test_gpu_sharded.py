@@ -67,6 +67,106 @@ def _worker(rank, world, port, log_adds, variant, q):
         raise
 
 
+def _random_worker(rank, world, port, seed, n_cases, q):
+    """random systems: 0-2 replicated random circuits (any position) + one random circuit instantiated once per rank"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4", OMP_WAIT_POLICY="passive",
+                          MSAMD_NO_JIT="1")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import importlib
+
+        import numpy as np
+        import torch.distributed as dist
+        from __graft_entry__ import load_package
+
+        import fuzz_parity as fz
+
+        pkg = load_package()
+        fe = pkg.frontend
+        sharded = importlib.import_module("multi_stark_amd.sharded")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            ctx = pkg.Context(0)
+            comm = sharded.TorchComm(0)
+            master = np.random.default_rng(seed)
+            done = 0
+            for case in range(n_cases):
+                rng = np.random.default_rng(master.integers(0, 1 << 62))   # the same stream on every rank
+                lb = int(rng.integers(1, 3))
+                lw = world.bit_length() - 1
+                params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 1)), log_final_poly_len=0,
+                                   num_queries=int(rng.integers(1, 12)), commit_proof_of_work_bits=int(rng.integers(0, 5)),
+                                   query_proof_of_work_bits=int(rng.integers(0, 5)))
+                shard_ci, shard_w, fixed_h = fz.random_circuit(rng, fe, lb)
+                shard_h = fixed_h if fixed_h else 1 << int(rng.integers(2, 10))
+                if shard_h < 4:
+                    continue
+                circuits, traces, owners = [], [], []
+                n_rep = int(rng.integers(0, 3))
+                rep_positions = sorted(int(x) for x in rng.integers(0, world + 1, n_rep))
+                k = 0
+                for slot in range(world + 1):
+                    for _ in range(rep_positions.count(slot)):
+                        ci, w, fh = fz.random_circuit(rng, fe, lb)
+                        h = fh if fh else 1 << int(rng.integers(2, 10))
+                        if h < 4:
+                            h = 4 if not fh else h
+                        circuits.append(ci)
+                        traces.append(fz.rand_field(rng, (h, w)))
+                        owners.append(-1)
+                    if slot < world:
+                        circuits.append(shard_ci)
+                        traces.append(fz.rand_field(rng, (shard_h, shard_w)))
+                        owners.append(k)
+                        k += 1
+                if any(t.shape[0] < 4 for t in traces):
+                    continue
+                claims = [[int(x) for x in fz.rand_field(rng, int(rng.integers(0, 5)))] for _ in range(int(rng.integers(0, 4)))]
+                packed = fe.pack_claims(claims)
+                try:
+                    compiled = [fe.compile_circuit(c) for c in circuits]
+                except fe.CompileError:
+                    continue
+                try:
+                    system = pkg.System(ctx, fe.system_blob(params, compiled), len(compiled))
+                except pkg.MstarkError:
+                    continue   # e.g. a random constraint above the degree bound: every rank skips alike
+                mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+                remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+                w_s = system.witness(mine, packed, remote_heights=remote)
+                proof = system.prove_sharded(w_s, comm, owners).to_bytes()
+                want = system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
+                assert proof == want, "random case %d: sharded proof differs from the single-GPU proof" % case
+                done += 1
+            q.put((rank, "cases=%d" % done, comm.bytes_moved))
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+    except BaseException as e:
+        q.put((rank, "ERROR: %r" % (e,), 0))
+        raise
+
+
+@pytest.mark.parametrize("world,seed", [(2, 5), (4, 6)])
+def test_sharded_random_systems(world, seed):
+    port = 29700 + (os.getpid() % 1000) + world
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    n_cases = int(os.environ.get("MSAMD_SHARDED_FUZZ_CASES", "40"))  # more for an ad-hoc soak
+    procs = [mpc.Process(target=_random_worker, args=(r, world, port, seed, n_cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert all(not str(r[1]).startswith("ERROR") for r in res), res
+    assert all(p.exitcode == 0 for p in procs)
+    assert len({r[1] for r in res}) == 1 and int(res[0][1].split("=")[1]) >= 15, res
+    print("sharded random systems:", res[0][1], "world", world)
+
+
 # 2^8 additions: the adders' LDE is as tall as the byte table's (same leaf group); 2^10: the byte table is injected
 @pytest.mark.parametrize("world,log_adds,variant", [(1, 9, "bench"), (2, 8, "bench"), (2, 10, "bad-owners"), (4, 10, "bench"),
                                                     (2, 9, "cap1")])
