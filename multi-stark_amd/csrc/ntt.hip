@@ -316,6 +316,10 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
 
 // 8-bit strided pass: sub-transforms of 256 points at stride S = 2^logS inside blocks of 2^(8 + logS); a tile is
 // 256 (h) x 16 (l) with l contiguous in memory. Includes the four-step inter-pass twiddle w_B^{l * bitrev8(h)}.
+// The forward branch issues its 16 raw loads first and the 16 scale loads + multiplications after them: the strided pass
+// is the one kernel where waves still park on HBM latency (profiles/r01_pmc_sq.txt), and interleaving load / scale load /
+// multiply per element kept fewer requests in flight (-9 % on the launch). Taking two tiles per workgroup and prefetching
+// the second was tried as well: no gain, it halves the occupancy.
 template <bool DIT, bool INV>
 __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
                                                const u64* __restrict__ twc, const u64* __restrict__ twc3,
@@ -327,25 +331,21 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
   const unsigned logB = 8 + logS;
   const unsigned tiles = 1u << (logS - 4);
   const size_t col = blockIdx.y;
-  const u32 tile = blockIdx.x & (tiles - 1);
-  const size_t blk = blockIdx.x >> (logS - 4);
-  const u32 l0 = tile << 4;
-  const size_t base = blk << logB;
-  const u64* s = src + (col / src_div) * n + base;
-  const u64* sc = scale ? scale + (col % src_div) * n + base : nullptr;
-  u64* d = dst + col * n + base;
   const u32 t = threadIdx.x, hq = t >> 4, l = t & 15;  // hq: low 4 bits of h in the strided round, high 4 in the other
-  const u32 lg = l0 + l;
   const unsigned esh = TW_LOG - logB;
   const u32 rev_hq = bitrev32(hq, 4);
   u64 x[16];
   if (!DIT) {
+    const u32 lg = ((blockIdx.x & (tiles - 1)) << 4) + l;
+    const size_t base = size_t(blockIdx.x >> (logS - 4)) << logB;
+    const u64* s = src + (col / src_div) * n + base;
+    const u64* sc = scale ? scale + (col % src_div) * n + base : nullptr;
+    u64* d = dst + col * n + base;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      size_t pos = (size_t(hq + 16 * j) << logS) + lg;
-      u64 v = s[pos];
-      if (sc) v = gl_mul(v, sc[pos]);
-      x[j] = v;
+    for (int j = 0; j < 16; j++) x[j] = s[(size_t(hq + 16 * j) << logS) + lg];
+    if (sc) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) x[j] = gl_mul(x[j], sc[(size_t(hq + 16 * j) << logS) + lg]);
     }
     reg_stages16_r4<false, INV>(x, hq, 4, twc, twc3);  // h bits 7..4
 #pragma unroll
@@ -354,21 +354,33 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq * 16 + j) * 16 + l)];
     reg_stages16_uniform<false, INV>(x);  // h bits 3..0
+    u64 tw[16];  // the sixteen inter-pass twiddles are requested together, before the first product needs one
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       // h = hq * 16 + j, bitrev8(h) = bitrev4(j) * 16 + bitrev4(hq)
       const u32 rev = (u32)(((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) << 4) + rev_hq;
-      const size_t pos = (size_t(hq * 16 + j) << logS) + lg;
-      u64 v = gl_mul(x[j], ttab ? ttab[pos] : tw_lookup(t0, t1, (lg * rev) << esh));
+      tw[j] = ttab ? ttab[(size_t(hq * 16 + j) << logS) + lg] : tw_lookup(t0, t1, (lg * rev) << esh);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      u64 v = gl_mul(x[j], tw[j]);
       if (out_mul != 1) v = gl_mul(v, out_mul);
-      d[pos] = v;
+      d[(size_t(hq * 16 + j) << logS) + lg] = v;
     }
   } else {
+    const u32 tile = blockIdx.x & (tiles - 1);
+    const size_t blk = blockIdx.x >> (logS - 4);
+    const u32 l0 = tile << 4;
+    const size_t base = blk << logB;
+    const u64* s = src + (col / src_div) * n + base;
+    u64* d = dst + col * n + base;
+    const u32 lg = l0 + l;
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = s[(size_t(hq * 16 + j) << logS) + lg];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const u32 rev = (u32)(((j & 1) << 3 | (j & 2) << 1 | (j & 4) >> 1 | (j & 8) >> 3) << 4) + rev_hq;
-      const size_t pos = (size_t(hq * 16 + j) << logS) + lg;
-      x[j] = gl_mul(s[pos], ttab ? ttab[pos] : tw_lookup(t0, t1, (lg * rev) << esh));
+      x[j] = gl_mul(x[j], ttab ? ttab[(size_t(hq * 16 + j) << logS) + lg] : tw_lookup(t0, t1, (lg * rev) << esh));
     }
     reg_stages16_uniform<true, INV>(x);  // h bits 0..3
 #pragma unroll
