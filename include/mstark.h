@@ -128,6 +128,13 @@ typedef struct ms_comm {
   void* user;
   int32_t (*all_to_all)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
   int32_t (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes);
+  /* Optional pair (both NULL = not offered): a non-blocking all_to_all, so that the exchange of one group of LDE columns
+   * runs while the next group is being transformed. `start` is called with the context's stream idle and returns at once;
+   * chunk k of the exchange is bytes_per_peer bytes at send_dev + k * send_stride (to rank k) and at recv_dev +
+   * k * recv_stride (from rank k). Buffers stay untouched until `wait` - which completes every started exchange - returns. */
+  int32_t (*all_to_all_start)(void* user, const void* send_dev, size_t send_stride, void* recv_dev, size_t recv_stride,
+                              size_t bytes_per_peer);
+  int32_t (*all_to_all_wait)(void* user);
 } ms_comm;
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms);

@@ -11,10 +11,13 @@ import torch
 import torch.distributed as dist
 
 _CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t)
+_WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 
 
 class MsComm(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB)]
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB),
+                ("all_to_all_start", _START), ("all_to_all_wait", _WAIT)]
 
 
 class _DevBytes:
@@ -35,7 +38,10 @@ class TorchComm:
         self.bytes_moved = 0
         self._a2a = _CB(self._all_to_all)
         self._ag = _CB(self._all_gather)
-        self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag)
+        self._start = _START(self._all_to_all_start)
+        self._wait = _WAIT(self._all_to_all_wait)
+        self._pending = []
+        self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag, self._start, self._wait)
 
     def _view(self, ptr, nbytes):
         return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
@@ -68,6 +74,34 @@ class TorchComm:
                 hr = torch.cat([p[self.rank * per_peer:(self.rank + 1) * per_peer] for p in parts])
                 r.copy_(hr)
                 torch.cuda.synchronize(self.device)
+
+        return self._guard(run)
+
+    def _all_to_all_start(self, _user, send, send_stride, recv, recv_stride, per_peer):
+        """non-blocking exchange of one column group: chunk k lives at send + k * send_stride / recv + k * recv_stride"""
+
+        def run():
+            ins = [self._view(send + k * send_stride, per_peer) for k in range(self.world)]
+            outs = [self._view(recv + k * recv_stride, per_peer) for k in range(self.world)]
+            self.bytes_moved += per_peer * self.world
+            if self.direct:
+                self._pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))  # RCCL's own stream
+            else:  # staged transports have nothing to overlap with: exchange now
+                mine = torch.cat([t.cpu() for t in ins])
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                for k in range(self.world):
+                    outs[k].copy_(parts[k][self.rank * per_peer:(self.rank + 1) * per_peer])
+                torch.cuda.synchronize(self.device)
+
+        return self._guard(run)
+
+    def _all_to_all_wait(self, _user):
+        def run():
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            torch.cuda.synchronize(self.device)
 
         return self._guard(run)
 
