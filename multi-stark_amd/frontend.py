@@ -16,12 +16,33 @@ import struct
 
 import numpy as np
 
+import contextlib
+
 P = (1 << 64) - (1 << 32) + 1
+EXT_D, EXT_W = 2, 7  # Challenge = BinomialExtensionField<Goldilocks, 2>, X^2 = 7
 
 # node kinds (the system-blob encoding, see include/mstark.h)
 N_CONST, N_VAR, N_PUBLIC, N_IS_FIRST, N_IS_LAST, N_IS_TRANS, N_ADD, N_SUB, N_MUL, N_NEG = range(10)
 SRC_PRE, SRC_MAIN, SRC_STAGE2 = 0, 1, 2
 BLOB_MAGIC = 0x31305359534D0000
+
+# The two StarkGenericConfig instantiations of the reference: GoldilocksBlake3Config (src/types.rs:24-29,199-223) and
+# the BabyBear / degree-4 extension / Poseidon2 test configuration (src/test_circuits/baby_bear_config.rs:28-38).
+GOLDILOCKS = dict(name="goldilocks", P=P, EXT_D=2, EXT_W=7, BLOB_MAGIC=0x31305359534D0000)
+BABYBEAR = dict(name="babybear", P=(1 << 31) - (1 << 27) + 1, EXT_D=4, EXT_W=11, BLOB_MAGIC=0x31304259534D0000)
+
+
+@contextlib.contextmanager
+def field(cfg):
+    """Author circuits / witnesses / blobs over another configuration's field: `with frontend.field(frontend.BABYBEAR):`.
+    (The reference picks the field through the SC type parameter; this front-end keeps it in module state.)"""
+    g = globals()
+    saved = {k: g[k] for k in ("P", "EXT_D", "EXT_W", "BLOB_MAGIC")}
+    g.update({k: cfg[k] for k in saved})
+    try:
+        yield cfg
+    finally:
+        g.update(saved)
 
 
 class Expr:
@@ -354,8 +375,10 @@ class CircuitInputs:
         self.lookups = list(lookups or [])
 
 
-def compile_circuit(inputs, d=2, w=7):
+def compile_circuit(inputs, d=None, w=None):
     """`graph::compile` (src/graph.rs:120-188) on the spec System::new builds (src/system.rs:128-149)."""
+    d = EXT_D if d is None else d
+    w = EXT_W if w is None else w
     pre = inputs.preprocessed
     spec = {
         "main_width": inputs.main_width,
@@ -482,9 +505,16 @@ def test_params():
     return Params(1, 0, 0, 1, 64, 0, 0)
 
 
-def system_blob(params, compiled):
-    """Serialise (params, compiled circuits) into the little-endian u64-word blob both libraries parse."""
-    words = [BLOB_MAGIC] + params.words() + [len(compiled)]
+def system_blob(params, compiled, poseidon2=None):
+    """Serialise (params, compiled circuits) into the little-endian u64-word blob both libraries parse. Under
+    `field(BABYBEAR)` the parameters are followed by the 141 Poseidon2 round constants (8 x 16 external, 13 internal)."""
+    words = [BLOB_MAGIC] + params.words()
+    if BLOB_MAGIC == BABYBEAR["BLOB_MAGIC"]:
+        k = np.asarray(poseidon2, dtype=np.uint64).reshape(-1)
+        if k.size != 141 or int(k.max()) >= P:
+            raise ValueError("the BabyBear configuration needs 141 canonical Poseidon2 round constants")
+        words += [int(x) for x in k]
+    words += [len(compiled)]
     chunks = []
     for c in compiled:
         pre = c.preprocessed
@@ -700,6 +730,39 @@ def even_odd_traces():
     even = np.array([[1, 4, inv(4), 0, 1, 1], [1, 2, inv(2), 0, 1, 1], [1, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0]], dtype=np.uint64)
     odd = np.array([[1, 3, inv(3), 0, 1, 1], [1, 1, inv(1), 0, 1, 1], [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0]], dtype=np.uint64)
     return [even, odd]
+
+
+# --------------------------------------------------------------------------- BabyBear / Poseidon2 configuration
+def poseidon2_constants(seed=42):
+    """141 round constants for Poseidon2BabyBear<16> (8 x 16 external, then 13 internal), uniform below p.
+    The reference draws them from rand's SmallRng::seed_from_u64(42) (src/test_circuits/baby_bear_config.rs:54-55), a
+    stream that cannot be reproduced without that crate, so they are an INPUT of this build; this helper is a documented
+    stand-in (numpy PCG64, the same seed number) - not the reference's constants."""
+    return np.random.default_rng(seed).integers(0, BABYBEAR["P"], 141, dtype=np.uint64)
+
+
+def mul_air_inputs():
+    """MulAir + its self-cancelling push/pull pair, src/test_circuits/baby_bear_config.rs:129-157: a * b = c per row,
+    lookups push(1, [a, c]) and pull(1, [a, c]). Use under `field(BABYBEAR)`."""
+    def ev(b):
+        local, _ = b.main()
+        b.assert_eq(local[0] * local[1], local[2])
+
+    one = Expr.const(1)
+    return [lookup_air(3, ev, [Lookup.push(one, [Expr.main(0), Expr.main(2)]), Lookup.pull(one, [Expr.main(0), Expr.main(2)])])]
+
+
+def mul_air_trace(rows):
+    """rows (r + 1, r + 2, product mod p): BASELINE config 4's scaling of the reference's 4-row trace
+    (baby_bear_config.rs:176-192 uses (2,3,6), (4,5,20), (7,8,56), (0,0,0))."""
+    r = np.arange(rows, dtype=np.uint64)
+    a, b = (r + 1) % P, (r + 2) % P
+    return np.stack([a, b, (a * b) % P], axis=1).astype(np.uint64)
+
+
+def mul_air_smoke_trace():
+    """the reference's own 4 rows, baby_bear_config.rs:176-192"""
+    return np.array([[2, 3, 6], [4, 5, 20], [7, 8, 56], [0, 0, 0]], dtype=np.uint64)
 
 
 def pack_claims(claims):

@@ -15,12 +15,13 @@
 // test-suite (restated in tests/), and prove -> verify self-consistency incl. tamper rejection.
 #pragma once
 #include <array>
+#include <cstring>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
-#include "gl.hpp"
+#include "field.hpp"
 
 namespace mso {
 
@@ -30,7 +31,19 @@ struct Digest {
   bool operator!=(const Digest& o) const { return !(*this == o); }
 };
 
-// Row-major matrix of Goldilocks elements (what RowMajorMatrix<Val>.values holds).
+#ifdef MSO_BABYBEAR
+static inline u64 digest_elem(const Digest& d, int i) {
+  return (u64)d.b[4 * i] | (u64)d.b[4 * i + 1] << 8 | (u64)d.b[4 * i + 2] << 16 | (u64)d.b[4 * i + 3] << 24;
+}
+static inline void digest_set(Digest& d, int i, u64 v) {
+  for (int k = 0; k < 4; k++) d.b[4 * i + k] = (uint8_t)(v >> (8 * k));
+}
+// the permutation of the configuration (process-wide in the oracle; set from the system blob or mso_set_poseidon2)
+Poseidon2Constants& poseidon2_constants();
+void poseidon2_permute(u64* state16);
+#endif
+
+// Row-major matrix of base-field elements (what RowMajorMatrix<Val>.values holds).
 struct Mat {
   size_t h = 0, w = 0;
   std::vector<u64> v;
@@ -73,7 +86,9 @@ struct Dim { size_t w, h; };
 bool mmcs_verify_batch(const std::vector<Digest>& cap, const std::vector<Dim>& dims, size_t index,
                        const BatchOpening& opening);
 
-// ---- Challenger: DeterministicPow<SerializingChallenger64<Goldilocks, HashChallenger<u8,Blake3,32>>> ----
+// ---- Challenger ----
+#ifndef MSO_BABYBEAR
+// DeterministicPow<SerializingChallenger64<Goldilocks, HashChallenger<u8,Blake3,32>>> (src/types.rs:28-29,44-81)
 struct Challenger {
   std::vector<uint8_t> input, output;
   explicit Challenger(const std::vector<uint8_t>& seed) : input(seed) {}
@@ -85,9 +100,8 @@ struct Challenger {
     for (size_t i = 0; i < n; i++) observe_byte(p[i]);
   }
   void observe(u64 canonical);
-  void observe_ext(E2 e) {
-    observe(e.c0);
-    observe(e.c1);
+  void observe_ext(EF e) {
+    for (unsigned k = 0; k < EXT_D; k++) observe(e.c[k]);
   }
   void observe_digest(const Digest& d) { observe_bytes(d.b, 32); }
   void observe_cap(const std::vector<Digest>& cap) {
@@ -96,11 +110,40 @@ struct Challenger {
   uint8_t sample_byte();
   u64 sample_u64();   // 8 sampled bytes, little-endian
   u64 sample_base();  // rejection sampling below p
-  E2 sample_ext();
+  EF sample_ext();
   size_t sample_bits(unsigned bits);
   bool check_witness(unsigned bits, u64 witness);
   u64 grind(unsigned bits);  // smallest witness; ZERO at 0 bits (src/types.rs:72-81)
 };
+#else
+// DuplexChallenger<BabyBear, Poseidon2BabyBear<16>, 16, 8> (src/test_circuits/baby_bear_config.rs:37)
+// [UPSTREAM-RECALL p3-challenger 0.5.1 duplex_challenger.rs]. The seed is a list of field elements observed into a
+// fresh challenger (baby_bear_config.rs:72-86,108-114). A digest is 8 field elements, held as 8 canonical u32 LE.
+struct Challenger {
+  u64 state[16];
+  std::vector<u64> input, output;
+  explicit Challenger(const std::vector<u64>& seed) {
+    for (auto& x : state) x = 0;
+    for (u64 v : seed) observe(v);
+  }
+  void duplexing();
+  void observe(u64 canonical);
+  void observe_ext(EF e) {
+    for (unsigned k = 0; k < EXT_D; k++) observe(e.c[k]);
+  }
+  void observe_digest(const Digest& d) {
+    for (int i = 0; i < 8; i++) observe(digest_elem(d, i));
+  }
+  void observe_cap(const std::vector<Digest>& cap) {
+    for (auto& d : cap) observe_digest(d);
+  }
+  u64 sample_base();
+  EF sample_ext();
+  size_t sample_bits(unsigned bits);
+  bool check_witness(unsigned bits, u64 witness);
+  u64 grind(unsigned bits);  // smallest witness; ZERO at 0 bits (the reference's test config only runs 0 bits)
+};
+#endif
 
 // ---- system description (what System::new produces; graph compile itself is out of scope) ----
 struct Params {
@@ -134,7 +177,12 @@ struct System {
   std::vector<Digest> pre_commit;
   std::vector<int> pre_indices;  // -1 = none
   MerkleTree pre_tree;           // ProverKey.preprocessed_data
+#ifndef MSO_BABYBEAR
   std::vector<uint8_t> challenger_seed() const;
+#else
+  std::vector<u64> challenger_seed() const;
+#endif
+  Challenger new_challenger() const { return Challenger(challenger_seed()); }
   void observe_shape(Challenger& ch) const;
 };
 // Parses the system blob produced by the Python front-end (format: multi-stark_amd/frontend.py) and runs
@@ -155,10 +203,10 @@ struct Witness {
 Witness witness_from_stage_1(const System& sys, std::vector<Mat>&& traces);
 
 // ---- proof containers ----
-typedef std::vector<std::vector<std::vector<E2>>> OpenedRound;  // matrix -> point -> column
+typedef std::vector<std::vector<std::vector<EF>>> OpenedRound;  // matrix -> point -> column
 struct CommitPhaseStep {
   uint8_t log_arity = 1;
-  std::vector<E2> sibling_values;
+  std::vector<EF> sibling_values;
   std::vector<Digest> proof;
 };
 struct QueryProof {
@@ -169,13 +217,13 @@ struct FriProof {
   std::vector<std::vector<Digest>> commit_phase_commits;
   std::vector<u64> commit_pow_witnesses;
   std::vector<QueryProof> query_proofs;
-  std::vector<E2> final_poly;
+  std::vector<EF> final_poly;
   u64 query_pow_witness = 0;
 };
 struct Proof {
   std::vector<uint8_t> active;
   std::vector<Digest> stage1_commit, stage2_commit, quotient_commit;
-  std::vector<E2> intermediate_accumulators;
+  std::vector<EF> intermediate_accumulators;
   std::vector<uint8_t> log_degrees;
   FriProof opening_proof;
   OpenedRound quotient_opened, stage1_opened, stage2_opened;
@@ -206,15 +254,15 @@ enum VerifyError {
 VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claims, const Proof& proof);
 
 // pieces exposed for kernel-level parity tests
-void stage_2_traces(const std::vector<LookupValues>& circuits, E2 beta, E2 gamma, E2 acc_in,
-                    std::vector<std::vector<E2>>& traces_out, std::vector<E2>& accs_out);
-E2 claims_accumulator(const std::vector<std::vector<u64>>& claims, E2 beta, E2 gamma);
-std::vector<E2> quotient_values(const Circuit& c, const u64 publics[8], unsigned log_n, unsigned log_q,
-                                const Mat* pre_q, const Mat& s1_q, const Mat& s2_q, E2 alpha);
+void stage_2_traces(const std::vector<LookupValues>& circuits, EF beta, EF gamma, EF acc_in,
+                    std::vector<std::vector<EF>>& traces_out, std::vector<EF>& accs_out);
+EF claims_accumulator(const std::vector<std::vector<u64>>& claims, EF beta, EF gamma);
+std::vector<EF> quotient_values(const Circuit& c, const u64* publics /* 4 * EXT_D */, unsigned log_n, unsigned log_q,
+                                const Mat* pre_q, const Mat& s1_q, const Mat& s2_q, EF alpha);
 struct Selectors {
   std::vector<u64> is_first, is_last, is_trans, inv_van;
 };
 Selectors selectors_on_coset(unsigned log_n, unsigned log_q);  // trace domain H_n, coset 7*H_{nq}
-E2 fingerprint(E2 r, const u64* coeffs, size_t n);
+EF fingerprint(EF r, const u64* coeffs, size_t n);
 
 }  // namespace mso

@@ -46,21 +46,30 @@ int mso_max_threads() { return 1; }
 #endif
 
 // ---- field / hash primitives (KAT pinning)
-u64 mso_gl_mul(u64 a, u64 b) { return gl_mul(a, b); }
-u64 mso_gl_add(u64 a, u64 b) { return gl_add(a, b); }
-u64 mso_gl_sub(u64 a, u64 b) { return gl_sub(a, b); }
-u64 mso_gl_inv(u64 a) { return gl_inv(a); }
-u64 mso_gl_two_adic_generator(unsigned bits) { return gl_two_adic_generator(bits); }
-void mso_e2_mul(const u64* a, const u64* b, u64* o) {
-  E2 r = e2_mul(E2{a[0], a[1]}, E2{b[0], b[1]});
-  o[0] = r.c0;
-  o[1] = r.c1;
+u64 mso_gl_mul(u64 a, u64 b) { return f_mul(a, b); }
+u64 mso_gl_add(u64 a, u64 b) { return f_add(a, b); }
+u64 mso_gl_sub(u64 a, u64 b) { return f_sub(a, b); }
+u64 mso_gl_inv(u64 a) { return f_inv(a); }
+u64 mso_gl_two_adic_generator(unsigned bits) { return f_two_adic_generator(bits); }
+// extension elements cross this surface as EXT_D consecutive u64 (2 for Goldilocks, 4 for BabyBear)
+unsigned mso_ext_degree() { return EXT_D; }
+u64 mso_field_order() { return F_P; }
+void mso_e2_mul(const u64* a, const u64* b, u64* o) { ef_to(ef_mul(ef_from(a), ef_from(b)), o); }
+void mso_e2_inv(const u64* a, u64* o) { ef_to(ef_inv(ef_from(a)), o); }
+#ifdef MSO_BABYBEAR
+// 8*16 external then 13 internal round constants, canonical
+int mso_set_poseidon2(const u64* k141) {
+  Poseidon2Constants& k = poseidon2_constants();
+  for (int i = 0; i < 141; i++)
+    if (k141[i] >= F_P) return -1;
+  for (int r = 0; r < 8; r++)
+    for (int i = 0; i < 16; i++) k.external[r][i] = k141[16 * r + i];
+  for (int r = 0; r < 13; r++) k.internal[r] = k141[128 + r];
+  return 0;
 }
-void mso_e2_inv(const u64* a, u64* o) {
-  E2 r = e2_inv(E2{a[0], a[1]});
-  o[0] = r.c0;
-  o[1] = r.c1;
-}
+void mso_poseidon2_permute(u64* state16) { poseidon2_permute(state16); }
+u64 mso_to_wire(u64 x) { return bb_to_wire(x); }
+#endif
 void mso_b3_g(uint32_t* v4, uint32_t mx, uint32_t my) {
   uint32_t v[16] = {0};
   v[0] = v4[0];
@@ -111,7 +120,7 @@ int mso_coset_lde_bitrev(const u64* in, size_t h, size_t w, unsigned log_blowup,
   CATCH
 }
 int mso_shifted_quotient_slices(const u64* in, size_t h, size_t w, size_t qdeg, u64* out) {
-  TRY Mat o = shifted_quotient_slices(mat_from(in, h, w), GL_GENERATOR, qdeg);
+  TRY Mat o = shifted_quotient_slices(mat_from(in, h, w), F_GENERATOR, qdeg);
   memcpy(out, o.v.data(), o.v.size() * 8);
   return 0;
   CATCH
@@ -170,14 +179,20 @@ int mso_mmcs_verify(const uint8_t* cap, size_t ncap, size_t n, const u64* height
 }
 
 // ---- challenger
+#ifndef MSO_BABYBEAR
 void* mso_challenger_new(const uint8_t* seed, size_t n) { return new Challenger(std::vector<uint8_t>(seed, seed + n)); }
+void mso_challenger_observe_bytes(void* c, const uint8_t* p, size_t n) { ((Challenger*)c)->observe_bytes(p, n); }
+#else
+// the seed bytes are observed one field element each (the way baby_bear_config.rs:72-75 feeds its tag)
+void* mso_challenger_new(const uint8_t* seed, size_t n) { return new Challenger(std::vector<u64>(seed, seed + n)); }
+void mso_challenger_observe_bytes(void* c, const uint8_t* p, size_t n) {
+  for (size_t i = 0; i < n; i++) ((Challenger*)c)->observe(p[i]);
+}
+#endif
 void mso_challenger_free(void* c) { delete (Challenger*)c; }
 void mso_challenger_observe(void* c, u64 x) { ((Challenger*)c)->observe(x); }
-void mso_challenger_observe_bytes(void* c, const uint8_t* p, size_t n) { ((Challenger*)c)->observe_bytes(p, n); }
 void mso_challenger_sample_ext(void* c, u64* out2) {
-  E2 e = ((Challenger*)c)->sample_ext();
-  out2[0] = e.c0;
-  out2[1] = e.c1;
+  ef_to(((Challenger*)c)->sample_ext(), out2);
 }
 u64 mso_challenger_sample_bits(void* c, unsigned bits) { return ((Challenger*)c)->sample_bits(bits); }
 u64 mso_challenger_grind(void* c, unsigned bits) { return ((Challenger*)c)->grind(bits); }
@@ -269,26 +284,20 @@ int mso_stage2_trace(size_t height, size_t num_lookups, const u64* mult, const u
   lv.arg_offsets.assign(arg_offsets, arg_offsets + num_lookups + 1);
   lv.mult.assign(mult, mult + height * num_lookups);
   lv.args.assign(args, args + height * lv.arg_offsets.back());
-  std::vector<std::vector<E2>> tr;
-  std::vector<E2> accs;
+  std::vector<std::vector<EF>> tr;
+  std::vector<EF> accs;
   std::vector<LookupValues> cs;
   cs.push_back(std::move(lv));
-  stage_2_traces(cs, E2{beta[0], beta[1]}, E2{gamma[0], gamma[1]}, E2{acc_in[0], acc_in[1]}, tr, accs);
-  for (size_t i = 0; i < tr[0].size(); i++) {
-    trace_out[2 * i] = tr[0][i].c0;
-    trace_out[2 * i + 1] = tr[0][i].c1;
-  }
-  acc_out[0] = accs[0].c0;
-  acc_out[1] = accs[0].c1;
+  stage_2_traces(cs, ef_from(beta), ef_from(gamma), ef_from(acc_in), tr, accs);
+  for (size_t i = 0; i < tr[0].size(); i++) ef_to(tr[0][i], trace_out + EXT_D * i);
+  ef_to(accs[0], acc_out);
   return 0;
   CATCH
 }
 int mso_claims_accumulator(size_t n_claims, const u64* claim_offsets, const u64* claim_data, const u64* beta,
                            const u64* gamma, u64* acc_out) {
-  TRY E2 a = claims_accumulator(unpack_claims(n_claims, claim_offsets, claim_data), E2{beta[0], beta[1]},
-                               E2{gamma[0], gamma[1]});
-  acc_out[0] = a.c0;
-  acc_out[1] = a.c1;
+  TRY EF a = claims_accumulator(unpack_claims(n_claims, claim_offsets, claim_data), ef_from(beta), ef_from(gamma));
+  ef_to(a, acc_out);
   return 0;
   CATCH
 }
@@ -300,11 +309,8 @@ int mso_quotient_values(void* s, size_t ci, const u64* publics8, unsigned log_n,
   size_t N = size_t(1) << (log_n + log_q);
   Mat pre = c.pre_width ? mat_from(pre_q, N, c.pre_width) : Mat();
   Mat s1 = mat_from(s1_q, N, c.main_width), s2 = mat_from(s2_q, N, c.stage2_width);
-  std::vector<E2> q = quotient_values(c, publics8, log_n, log_q, c.pre_width ? &pre : nullptr, s1, s2, E2{alpha[0], alpha[1]});
-  for (size_t i = 0; i < N; i++) {
-    out[2 * i] = q[i].c0;
-    out[2 * i + 1] = q[i].c1;
-  }
+  std::vector<EF> q = quotient_values(c, publics8, log_n, log_q, c.pre_width ? &pre : nullptr, s1, s2, ef_from(alpha));
+  for (size_t i = 0; i < N; i++) ef_to(q[i], out + EXT_D * i);
   return 0;
   CATCH
 }

@@ -11,6 +11,7 @@
 namespace mso {
 
 // ------------------------------------------------------------------ hashing
+#ifndef MSO_BABYBEAR
 Digest hash_bytes(const uint8_t* p, size_t n) {
   Digest d;
   blake3_hash(p, n, d.b);
@@ -33,6 +34,48 @@ Digest compress2(const Digest& l, const Digest& r) {
   memcpy(buf + 32, r.b, 32);
   return hash_bytes(buf, 64);
 }
+#else
+Poseidon2Constants& poseidon2_constants() {
+  static Poseidon2Constants k = {};
+  return k;
+}
+void poseidon2_permute(u64* s) { bb_poseidon2_permute(poseidon2_constants(), s); }
+
+// BLAKE3 is not part of this configuration; kept so the primitive tests of the C surface still link
+Digest hash_bytes(const uint8_t* p, size_t n) {
+  Digest d;
+  blake3_hash(p, n, d.b);
+  return d;
+}
+
+// PaddingFreeSponge<Perm, 16, 8, 8>::hash_iter (baby_bear_config.rs:30): overwrite the first 8 state words with the
+// next 8 inputs and permute; a partial last block is permuted too (the rest of the state keeps its old words), an
+// input that ends on a block boundary - the empty input included - gets no extra permutation.
+// [UPSTREAM-RECALL p3-symmetric 0.5.1 sponge.rs]
+Digest hash_elems(const u64* e, size_t n) {
+  u64 st[16] = {0};
+  size_t i = 0;
+  while (i < n) {
+    size_t k = std::min<size_t>(8, n - i);
+    for (size_t j = 0; j < k; j++) st[j] = e[i + j];
+    poseidon2_permute(st);
+    i += k;
+  }
+  Digest d;
+  for (int j = 0; j < 8; j++) digest_set(d, j, st[j]);
+  return d;
+}
+
+// TruncatedPermutation<Perm, 2, 8, 16>::compress (baby_bear_config.rs:31): permute(left || right)[..8]
+Digest compress2(const Digest& l, const Digest& r) {
+  u64 st[16];
+  for (int j = 0; j < 8; j++) st[j] = digest_elem(l, j), st[8 + j] = digest_elem(r, j);
+  poseidon2_permute(st);
+  Digest d;
+  for (int j = 0; j < 8; j++) digest_set(d, j, st[j]);
+  return d;
+}
+#endif
 
 // ------------------------------------------------------------------ DFT
 namespace {
@@ -50,13 +93,13 @@ const Twiddles& twiddles(unsigned logn) {
   size_t half = logn ? (size_t(1) << (logn - 1)) : 0;
   t.fwd.resize(half);
   t.inv.resize(half);
-  u64 w = gl_two_adic_generator(logn), wi = gl_inv(w);
+  u64 w = f_two_adic_generator(logn), wi = f_inv(w);
   u64 a = 1, b = 1;
   for (size_t i = 0; i < half; i++) {
     t.fwd[i] = a;
     t.inv[i] = b;
-    a = gl_mul(a, w);
-    b = gl_mul(b, wi);
+    a = f_mul(a, w);
+    b = f_mul(b, wi);
   }
   return g_tw.emplace(logn, std::move(t)).first->second;
 }
@@ -76,9 +119,9 @@ void ntt_column(u64* a, unsigned logn, const std::vector<u64>& tw) {
     for (size_t b = 0; b < n / 2; b++) {
       size_t k = (b / half) * m, j = b % half;
       u64 w = tw[j * step];
-      u64 u = a[k + j], t = gl_mul(w, a[k + j + half]);
-      a[k + j] = gl_add(u, t);
-      a[k + j + half] = gl_sub(u, t);
+      u64 u = a[k + j], t = f_mul(w, a[k + j + half]);
+      a[k + j] = f_add(u, t);
+      a[k + j + half] = f_sub(u, t);
     }
   }
 }
@@ -114,11 +157,11 @@ Mat idft_batch(const Mat& m) {
   const Twiddles& tw = twiddles(logn);
   std::vector<u64> c = to_cols(m);
   for (size_t j = 0; j < m.w; j++) ntt_column(&c[j * m.h], logn, tw.inv);
-  u64 ninv = gl_inv((u64)m.h);
+  u64 ninv = f_inv((u64)m.h);
   Mat o(m.h, m.w);
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < m.h; r++)
-    for (size_t j = 0; j < m.w; j++) o.v[r * m.w + j] = gl_mul(c[j * m.h + r], ninv);
+    for (size_t j = 0; j < m.w; j++) o.v[r * m.w + j] = f_mul(c[j * m.h + r], ninv);
   return o;
 }
 
@@ -142,20 +185,20 @@ Mat coset_lde_bitrev(const Mat& evals, unsigned log_blowup, u64 shift) {
   {
     std::vector<u64> small = to_cols(evals);
     const Twiddles& tw = twiddles(logn);
-    u64 ninv = gl_inv((u64)n);
+    u64 ninv = f_inv((u64)n);
     // shift^j / n, per row
     std::vector<u64> sc(n);
     u64 s = ninv;
     for (size_t j = 0; j < n; j++) {
       sc[j] = s;
-      s = gl_mul(s, shift);
+      s = f_mul(s, shift);
     }
     for (size_t j = 0; j < w; j++) {
       if (n > 1) ntt_column(&small[j * n], logn, tw.inv);
       u64* dst = &c[j * N];
       const u64* src = &small[j * n];
 #pragma omp parallel for schedule(static)
-      for (size_t r = 0; r < n; r++) dst[r] = gl_mul(src[r], sc[r]);
+      for (size_t r = 0; r < n; r++) dst[r] = f_mul(src[r], sc[r]);
     }
   }
   const Twiddles& twN = twiddles(logN);
@@ -172,18 +215,18 @@ Mat coset_lde_bitrev(const Mat& evals, unsigned log_blowup, u64 shift) {
 
 // src/prover.rs:631-679
 Mat shifted_quotient_slices(const Mat& quotient_evals, u64 domain_shift, size_t quotient_degree) {
-  if (domain_shift != GL_GENERATOR) throw std::runtime_error("quotient domain shift must equal the LDE shift");
+  if (domain_shift != F_GENERATOR) throw std::runtime_error("quotient domain shift must equal the LDE shift");
   size_t ext_degree = quotient_evals.w, big = quotient_evals.h;
   unsigned log_big = log2_strict(big);
   size_t n = big / quotient_degree, width = quotient_degree * ext_degree;
   Mat storage = bit_reverse_rows(dft_batch(quotient_evals));  // natural k lives at row rev(k)
-  u64 n_inv = gl_inv((u64)big);
-  u64 weight_step = gl_inv(gl_pow(GL_GENERATOR, (u64)n));
+  u64 n_inv = f_inv((u64)big);
+  u64 weight_step = f_inv(f_pow(F_GENERATOR, (u64)n));
   std::vector<u64> weights(quotient_degree);
   u64 wgt = 1;
   for (size_t k = 0; k < quotient_degree; k++) {
-    weights[k] = gl_mul(wgt, n_inv);
-    wgt = gl_mul(wgt, weight_step);
+    weights[k] = f_mul(wgt, n_inv);
+    wgt = f_mul(wgt, weight_step);
   }
   Mat out(n, width);
 #pragma omp parallel for schedule(static)
@@ -192,7 +235,7 @@ Mat shifted_quotient_slices(const Mat& quotient_evals, u64 domain_shift, size_t 
       size_t j = chunk * n + row;
       size_t src = bitrev((big - j) & (big - 1), log_big);
       for (size_t c = 0; c < ext_degree; c++)
-        out.v[row * width + chunk * ext_degree + c] = gl_mul(storage.v[src * ext_degree + c], weights[chunk]);
+        out.v[row * width + chunk * ext_degree + c] = f_mul(storage.v[src * ext_degree + c], weights[chunk]);
     }
   return out;
 }
@@ -313,6 +356,7 @@ bool mmcs_verify_batch(const std::vector<Digest>& cap, const std::vector<Dim>& d
 }
 
 // ------------------------------------------------------------------ challenger
+#ifndef MSO_BABYBEAR
 // [UPSTREAM-RECALL p3-challenger 0.5.1 HashChallenger / SerializingChallenger64]
 void Challenger::observe(u64 canonical) {
   uint8_t b[8];
@@ -337,17 +381,45 @@ u64 Challenger::sample_u64() {
 u64 Challenger::sample_base() {
   for (;;) {
     u64 v = sample_u64();
-    if (v < GL_P) return v;
+    if (v < F_P) return v;
   }
-}
-E2 Challenger::sample_ext() {
-  u64 a = sample_base();
-  u64 b = sample_base();
-  return E2{a, b};
 }
 size_t Challenger::sample_bits(unsigned bits) {
   u64 v = sample_u64();
   return (size_t)(v & ((u64(1) << bits) - 1));
+}
+#else
+// [UPSTREAM-RECALL p3-challenger 0.5.1 DuplexChallenger]: observe clears the output buffer and queues the value; a full
+// queue (RATE = 8) is absorbed at once: the queued values overwrite the first state words, the state is permuted and
+// the first 8 words become the output buffer. sample absorbs whatever is queued (or refills an empty output buffer)
+// and pops from the BACK of the output buffer.
+void Challenger::duplexing() {
+  for (size_t i = 0; i < input.size(); i++) state[i] = input[i];
+  input.clear();
+  poseidon2_permute(state);
+  output.assign(state, state + 8);
+}
+void Challenger::observe(u64 canonical) {
+  output.clear();
+  input.push_back(canonical);
+  if (input.size() == 8) duplexing();
+}
+u64 Challenger::sample_base() {
+  if (!input.empty() || output.empty()) duplexing();
+  u64 v = output.back();
+  output.pop_back();
+  return v;
+}
+// sample_bits: the low bits of the canonical value of one sampled element
+size_t Challenger::sample_bits(unsigned bits) {
+  if (bits >= 31) throw std::runtime_error("sample_bits: too many bits for a 31-bit field");
+  return (size_t)(sample_base() & ((u64(1) << bits) - 1));
+}
+#endif
+EF Challenger::sample_ext() {
+  EF e;
+  for (unsigned k = 0; k < EXT_D; k++) e.c[k] = sample_base();
+  return e;
 }
 bool Challenger::check_witness(unsigned bits, u64 witness) {
   if (bits == 0) return true;
@@ -357,6 +429,7 @@ bool Challenger::check_witness(unsigned bits, u64 witness) {
 u64 Challenger::grind(unsigned bits) {
   if (bits == 0) return 0;  // DeterministicPow, src/types.rs:75-80
   for (u64 w = 0;; w++) {
+    if (w >= F_P) throw std::runtime_error("grind: no witness");
     Challenger c = *this;
     if (c.check_witness(bits, w)) {
       check_witness(bits, w);
@@ -373,6 +446,7 @@ size_t Circuit::quotient_degree() const {
   return q;
 }
 
+#ifndef MSO_BABYBEAR
 std::vector<uint8_t> System::challenger_seed() const {
   // src/types.rs:118-130
   const char* tag = "multi-stark/v0";
@@ -383,17 +457,28 @@ std::vector<uint8_t> System::challenger_seed() const {
     for (int k = 0; k < 8; k++) s.push_back((uint8_t)(p >> (8 * k)));
   return s;
 }
+#else
+std::vector<u64> System::challenger_seed() const {
+  // src/test_circuits/baby_bear_config.rs:72-86: the tag bytes and the seven parameters, each as a field element
+  const char* tag = "multi-stark/v0";
+  std::vector<u64> s(tag, tag + 14);
+  const u64 ps[7] = {params.log_blowup,  params.cap_height,      params.log_final_poly_len, params.max_log_arity,
+                     params.num_queries, params.commit_pow_bits, params.query_pow_bits};
+  for (u64 p : ps) s.push_back(p % F_P);
+  return s;
+}
+#endif
 
 void System::observe_shape(Challenger& ch) const {
   // src/system.rs:211-222
-  ch.observe((u64)circuits.size());
+  ch.observe(f_from_u64((u64)circuits.size()));
   for (auto& c : circuits) {
-    ch.observe((u64)c.constraint_count);
-    ch.observe((u64)c.max_constraint_degree);
-    ch.observe((u64)c.pre_height);
-    ch.observe((u64)c.pre_width);
-    ch.observe((u64)c.main_width);
-    ch.observe((u64)c.stage2_width);
+    ch.observe(f_from_u64((u64)c.constraint_count));
+    ch.observe(f_from_u64((u64)c.max_constraint_degree));
+    ch.observe(f_from_u64((u64)c.pre_height));
+    ch.observe(f_from_u64((u64)c.pre_width));
+    ch.observe(f_from_u64((u64)c.main_width));
+    ch.observe(f_from_u64((u64)c.stage2_width));
   }
 }
 
@@ -411,7 +496,11 @@ struct Reader {
 };
 }  // namespace
 
+#ifndef MSO_BABYBEAR
 static const u64 BLOB_MAGIC = 0x31305359534D0000ULL;  // "\0\0MSYS01"
+#else
+static const u64 BLOB_MAGIC = 0x31304259534D0000ULL;  // "\0\0MSYB01": the parameters are followed by the Poseidon2 constants
+#endif
 
 System system_from_blob(const uint8_t* blob, size_t len) {
   Reader rd{blob, len};
@@ -427,8 +516,18 @@ System system_from_blob(const uint8_t* blob, size_t len) {
   p.query_pow_bits = rd.word();
   if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 is restated");
   if (p.log_blowup < 1 || p.log_blowup > 8) throw std::runtime_error("bad log_blowup");
+#ifdef MSO_BABYBEAR
+  {
+    Poseidon2Constants& k = poseidon2_constants();
+    for (int r = 0; r < 8; r++)
+      for (int i = 0; i < 16; i++)
+        if ((k.external[r][i] = rd.word()) >= F_P) throw std::runtime_error("non-canonical round constant");
+    for (int r = 0; r < 13; r++)
+      if ((k.internal[r] = rd.word()) >= F_P) throw std::runtime_error("non-canonical round constant");
+  }
+#endif
   size_t nc = rd.word();
-  const size_t D = 2;
+  const size_t D = EXT_D;
   std::vector<Mat> pre_traces;
   for (size_t ci = 0; ci < nc; ci++) {
     Circuit c;
@@ -456,7 +555,7 @@ System system_from_blob(const uint8_t* blob, size_t len) {
       uint32_t deg = 0;
       switch (nd.kind) {  // src/graph.rs:242-252
         case N_CONST:
-          if (nd.a >= GL_P) throw std::runtime_error("non-canonical constant");
+          if (nd.a >= F_P) throw std::runtime_error("non-canonical constant");
           deg = 0;
           break;
         case N_PUBLIC:
@@ -514,10 +613,10 @@ System system_from_blob(const uint8_t* blob, size_t len) {
       c.preprocessed = Mat(c.pre_height, c.pre_width);
       for (auto& x : c.preprocessed.v) {
         x = rd.word();
-        if (x >= GL_P) throw std::runtime_error("non-canonical preprocessed value");
+        if (x >= F_P) throw std::runtime_error("non-canonical preprocessed value");
       }
       sys.pre_indices.push_back((int)pre_traces.size());
-      pre_traces.push_back(coset_lde_bitrev(c.preprocessed, (unsigned)p.log_blowup, GL_GENERATOR));
+      pre_traces.push_back(coset_lde_bitrev(c.preprocessed, (unsigned)p.log_blowup, F_GENERATOR));
     } else {
       c.pre_height = 0;
       sys.pre_indices.push_back(-1);
@@ -545,11 +644,21 @@ struct W {
   void u64_(u64 x) {
     for (int k = 0; k < 8; k++) b.push_back((uint8_t)(x >> (8 * k)));
   }
-  void ext(E2 e) {
-    u64_(e.c0);
-    u64_(e.c1);
-  }
+#ifndef MSO_BABYBEAR
+  void fe(u64 x) { u64_(x); }
   void dig(const Digest& d) { b.insert(b.end(), d.b, d.b + 32); }
+#else
+  void fe(u64 x) {  // MontyField31 serialises its Montgomery form as a u32
+    uint32_t m = bb_to_wire(x);
+    for (int k = 0; k < 4; k++) b.push_back((uint8_t)(m >> (8 * k)));
+  }
+  void dig(const Digest& d) {  // [BabyBear; 8]: a fixed-size array, no length prefix
+    for (int i = 0; i < 8; i++) fe(digest_elem(d, i));
+  }
+#endif
+  void ext(EF e) {
+    for (unsigned k = 0; k < EXT_D; k++) fe(e.c[k]);
+  }
   void cap(const std::vector<Digest>& c) {
     u64_(c.size());
     for (auto& d : c) dig(d);
@@ -587,15 +696,11 @@ struct R {
     if (item_min && l > (n - off) / item_min) throw std::runtime_error("proof length field too large");
     return (size_t)l;
   }
+#ifndef MSO_BABYBEAR
   u64 fe() {
     u64 v = u64_();
-    if (v >= GL_P) throw std::runtime_error("non-canonical field element");
+    if (v >= F_P) throw std::runtime_error("non-canonical field element");
     return v;
-  }
-  E2 ext() {
-    u64 a = fe();
-    u64 b = fe();
-    return E2{a, b};
   }
   Digest dig() {
     need(32);
@@ -603,6 +708,26 @@ struct R {
     memcpy(d.b, p + off, 32);
     off += 32;
     return d;
+  }
+#else
+  u64 fe() {
+    need(4);
+    uint32_t m = 0;
+    for (int k = 0; k < 4; k++) m |= (uint32_t)p[off + k] << (8 * k);
+    off += 4;
+    if (m >= F_P) throw std::runtime_error("non-canonical field element");
+    return bb_from_wire(m);
+  }
+  Digest dig() {
+    Digest d;
+    for (int i = 0; i < 8; i++) digest_set(d, i, fe());
+    return d;
+  }
+#endif
+  EF ext() {
+    EF e;
+    for (unsigned k = 0; k < EXT_D; k++) e.c[k] = fe();
+    return e;
   }
   std::vector<Digest> cap() {
     size_t l = len(32);
@@ -615,7 +740,7 @@ struct R {
     for (auto& m : r) {
       m.resize(len(8));
       for (auto& pt : m) {
-        pt.resize(len(16));
+        pt.resize(len(EXT_D * F_WIRE_BYTES));
         for (auto& e : pt) e = ext();
       }
     }
@@ -639,7 +764,7 @@ std::vector<uint8_t> proof_to_bytes(const Proof& p) {
   w.u64_(f.commit_phase_commits.size());
   for (auto& c : f.commit_phase_commits) w.cap(c);
   w.u64_(f.commit_pow_witnesses.size());
-  for (auto x : f.commit_pow_witnesses) w.u64_(x);
+  for (auto x : f.commit_pow_witnesses) w.fe(x);
   w.u64_(f.query_proofs.size());
   for (auto& q : f.query_proofs) {
     w.u64_(q.input_proof.size());
@@ -647,7 +772,7 @@ std::vector<uint8_t> proof_to_bytes(const Proof& p) {
       w.u64_(bo.opened_values.size());
       for (auto& row : bo.opened_values) {
         w.u64_(row.size());
-        for (auto x : row) w.u64_(x);
+        for (auto x : row) w.fe(x);
       }
       w.u64_(bo.proof.size());
       for (auto& d : bo.proof) w.dig(d);
@@ -663,7 +788,7 @@ std::vector<uint8_t> proof_to_bytes(const Proof& p) {
   }
   w.u64_(f.final_poly.size());
   for (auto& e : f.final_poly) w.ext(e);
-  w.u64_(f.query_pow_witness);
+  w.fe(f.query_pow_witness);
   w.round(p.quotient_opened);
   w.u8(p.has_pre_opened ? 1 : 0);
   if (p.has_pre_opened) w.round(p.pre_opened);
@@ -683,14 +808,14 @@ Proof proof_from_bytes(const uint8_t* bytes, size_t n) {
   p.stage1_commit = r.cap();
   p.stage2_commit = r.cap();
   p.quotient_commit = r.cap();
-  p.intermediate_accumulators.resize(r.len(16));
+  p.intermediate_accumulators.resize(r.len(EXT_D * F_WIRE_BYTES));
   for (auto& e : p.intermediate_accumulators) e = r.ext();
   p.log_degrees.resize(r.len(1));
   for (auto& d : p.log_degrees) d = r.u8();
   FriProof& f = p.opening_proof;
   f.commit_phase_commits.resize(r.len(8));
   for (auto& c : f.commit_phase_commits) c = r.cap();
-  f.commit_pow_witnesses.resize(r.len(8));
+  f.commit_pow_witnesses.resize(r.len(F_WIRE_BYTES));
   for (auto& x : f.commit_pow_witnesses) x = r.fe();
   f.query_proofs.resize(r.len(16));
   for (auto& q : f.query_proofs) {
@@ -698,7 +823,7 @@ Proof proof_from_bytes(const uint8_t* bytes, size_t n) {
     for (auto& bo : q.input_proof) {
       bo.opened_values.resize(r.len(8));
       for (auto& row : bo.opened_values) {
-        row.resize(r.len(8));
+        row.resize(r.len(F_WIRE_BYTES));
         for (auto& x : row) x = r.fe();
       }
       bo.proof.resize(r.len(32));
@@ -707,13 +832,13 @@ Proof proof_from_bytes(const uint8_t* bytes, size_t n) {
     q.commit_phase_openings.resize(r.len(17));
     for (auto& s : q.commit_phase_openings) {
       s.log_arity = r.u8();
-      s.sibling_values.resize(r.len(16));
+      s.sibling_values.resize(r.len(EXT_D * F_WIRE_BYTES));
       for (auto& e : s.sibling_values) e = r.ext();
       s.proof.resize(r.len(32));
       for (auto& d : s.proof) d = r.dig();
     }
   }
-  f.final_poly.resize(r.len(16));
+  f.final_poly.resize(r.len(EXT_D * F_WIRE_BYTES));
   for (auto& e : f.final_poly) e = r.ext();
   f.query_pow_witness = r.fe();
   p.quotient_opened = r.round();

@@ -14,22 +14,22 @@ namespace {
 struct BaseOps {
   typedef u64 T;
   static T from_base(u64 c) { return c; }
-  static T add(T a, T b) { return gl_add(a, b); }
-  static T sub(T a, T b) { return gl_sub(a, b); }
-  static T mul(T a, T b) { return gl_mul(a, b); }
-  static T neg(T a) { return gl_neg(a); }
-  static T mul_base(T a, u64 b) { return gl_mul(a, b); }
+  static T add(T a, T b) { return f_add(a, b); }
+  static T sub(T a, T b) { return f_sub(a, b); }
+  static T mul(T a, T b) { return f_mul(a, b); }
+  static T neg(T a) { return f_neg(a); }
+  static T mul_base(T a, u64 b) { return f_mul(a, b); }
   static T zero() { return 0; }
 };
 struct ExtOps {
-  typedef E2 T;
-  static T from_base(u64 c) { return E2{c, 0}; }
-  static T add(T a, T b) { return e2_add(a, b); }
-  static T sub(T a, T b) { return e2_sub(a, b); }
-  static T mul(T a, T b) { return e2_mul(a, b); }
-  static T neg(T a) { return e2_neg(a); }
-  static T mul_base(T a, u64 b) { return e2_mul_base(a, b); }
-  static T zero() { return E2{0, 0}; }
+  typedef EF T;
+  static T from_base(u64 c) { return ef(c); }
+  static T add(T a, T b) { return ef_add(a, b); }
+  static T sub(T a, T b) { return ef_sub(a, b); }
+  static T mul(T a, T b) { return ef_mul(a, b); }
+  static T neg(T a) { return ef_neg(a); }
+  static T mul_base(T a, u64 b) { return ef_mul_base(a, b); }
+  static T zero() { return ef(0); }
 };
 
 template <class O>
@@ -69,53 +69,59 @@ void sweep(const Circuit& c, const View<O>& v, std::vector<typename O::T>& buf, 
   }
 }
 
-// src/lookup.rs:123-128
+// src/lookup.rs:103-128: coordinate product in X^D = W on D coordinates of the working type (the values are the
+// coordinates of the extension product, whichever multiplication schedule - schoolbook or the D = 2 Karatsuba - is used)
 template <class O>
-inline void mul2(typename O::T a0, typename O::T a1, typename O::T b0, typename O::T b1, typename O::T& c0,
-                 typename O::T& c1) {
-  typename O::T v0 = O::mul(a0, b0), v1 = O::mul(a1, b1);
-  typename O::T cross = O::sub(O::sub(O::mul(O::add(a0, a1), O::add(b0, b1)), v0), v1);
-  c0 = O::add(v0, O::mul_base(v1, GL_EXT_W));
-  c1 = cross;
+inline void coord_mul(const typename O::T* a, const typename O::T* b, typename O::T* out) {
+  typedef typename O::T T;
+  T lo[EXT_D], hi[EXT_D];
+  for (unsigned k = 0; k < EXT_D; k++) lo[k] = hi[k] = O::zero();
+  for (unsigned i = 0; i < EXT_D; i++)
+    for (unsigned j = 0; j < EXT_D; j++) {
+      T p = O::mul(a[i], b[j]);
+      if (i + j < EXT_D)
+        lo[i + j] = O::add(lo[i + j], p);
+      else
+        hi[i + j - EXT_D] = O::add(hi[i + j - EXT_D], p);
+    }
+  for (unsigned k = 0; k < EXT_D; k++) out[k] = O::add(lo[k], O::mul_base(hi[k], EXT_W));
 }
 
-// src/lookup.rs:152-208 (the D = 2 path; the only extension degree of GoldilocksBlake3Config)
+// src/lookup.rs:152-256
 template <class O>
 void logup_constraint_values(const Circuit& c, const std::vector<typename O::T>& nv, const typename O::T* s2,
                              const typename O::T* s2n, const typename O::T* publics,
-                             const typename O::T delta_scaled[2], typename O::T is_last,
+                             const typename O::T* delta_scaled, typename O::T is_last,
                              std::vector<typename O::T>& out) {
   typedef typename O::T T;
-  T beta0 = publics[0], beta1 = publics[1], gamma0 = publics[2], gamma1 = publics[3];
-  T inj0 = O::mul(is_last, delta_scaled[0]), inj1 = O::mul(is_last, delta_scaled[1]);
+  const unsigned D = EXT_D;
+  const T* beta = publics;
+  const T* gamma = publics + D;
+  T inj[EXT_D];
+  for (unsigned k = 0; k < D; k++) inj[k] = O::mul(is_last, delta_scaled[k]);
   if (c.lookups.empty()) {
-    out.push_back(O::add(O::sub(s2n[0], s2[0]), inj0));
-    out.push_back(O::add(O::sub(s2n[1], s2[1]), inj1));
+    for (unsigned k = 0; k < D; k++) out.push_back(O::add(O::sub(s2n[k], s2[k]), inj[k]));
     return;
   }
   size_t last = c.lookups.size() - 1;
   for (size_t j = 0; j < c.lookups.size(); j++) {
     const Lookup& l = c.lookups[j];
-    T src0 = s2[2 * j], src1 = s2[2 * j + 1];
-    T tgt0, tgt1;
-    if (j < last) {
-      tgt0 = s2[2 * j + 2];
-      tgt1 = s2[2 * j + 3];
-    } else {
-      tgt0 = O::add(s2n[0], inj0);
-      tgt1 = O::add(s2n[1], inj1);
+    T diff[EXT_D];
+    for (unsigned k = 0; k < D; k++) {
+      T tgt = j < last ? s2[D * (j + 1) + k] : O::add(s2n[k], inj[k]);
+      diff[k] = O::sub(tgt, s2[D * j + k]);
     }
-    T f0 = O::zero(), f1 = O::zero();
-    for (size_t k = l.args.size(); k-- > 0;) {
-      T g0, g1;
-      mul2<O>(f0, f1, gamma0, gamma1, g0, g1);
-      f0 = O::add(g0, nv[l.args[k]]);
-      f1 = g1;
+    T f[EXT_D], g[EXT_D];
+    for (unsigned k = 0; k < D; k++) f[k] = O::zero();
+    for (size_t a = l.args.size(); a-- > 0;) {
+      coord_mul<O>(f, gamma, g);
+      for (unsigned k = 0; k < D; k++) f[k] = g[k];
+      f[0] = O::add(f[0], nv[l.args[a]]);
     }
-    T c0, c1;
-    mul2<O>(O::add(f0, beta0), O::add(f1, beta1), O::sub(tgt0, src0), O::sub(tgt1, src1), c0, c1);
-    out.push_back(O::sub(c0, nv[l.mult]));
-    out.push_back(c1);
+    for (unsigned k = 0; k < D; k++) f[k] = O::add(f[k], beta[k]);
+    coord_mul<O>(f, diff, g);
+    out.push_back(O::sub(g[0], nv[l.mult]));
+    for (unsigned k = 1; k < D; k++) out.push_back(g[k]);
   }
 }
 
@@ -187,81 +193,81 @@ Witness witness_from_stage_1(const System& sys, std::vector<Mat>&& traces) {
 
 // ------------------------------------------------------------------ lookups
 // src/lookup.rs:375-384: Horner over the reversed coefficients
-E2 fingerprint(E2 r, const u64* coeffs, size_t n) {
-  E2 acc = e2(0);
-  for (size_t k = n; k-- > 0;) acc = e2_add(e2_mul(acc, r), e2(coeffs[k]));
+EF fingerprint(EF r, const u64* coeffs, size_t n) {
+  EF acc = ef(0);
+  for (size_t k = n; k-- > 0;) acc = ef_add(ef_mul(acc, r), ef(coeffs[k]));
   return acc;
 }
 
 // src/prover.rs:382-387
-E2 claims_accumulator(const std::vector<std::vector<u64>>& claims, E2 beta, E2 gamma) {
-  E2 acc = e2(0);
+EF claims_accumulator(const std::vector<std::vector<u64>>& claims, EF beta, EF gamma) {
+  EF acc = ef(0);
   // exact field sum: order of additions is irrelevant, so the loop may be chunked
   size_t n = claims.size();
-  std::vector<E2> part;
+  std::vector<EF> part;
 #pragma omp parallel
   {
-    E2 local = e2(0);
+    EF local = ef(0);
 #pragma omp for schedule(static) nowait
     for (size_t i = 0; i < n; i++) {
-      E2 m = e2_add(beta, fingerprint(gamma, claims[i].data(), claims[i].size()));
-      local = e2_add(local, e2_inv(m));
+      EF m = ef_add(beta, fingerprint(gamma, claims[i].data(), claims[i].size()));
+      local = ef_add(local, ef_inv(m));
     }
 #pragma omp critical
-    acc = e2_add(acc, local);
+    acc = ef_add(acc, local);
   }
   return acc;
 }
 
 // p3_field::batch_multiplicative_inverse (values are mathematically determined)
-static void batch_inverse(std::vector<E2>& v) {
+static void batch_inverse(std::vector<EF>& v) {
   size_t n = v.size();
   const size_t CH = 1024;
 #pragma omp parallel for schedule(static)
   for (size_t s = 0; s < n; s += CH) {
     size_t e = std::min(n, s + CH);
-    std::vector<E2> pre(e - s);
-    E2 acc = e2(1);
+    std::vector<EF> pre(e - s);
+    EF acc = ef(1);
     for (size_t i = s; i < e; i++) {
       pre[i - s] = acc;
-      acc = e2_mul(acc, v[i]);
+      acc = ef_mul(acc, v[i]);
     }
-    E2 inv = e2_inv(acc);
+    EF inv = ef_inv(acc);
     for (size_t i = e; i-- > s;) {
-      E2 x = v[i];
-      v[i] = e2_mul(inv, pre[i - s]);
-      inv = e2_mul(inv, x);
+      EF x = v[i];
+      v[i] = ef_mul(inv, pre[i - s]);
+      inv = ef_mul(inv, x);
     }
   }
 }
 
 // src/lookup.rs:472-555
-void stage_2_traces(const std::vector<LookupValues>& circuits, E2 beta, E2 gamma, E2 accumulator,
-                    std::vector<std::vector<E2>>& traces, std::vector<E2>& accs) {
+void stage_2_traces(const std::vector<LookupValues>& circuits, EF beta, EF gamma, EF accumulator,
+                    std::vector<std::vector<EF>>& traces, std::vector<EF>& accs) {
   traces.clear();
   accs.clear();
   for (auto& c : circuits) {
     size_t nm = c.height * c.num_lookups;
-    std::vector<E2> msgs(nm);
+    std::vector<EF> msgs(nm);
     size_t aw = c.arg_offsets.empty() ? 0 : c.arg_offsets.back();
 #pragma omp parallel for schedule(static)
     for (size_t idx = 0; idx < nm; idx++) {
       size_t row = idx / c.num_lookups, l = idx % c.num_lookups;
       const u64* a = c.args.data() + row * aw + c.arg_offsets[l];
-      msgs[idx] = e2_add(beta, fingerprint(gamma, a, c.arg_offsets[l + 1] - c.arg_offsets[l]));
+      msgs[idx] = ef_add(beta, fingerprint(gamma, a, c.arg_offsets[l + 1] - c.arg_offsets[l]));
     }
     batch_inverse(msgs);
-    std::vector<E2> vec;
+    std::vector<EF> vec;
     if (c.num_lookups == 0) {
-      vec.assign(c.height, e2(0));
+      vec.assign(c.height, ef(0));
     } else {
       vec.resize(nm);
-      E2 local = e2(0);
+      EF local = ef(0);
       for (size_t idx = 0; idx < nm; idx++) {  // serial, as in the reference (src/lookup.rs:530-543)
         vec[idx] = local;
-        local = e2_add(local, e2_mul_base(msgs[idx], c.mult[idx]));
+        local = ef_add(local, ef_mul_base(msgs[idx], c.mult[idx]));
       }
-      accumulator = e2_add(accumulator, local);
+      accumulator = ef_add(accumulator, local);
     }
     accs.push_back(accumulator);
     traces.push_back(std::move(vec));
@@ -273,16 +279,16 @@ void stage_2_traces(const std::vector<LookupValues>& circuits, E2 beta, E2 gamma
 // src/lookup.rs:697-756]
 Selectors selectors_on_coset(unsigned log_n, unsigned log_q) {
   size_t n = size_t(1) << log_n, q = size_t(1) << log_q, N = n * q;
-  u64 s_pow_n = gl_exp_pow2(GL_GENERATOR, log_n);
+  u64 s_pow_n = f_exp_pow2(F_GENERATOR, log_n);
   std::vector<u64> zh(q), zh_inv(q);
-  u64 wq = gl_two_adic_generator(log_q), x = 1;
+  u64 wq = f_two_adic_generator(log_q), x = 1;
   for (size_t j = 0; j < q; j++) {
-    zh[j] = gl_sub(gl_mul(s_pow_n, x), 1);
-    zh_inv[j] = gl_inv(zh[j]);
-    x = gl_mul(x, wq);
+    zh[j] = f_sub(f_mul(s_pow_n, x), 1);
+    zh_inv[j] = f_inv(zh[j]);
+    x = f_mul(x, wq);
   }
-  u64 g_inv = gl_inv(gl_two_adic_generator(log_n));
-  u64 wN = gl_two_adic_generator(log_n + log_q);
+  u64 g_inv = f_inv(f_two_adic_generator(log_n));
+  u64 wN = f_two_adic_generator(log_n + log_q);
   Selectors s;
   s.is_first.resize(N);
   s.is_last.resize(N);
@@ -292,37 +298,37 @@ Selectors selectors_on_coset(unsigned log_n, unsigned log_q) {
 #pragma omp parallel for schedule(static)
   for (size_t st = 0; st < N; st += CH) {
     size_t en = std::min(N, st + CH);
-    u64 xi = gl_mul(GL_GENERATOR, gl_pow(wN, st));
+    u64 xi = f_mul(F_GENERATOR, f_pow(wN, st));
     for (size_t i = st; i < en; i++) {
-      s.is_first[i] = gl_mul(zh[i % q], gl_inv(gl_sub(xi, 1)));
-      s.is_last[i] = gl_mul(zh[i % q], gl_inv(gl_sub(xi, g_inv)));
-      s.is_trans[i] = gl_sub(xi, g_inv);
+      s.is_first[i] = f_mul(zh[i % q], f_inv(f_sub(xi, 1)));
+      s.is_last[i] = f_mul(zh[i % q], f_inv(f_sub(xi, g_inv)));
+      s.is_trans[i] = f_sub(xi, g_inv);
       s.inv_van[i] = zh_inv[i % q];
-      xi = gl_mul(xi, wN);
+      xi = f_mul(xi, wN);
     }
   }
   return s;
 }
 
 // ------------------------------------------------------------------ quotient (src/prover.rs:756-962)
-std::vector<E2> quotient_values(const Circuit& c, const u64 publics[8], unsigned log_n, unsigned log_q,
-                                const Mat* pre_q, const Mat& s1_q, const Mat& s2_q, E2 alpha) {
+std::vector<EF> quotient_values(const Circuit& c, const u64* publics, unsigned log_n, unsigned log_q,
+                                const Mat* pre_q, const Mat& s1_q, const Mat& s2_q, EF alpha) {
   size_t n = size_t(1) << log_n, q = size_t(1) << log_q, N = n * q;
   Selectors sels = selectors_on_coset(log_n, log_q);
-  u64 g = gl_two_adic_generator(log_n);
-  u64 inj_norm = gl_inv(gl_mul((u64)n % GL_P, g));
+  u64 g = f_two_adic_generator(log_n);
+  u64 inj_norm = f_inv(f_mul((u64)n % F_P, g));
   size_t next_step = q;
   size_t k = c.constraint_count;
   // reversed alpha powers, src/prover.rs:798-808
-  std::vector<E2> apow(k);
-  E2 a = e2(1);
+  std::vector<EF> apow(k);
+  EF a = ef(1);
   for (size_t i = 0; i < k; i++) {
     apow[k - 1 - i] = a;
-    a = e2_mul(a, alpha);
+    a = ef_mul(a, alpha);
   }
-  u64 delta_scaled[2] = {gl_mul(gl_sub(publics[6], publics[4]), inj_norm),
-                         gl_mul(gl_sub(publics[7], publics[5]), inj_norm)};
-  std::vector<E2> out(N);
+  u64 delta_scaled[EXT_D];  // (acc_final - acc_initial) / (n g): publics = beta, gamma, acc_initial, acc_final
+  for (unsigned d = 0; d < EXT_D; d++) delta_scaled[d] = f_mul(f_sub(publics[3 * EXT_D + d], publics[2 * EXT_D + d]), inj_norm);
+  std::vector<EF> out(N);
 #pragma omp parallel
   {
     std::vector<u64> buf, cv;
@@ -344,12 +350,9 @@ std::vector<E2> quotient_values(const Circuit& c, const u64 publics[8], unsigned
       cv.clear();
       for (auto z : c.zeros) cv.push_back(buf[z]);
       logup_constraint_values<BaseOps>(c, buf, v.s2[0], v.s2[1], publics, delta_scaled, v.is_last, cv);
-      u64 acc0 = 0, acc1 = 0;
-      for (size_t j = 0; j < k; j++) {
-        acc0 = gl_add(acc0, gl_mul(cv[j], apow[j].c0));
-        acc1 = gl_add(acc1, gl_mul(cv[j], apow[j].c1));
-      }
-      out[i] = E2{gl_mul(acc0, sels.inv_van[i]), gl_mul(acc1, sels.inv_van[i])};
+      EF acc = ef(0);
+      for (size_t j = 0; j < k; j++) acc = ef_add(acc, ef_mul_base(apow[j], cv[j]));
+      out[i] = ef_mul_base(acc, sels.inv_van[i]);
     }
   }
   return out;
@@ -361,26 +364,26 @@ std::vector<E2> quotient_values(const Circuit& c, const u64 publics[8], unsigned
 namespace {
 struct OpenRound {
   const MerkleTree* tree;
-  std::vector<std::vector<E2>> points;  // per matrix
+  std::vector<std::vector<EF>> points;  // per matrix
 };
 
 struct E2Less {
-  bool operator()(const E2& a, const E2& b) const { return a.c0 != b.c0 ? a.c0 < b.c0 : a.c1 < b.c1; }
+  bool operator()(const EF& a, const EF& b) const { return ef_less(a, b); }
 };
 
 // x_i = GENERATOR * w_H^{bitrev(i)}; coset[..2^k] is the bit-reversed coset of size 2^k
 std::vector<u64> bitrev_coset(unsigned log_h) {
   size_t H = size_t(1) << log_h;
   std::vector<u64> xs(H);
-  u64 w = gl_two_adic_generator(log_h);
+  u64 w = f_two_adic_generator(log_h);
   const size_t CH = 4096;
 #pragma omp parallel for schedule(static)
   for (size_t st = 0; st < H; st += CH) {
     size_t en = std::min(H, st + CH);
-    u64 x = gl_mul(GL_GENERATOR, gl_pow(w, st));
+    u64 x = f_mul(F_GENERATOR, f_pow(w, st));
     for (size_t i = st; i < en; i++) {
       xs[bitrev(i, log_h)] = x;
-      x = gl_mul(x, w);
+      x = f_mul(x, w);
     }
   }
   return xs;
@@ -388,32 +391,32 @@ std::vector<u64> bitrev_coset(unsigned log_h) {
 
 // FRI fold of one layer: rows (lo, hi) = evaluations at (x, -x) with x = w_{2R}^{bitrev(i)} (no coset shift:
 // p3 folds over the subgroup), result (lo+hi)/2 + beta (lo-hi)/(2x).
-std::vector<E2> fri_fold_matrix(E2 beta, const std::vector<E2>& cur) {
+std::vector<EF> fri_fold_matrix(EF beta, const std::vector<EF>& cur) {
   size_t rows = cur.size() / 2;
   unsigned lr = log2_strict(rows);
-  u64 g_inv = gl_inv(gl_two_adic_generator(lr + 1));
-  u64 half = gl_inv(2);
-  E2 half_beta = e2_mul_base(beta, half);
-  std::vector<E2> out(rows);
+  u64 g_inv = f_inv(f_two_adic_generator(lr + 1));
+  u64 half = f_inv(2);
+  EF half_beta = ef_mul_base(beta, half);
+  std::vector<EF> out(rows);
   const size_t CH = 4096;
 #pragma omp parallel for schedule(static)
   for (size_t st = 0; st < rows; st += CH) {
     size_t en = std::min(rows, st + CH);
-    u64 gp = gl_pow(g_inv, st);
+    u64 gp = f_pow(g_inv, st);
     for (size_t j = st; j < en; j++) {
       // power index j (natural) lands at row bitrev(j)
       size_t i = bitrev(j, lr);
-      E2 pw = e2_mul_base(half_beta, gp);
-      E2 lo = cur[2 * i], hi = cur[2 * i + 1];
-      out[i] = e2_add(e2_mul(e2_add(e2(half), pw), lo), e2_mul(e2_sub(e2(half), pw), hi));
-      gp = gl_mul(gp, g_inv);
+      EF pw = ef_mul_base(half_beta, gp);
+      EF lo = cur[2 * i], hi = cur[2 * i + 1];
+      out[i] = ef_add(ef_mul(ef_add(ef(half), pw), lo), ef_mul(ef_sub(ef(half), pw), hi));
+      gp = f_mul(gp, g_inv);
     }
   }
   return out;
 }
 
 // roll-in factor for a reduced opening of matching height: beta^2
-E2 fri_roll_in_factor(E2 beta) { return e2_square(beta); }
+EF fri_roll_in_factor(EF beta) { return ef_square(beta); }
 
 void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenger& ch,
               std::vector<OpenedRound>& opened, FriProof& proof) {
@@ -426,19 +429,19 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
   std::vector<u64> coset = bitrev_coset(log_gmax);
 
   // inverse denominators 1/(z - x) per unique point, for the largest height opened there
-  std::map<E2, size_t, E2Less> max_h;
+  std::map<EF, size_t, E2Less> max_h;
   for (auto& r : rounds)
     for (size_t mi = 0; mi < r.tree->mats.size(); mi++)
       for (auto& z : r.points[mi]) {
         size_t& h = max_h[z];
         h = std::max(h, r.tree->mats[mi].h);
       }
-  std::map<E2, std::vector<E2>, E2Less> inv_denoms;
+  std::map<EF, std::vector<EF>, E2Less> inv_denoms;
   for (auto& kv : max_h) {
-    std::vector<E2> d(kv.second);
-    E2 z = kv.first;
+    std::vector<EF> d(kv.second);
+    EF z = kv.first;
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < d.size(); i++) d[i] = e2_sub(z, e2(coset[i]));
+    for (size_t i = 0; i < d.size(); i++) d[i] = ef_sub(z, ef(coset[i]));
     batch_inverse(d);
     inv_denoms.emplace(z, std::move(d));
   }
@@ -451,28 +454,28 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
       const Mat& mat = r.tree->mats[mi];
       size_t h = mat.h >> lb;
       unsigned log_h = log2_strict(h);
-      std::vector<std::vector<E2>> per_point;
+      std::vector<std::vector<EF>> per_point;
       for (auto& z : r.points[mi]) {
-        const std::vector<E2>& dinv = inv_denoms.at(z);
-        std::vector<E2> sums(mat.w, e2(0));
+        const std::vector<EF>& dinv = inv_denoms.at(z);
+        std::vector<EF> sums(mat.w, ef(0));
 #pragma omp parallel
         {
-          std::vector<E2> loc(mat.w, e2(0));
+          std::vector<EF> loc(mat.w, ef(0));
 #pragma omp for schedule(static) nowait
           for (size_t i = 0; i < h; i++) {
-            E2 cs = e2_mul_base(dinv[i], coset[i]);
+            EF cs = ef_mul_base(dinv[i], coset[i]);
             const u64* row = &mat.v[i * mat.w];
-            for (size_t c = 0; c < mat.w; c++) loc[c] = e2_add(loc[c], e2_mul_base(cs, row[c]));
+            for (size_t c = 0; c < mat.w; c++) loc[c] = ef_add(loc[c], ef_mul_base(cs, row[c]));
           }
 #pragma omp critical
-          for (size_t c = 0; c < mat.w; c++) sums[c] = e2_add(sums[c], loc[c]);
+          for (size_t c = 0; c < mat.w; c++) sums[c] = ef_add(sums[c], loc[c]);
         }
-        u64 s_pow = gl_exp_pow2(GL_GENERATOR, log_h);
-        E2 vanish = e2_sub(e2_exp_pow2(z, log_h), e2(s_pow));
-        u64 denom = gl_mul(s_pow, (u64)h % GL_P);
-        E2 scale = e2_mul_base(vanish, gl_inv(denom));
+        u64 s_pow = f_exp_pow2(F_GENERATOR, log_h);
+        EF vanish = ef_sub(ef_exp_pow2(z, log_h), ef(s_pow));
+        u64 denom = f_mul(s_pow, (u64)h % F_P);
+        EF scale = ef_mul_base(vanish, f_inv(denom));
         for (auto& y : sums) {
-          y = e2_mul(y, scale);
+          y = ef_mul(y, scale);
           ch.observe_ext(y);
         }
         per_point.push_back(std::move(sums));
@@ -482,16 +485,16 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
     opened.push_back(std::move(orr));
   }
 
-  E2 alpha = ch.sample_ext();
+  EF alpha = ch.sample_ext();
   size_t gw = 0;
   for (auto& r : rounds)
     for (auto& m : r.tree->mats) gw = std::max(gw, m.w);
-  std::vector<E2> apow(gw + 1);
-  apow[0] = e2(1);
-  for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
+  std::vector<EF> apow(gw + 1);
+  apow[0] = ef(1);
+  for (size_t i = 1; i <= gw; i++) apow[i] = ef_mul(apow[i - 1], alpha);
 
   std::vector<size_t> num_reduced(33, 0);
-  std::vector<std::vector<E2>> reduced(33);
+  std::vector<std::vector<EF>> reduced(33);
   std::vector<bool> present(33, false);
   for (size_t ri = 0; ri < rounds.size(); ri++) {
     auto& r = rounds[ri];
@@ -500,33 +503,33 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
       unsigned lh = log2_strict(mat.h);
       if (!present[lh]) {
         present[lh] = true;
-        reduced[lh].assign(mat.h, e2(0));
+        reduced[lh].assign(mat.h, ef(0));
       }
       if (r.points[mi].empty()) continue;
-      std::vector<E2> comp(mat.h);
+      std::vector<EF> comp(mat.h);
 #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < mat.h; i++) {
-        E2 s = e2(0);
+        EF s = ef(0);
         const u64* row = &mat.v[i * mat.w];
-        for (size_t c = 0; c < mat.w; c++) s = e2_add(s, e2_mul_base(apow[c], row[c]));
+        for (size_t c = 0; c < mat.w; c++) s = ef_add(s, ef_mul_base(apow[c], row[c]));
         comp[i] = s;
       }
       for (size_t pi = 0; pi < r.points[mi].size(); pi++) {
-        const E2 z = r.points[mi][pi];
-        const std::vector<E2>& ys = opened[ri][mi][pi];
-        E2 off = e2_pow(alpha, num_reduced[lh]);
-        E2 red_z = e2(0);
-        for (size_t c = 0; c < mat.w; c++) red_z = e2_add(red_z, e2_mul(apow[c], ys[c]));
-        const std::vector<E2>& dinv = inv_denoms.at(z);
-        std::vector<E2>& ro = reduced[lh];
+        const EF z = r.points[mi][pi];
+        const std::vector<EF>& ys = opened[ri][mi][pi];
+        EF off = ef_pow(alpha, num_reduced[lh]);
+        EF red_z = ef(0);
+        for (size_t c = 0; c < mat.w; c++) red_z = ef_add(red_z, ef_mul(apow[c], ys[c]));
+        const std::vector<EF>& dinv = inv_denoms.at(z);
+        std::vector<EF>& ro = reduced[lh];
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < mat.h; i++)
-          ro[i] = e2_add(ro[i], e2_mul(e2_mul(off, e2_sub(red_z, comp[i])), dinv[i]));
+          ro[i] = ef_add(ro[i], ef_mul(ef_mul(off, ef_sub(red_z, comp[i])), dinv[i]));
         num_reduced[lh] += mat.w;
       }
     }
   }
-  std::vector<std::vector<E2>> inputs;
+  std::vector<std::vector<EF>> inputs;
   for (int lh = 32; lh >= 0; lh--)
     if (present[lh]) inputs.push_back(std::move(reduced[lh]));
 
@@ -534,7 +537,7 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
   size_t final_len = size_t(1) << prm.log_final_poly_len;
   size_t stop = (size_t(1) << lb) * final_len;
   std::vector<MerkleTree> fri_trees;
-  std::vector<E2> folded = std::move(inputs[0]);
+  std::vector<EF> folded = std::move(inputs[0]);
   size_t next_in = 1;
   unsigned log_max_height = log2_strict(folded.size());
   proof = FriProof();
@@ -547,13 +550,11 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
   }
   while (folded.size() > stop) {
     size_t rows = folded.size() / 2;
-    Mat leaves(rows, 4);  // ExtensionMmcs: width-2 extension rows flattened to 4 base columns
+    Mat leaves(rows, 2 * EXT_D);  // ExtensionMmcs: width-2 extension rows flattened to 2 D base columns
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < rows; i++) {
-      leaves.v[4 * i] = folded[2 * i].c0;
-      leaves.v[4 * i + 1] = folded[2 * i].c1;
-      leaves.v[4 * i + 2] = folded[2 * i + 1].c0;
-      leaves.v[4 * i + 3] = folded[2 * i + 1].c1;
+      ef_to(folded[2 * i], &leaves.v[2 * EXT_D * i]);
+      ef_to(folded[2 * i + 1], &leaves.v[2 * EXT_D * i + EXT_D]);
     }
     fri_trees.emplace_back();
     std::vector<Mat> one;
@@ -563,13 +564,13 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
     ch.observe_cap(cap);
     proof.commit_phase_commits.push_back(cap);
     proof.commit_pow_witnesses.push_back(ch.grind((unsigned)prm.commit_pow_bits));
-    E2 beta = ch.sample_ext();
+    EF beta = ch.sample_ext();
     folded = fri_fold_matrix(beta, folded);
     if (next_in < inputs.size() && inputs[next_in].size() == folded.size()) {
-      E2 f = fri_roll_in_factor(beta);
-      const std::vector<E2>& in = inputs[next_in++];
+      EF f = fri_roll_in_factor(beta);
+      const std::vector<EF>& in = inputs[next_in++];
 #pragma omp parallel for schedule(static)
-      for (size_t i = 0; i < folded.size(); i++) folded[i] = e2_add(folded[i], e2_mul(f, in[i]));
+      for (size_t i = 0; i < folded.size(); i++) folded[i] = ef_add(folded[i], ef_mul(f, in[i]));
     }
   }
   if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
@@ -577,16 +578,12 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
   folded.resize(final_len);
   {
     unsigned lf = (unsigned)prm.log_final_poly_len;
-    Mat m(final_len, 2);
-    for (size_t i = 0; i < final_len; i++) {
-      size_t j = bitrev(i, lf);
-      m.v[2 * j] = folded[i].c0;
-      m.v[2 * j + 1] = folded[i].c1;
-    }
+    Mat m(final_len, EXT_D);
+    for (size_t i = 0; i < final_len; i++) ef_to(folded[i], &m.v[EXT_D * bitrev(i, lf)]);
     Mat c = idft_batch(m);
     proof.final_poly.resize(final_len);
     for (size_t i = 0; i < final_len; i++) {
-      proof.final_poly[i] = E2{c.v[2 * i], c.v[2 * i + 1]};
+      proof.final_poly[i] = ef_from(&c.v[EXT_D * i]);
       ch.observe_ext(proof.final_poly[i]);
     }
   }
@@ -606,7 +603,7 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
       CommitPhaseStep st;
       st.log_arity = 1;
       const std::vector<u64>& row = bo.opened_values[0];
-      st.sibling_values.push_back(E2{row[2 * (sib % 2)], row[2 * (sib % 2) + 1]});
+      st.sibling_values.push_back(ef_from(&row[EXT_D * (sib % 2)]));
       st.proof = std::move(bo.proof);
       qp.commit_phase_openings.push_back(std::move(st));
     }
@@ -629,7 +626,7 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
   unsigned lb = (unsigned)prm.log_blowup;
   size_t C = sys.circuits.size();
   if (witness.traces.size() != C || witness.lookups.size() != C) throw std::runtime_error("witness/circuit count mismatch");
-  Challenger ch(sys.challenger_seed());
+  Challenger ch = sys.new_challenger();
   sys.observe_shape(ch);
   Proof proof;
   std::vector<size_t> active_idx;
@@ -656,7 +653,7 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
       if (tr.h & (tr.h - 1)) throw std::runtime_error("trace height must be a power of two");
       if (tr.w != sys.circuits[ci].main_width) throw std::runtime_error("trace width mismatch");
       log_degrees.push_back(log2_strict(tr.h));
-      ldes.push_back(coset_lde_bitrev(tr, lb, GL_GENERATOR));
+      ldes.push_back(coset_lde_bitrev(tr, lb, F_GENERATOR));
     }
     mmcs_commit(std::move(ldes), (unsigned)prm.cap_height, s1_tree);
   }
@@ -666,20 +663,20 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
   if (sys.has_pre) ch.observe_cap(sys.pre_commit);
   ch.observe_cap(proof.stage1_commit);
   for (unsigned ld : log_degrees) ch.observe(ld);
-  ch.observe((u64)claims.size());
+  ch.observe(f_from_u64((u64)claims.size()));
   for (auto& c : claims) {
-    ch.observe((u64)c.size());
+    ch.observe(f_from_u64((u64)c.size()));
     for (u64 x : c) ch.observe(x);
   }
-  E2 beta = ch.sample_ext();
+  EF beta = ch.sample_ext();
   ch.observe_ext(beta);
-  E2 gamma = ch.sample_ext();
+  EF gamma = ch.sample_ext();
   ch.observe_ext(gamma);
-  E2 acc = claims_accumulator(claims, beta, gamma);
+  EF acc = claims_accumulator(claims, beta, gamma);
 
   // lookup construction
   t0 = now_s();
-  std::vector<std::vector<E2>> s2_traces;
+  std::vector<std::vector<EF>> s2_traces;
   {
     std::vector<LookupValues> active_lookups;
     for (size_t ci : active_idx) {
@@ -701,12 +698,9 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
       const Circuit& c = sys.circuits[active_idx[pos]];
       size_t n = size_t(1) << log_degrees[pos];
       Mat flat(n, c.stage2_width);
-      const std::vector<E2>& t = s2_traces[pos];
-      for (size_t i = 0; i < t.size(); i++) {
-        flat.v[2 * i] = t[i].c0;
-        flat.v[2 * i + 1] = t[i].c1;
-      }
-      ldes.push_back(coset_lde_bitrev(flat, lb, GL_GENERATOR));
+      const std::vector<EF>& t = s2_traces[pos];
+      for (size_t i = 0; i < t.size(); i++) ef_to(t[i], &flat.v[EXT_D * i]);
+      ldes.push_back(coset_lde_bitrev(flat, lb, F_GENERATOR));
     }
     s2_traces.clear();
     mmcs_commit(std::move(ldes), (unsigned)prm.cap_height, s2_tree);
@@ -715,7 +709,7 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
   if (times) times->stage2_commit = now_s() - t0;
   ch.observe_cap(proof.stage2_commit);
   for (auto& a : proof.intermediate_accumulators) ch.observe_ext(a);
-  E2 alpha = ch.sample_ext();
+  EF alpha = ch.sample_ext();
 
   // quotient
   t0 = now_s();
@@ -728,21 +722,19 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
       size_t qd = c.quotient_degree();
       unsigned log_q = log2_strict(qd), log_n = log_degrees[pos];
       size_t qsize = size_t(1) << (log_n + log_q);
-      E2 next_acc = proof.intermediate_accumulators[pos];
+      EF next_acc = proof.intermediate_accumulators[pos];
       Mat pre_q;
       bool has_pre = sys.has_pre && sys.pre_indices[ci] >= 0;
       if (has_pre) pre_q = evaluations_on_domain(sys.pre_tree.mats[sys.pre_indices[ci]], qsize);
       Mat s1_q = evaluations_on_domain(s1_tree.mats[pos], qsize);
       Mat s2_q = evaluations_on_domain(s2_tree.mats[pos], qsize);
-      u64 publics[8] = {beta.c0, beta.c1, gamma.c0, gamma.c1, acc.c0, acc.c1, next_acc.c0, next_acc.c1};
-      std::vector<E2> qv = quotient_values(c, publics, log_n, log_q, has_pre ? &pre_q : nullptr, s1_q, s2_q, alpha);
-      Mat qflat(qsize, 2);
-      for (size_t i = 0; i < qsize; i++) {
-        qflat.v[2 * i] = qv[i].c0;
-        qflat.v[2 * i + 1] = qv[i].c1;
-      }
+      u64 publics[4 * EXT_D];  // src/lookup.rs:82-84: beta, gamma, acc_initial, acc_final
+      ef_to(beta, publics), ef_to(gamma, publics + EXT_D), ef_to(acc, publics + 2 * EXT_D), ef_to(next_acc, publics + 3 * EXT_D);
+      std::vector<EF> qv = quotient_values(c, publics, log_n, log_q, has_pre ? &pre_q : nullptr, s1_q, s2_q, alpha);
+      Mat qflat(qsize, EXT_D);
+      for (size_t i = 0; i < qsize; i++) ef_to(qv[i], &qflat.v[EXT_D * i]);
       acc = next_acc;
-      Mat sliced = shifted_quotient_slices(qflat, GL_GENERATOR, qd);
+      Mat sliced = shifted_quotient_slices(qflat, F_GENERATOR, qd);
       q_ldes.push_back(lde_from_shifted_coefficients(sliced, lb));
     }
     mmcs_commit(std::move(q_ldes), (unsigned)prm.cap_height, q_tree);
@@ -753,13 +745,13 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
 
   // opening
   t0 = now_s();
-  E2 zeta = ch.sample_ext();
+  EF zeta = ch.sample_ext();
   std::vector<OpenRound> rounds(3);
   rounds[0].tree = &s1_tree;
   rounds[1].tree = &s2_tree;
   rounds[2].tree = &q_tree;
   for (unsigned ld : log_degrees) {
-    E2 zn = e2_mul_base(zeta, gl_two_adic_generator(ld));
+    EF zn = ef_mul_base(zeta, f_two_adic_generator(ld));
     rounds[0].points.push_back({zeta, zn});
     rounds[1].points.push_back({zeta, zn});
     rounds[2].points.push_back({zeta});
@@ -770,7 +762,7 @@ Proof prove(const System& sys, const std::vector<std::vector<u64>>& claims, Witn
     for (size_t ci = 0; ci < C; ci++) {
       if (sys.pre_indices[ci] < 0) continue;
       if (active_pos[ci] >= 0) {
-        E2 zn = e2_mul_base(zeta, gl_two_adic_generator(log_degrees[active_pos[ci]]));
+        EF zn = ef_mul_base(zeta, f_two_adic_generator(log_degrees[active_pos[ci]]));
         r0.points.push_back({zeta, zn});
       } else {
         r0.points.push_back({});
@@ -801,7 +793,7 @@ struct RoundClaim {
   std::vector<Digest> commit;
   // per matrix: log trace height, and (point, values) pairs
   std::vector<unsigned> log_n;
-  std::vector<std::vector<std::pair<E2, std::vector<E2>>>> mats;
+  std::vector<std::vector<std::pair<EF, std::vector<EF>>>> mats;
 };
 
 // [UPSTREAM-RECALL p3-fri TwoAdicFriPcs::verify + verifier::verify_fri / verify_query]
@@ -811,11 +803,11 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
     for (auto& m : r.mats)
       for (auto& pv : m)
         for (auto& y : pv.second) ch.observe_ext(y);
-  E2 alpha = ch.sample_ext();
+  EF alpha = ch.sample_ext();
   size_t nrounds = proof.commit_phase_commits.size();
   if (proof.commit_pow_witnesses.size() != nrounds) return false;
   unsigned log_gmax = (unsigned)(nrounds + lb + prm.log_final_poly_len);
-  std::vector<E2> betas;
+  std::vector<EF> betas;
   for (size_t i = 0; i < nrounds; i++) {
     ch.observe_cap(proof.commit_phase_commits[i]);
     if (!ch.check_witness((unsigned)prm.commit_pow_bits, proof.commit_pow_witnesses[i])) return false;
@@ -830,7 +822,7 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
     size_t index = ch.sample_bits(log_gmax);
     if (qp.input_proof.size() != rounds.size()) return false;
     // open_input: per-height reduced openings
-    std::map<unsigned, std::pair<E2, E2>> ro;  // log_height -> (alpha_pow, reduced opening)
+    std::map<unsigned, std::pair<EF, EF>> ro;  // log_height -> (alpha_pow, reduced opening)
     for (size_t ri = 0; ri < rounds.size(); ri++) {
       const RoundClaim& r = rounds[ri];
       const BatchOpening& bo = qp.input_proof[ri];
@@ -847,16 +839,16 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
       for (size_t mi = 0; mi < r.mats.size(); mi++) {
         unsigned lh = r.log_n[mi] + lb;
         size_t rev = bitrev(index >> (log_gmax - lh), lh);
-        u64 x = gl_mul(GL_GENERATOR, gl_pow(gl_two_adic_generator(lh), rev));
+        u64 x = f_mul(F_GENERATOR, f_pow(f_two_adic_generator(lh), rev));
         auto it = ro.find(lh);
-        if (it == ro.end()) it = ro.emplace(lh, std::make_pair(e2(1), e2(0))).first;
+        if (it == ro.end()) it = ro.emplace(lh, std::make_pair(ef(1), ef(0))).first;
         for (auto& pv : r.mats[mi]) {
           if (pv.second.size() != bo.opened_values[mi].size()) return false;
-          E2 quot = e2_inv(e2_sub(pv.first, e2(x)));
+          EF quot = ef_inv(ef_sub(pv.first, ef(x)));
           for (size_t c = 0; c < pv.second.size(); c++) {
-            E2 diff = e2_sub(pv.second[c], e2(bo.opened_values[mi][c]));
-            it->second.second = e2_add(it->second.second, e2_mul(e2_mul(it->second.first, diff), quot));
-            it->second.first = e2_mul(it->second.first, alpha);
+            EF diff = ef_sub(pv.second[c], ef(bo.opened_values[mi][c]));
+            it->second.second = ef_add(it->second.second, ef_mul(ef_mul(it->second.first, diff), quot));
+            it->second.first = ef_mul(it->second.first, alpha);
           }
         }
       }
@@ -864,14 +856,14 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
     // a height-1 trace gives a constant polynomial: its reduced opening must vanish
     auto low = ro.find(lb);
     if (low != ro.end() && log_final_height >= lb && lb < log_gmax) {
-      if (!(low->second.second.c0 == 0 && low->second.second.c1 == 0)) return false;
+      if (!ef_is_zero(low->second.second)) return false;
       ro.erase(low);
     }
     // verify_query
     if (qp.commit_phase_openings.size() != nrounds) return false;
     auto it = ro.rbegin();
     if (it == ro.rend() || it->first != log_gmax) return false;
-    E2 folded = it->second.second;
+    EF folded = it->second.second;
     ++it;
     size_t idx = index;
     for (size_t i = 0; i < nrounds; i++) {
@@ -879,31 +871,32 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
       const CommitPhaseStep& st = qp.commit_phase_openings[i];
       if (st.log_arity != 1 || st.sibling_values.size() != 1) return false;
       size_t sib = idx ^ 1, pair = idx >> 1;
-      E2 evals[2];
+      EF evals[2];
       evals[idx % 2] = folded;
       evals[sib % 2] = st.sibling_values[0];
       BatchOpening bo;
-      bo.opened_values.push_back({evals[0].c0, evals[0].c1, evals[1].c0, evals[1].c1});
+      bo.opened_values.emplace_back(2 * EXT_D);
+      ef_to(evals[0], bo.opened_values[0].data()), ef_to(evals[1], bo.opened_values[0].data() + EXT_D);
       bo.proof = st.proof;
-      if (!mmcs_verify_batch(proof.commit_phase_commits[i], {Dim{4, size_t(1) << log_folded_height}}, pair, bo))
+      if (!mmcs_verify_batch(proof.commit_phase_commits[i], {Dim{2 * EXT_D, size_t(1) << log_folded_height}}, pair, bo))
         return false;
       idx = pair;
       // fold_row: interpolate (x0, e0), (-x0, e1) and evaluate at beta
-      u64 x0 = gl_pow(gl_two_adic_generator(log_folded_height + 1), bitrev(idx, log_folded_height));
-      u64 x1 = gl_neg(x0);
-      E2 slope = e2_mul_base(e2_sub(evals[1], evals[0]), gl_inv(gl_sub(x1, x0)));
-      folded = e2_add(evals[0], e2_mul(e2_sub(betas[i], e2(x0)), slope));
+      u64 x0 = f_pow(f_two_adic_generator(log_folded_height + 1), bitrev(idx, log_folded_height));
+      u64 x1 = f_neg(x0);
+      EF slope = ef_mul_base(ef_sub(evals[1], evals[0]), f_inv(f_sub(x1, x0)));
+      folded = ef_add(evals[0], ef_mul(ef_sub(betas[i], ef(x0)), slope));
       if (it != ro.rend() && it->first == log_folded_height) {
-        folded = e2_add(folded, e2_mul(fri_roll_in_factor(betas[i]), it->second.second));
+        folded = ef_add(folded, ef_mul(fri_roll_in_factor(betas[i]), it->second.second));
         ++it;
       }
     }
     if (it != ro.rend()) return false;
     // final polynomial at x = w_{gmax}^{bitrev(idx, log_gmax)} (idx is now log_final_height bits wide)
-    u64 x = gl_pow(gl_two_adic_generator(log_gmax), bitrev(idx, log_gmax));
-    E2 eval = e2(0);
-    for (size_t k = proof.final_poly.size(); k-- > 0;) eval = e2_add(e2_mul_base(eval, x), proof.final_poly[k]);
-    if (!e2_eq(eval, folded)) return false;
+    u64 x = f_pow(f_two_adic_generator(log_gmax), bitrev(idx, log_gmax));
+    EF eval = ef(0);
+    for (size_t k = proof.final_poly.size(); k-- > 0;) eval = ef_add(ef_mul_base(eval, x), proof.final_poly[k]);
+    if (!ef_eq(eval, folded)) return false;
   }
   return true;
 }
@@ -946,7 +939,7 @@ VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claim
     }
   }
   std::vector<size_t> qdeg;
-  size_t max_log_degree = 32 - prm.log_blowup;  // src/types.rs:131
+  size_t max_log_degree = F_TWO_ADICITY - prm.log_blowup;  // src/types.rs:131, baby_bear_config.rs:87
   for (size_t pos = 0; pos < na; pos++) {
     size_t qd = sys.circuits[active_idx[pos]].quotient_degree();
     if (proof.log_degrees[pos] + log2_strict(qd) > max_log_degree) return V_INVALID_SHAPE;
@@ -955,37 +948,36 @@ VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claim
   if (proof.quotient_opened.size() != na) return V_INVALID_SHAPE;
   for (size_t pos = 0; pos < na; pos++) {
     if (proof.quotient_opened[pos].size() != 1) return V_INVALID_SHAPE;
-    if (proof.quotient_opened[pos][0].size() != qdeg[pos] * 2) return V_INVALID_SHAPE;
+    if (proof.quotient_opened[pos][0].size() != qdeg[pos] * EXT_D) return V_INVALID_SHAPE;
   }
   if (proof.intermediate_accumulators.size() != na) return V_INVALID_SHAPE;
 
   // ---- src/verifier.rs:242-246
   {
-    E2 last = proof.intermediate_accumulators.back();
-    if (!(last.c0 == 0 && last.c1 == 0)) return V_UNBALANCED;
+    if (!ef_is_zero(proof.intermediate_accumulators.back())) return V_UNBALANCED;
   }
   // ---- transcript replay, src/verifier.rs:255-326
-  Challenger ch(sys.challenger_seed());
+  Challenger ch = sys.new_challenger();
   sys.observe_shape(ch);
   for (auto a : proof.active) ch.observe(a ? 1 : 0);
   if (sys.has_pre) ch.observe_cap(sys.pre_commit);
   ch.observe_cap(proof.stage1_commit);
   for (auto ld : proof.log_degrees) ch.observe((u64)ld);
-  ch.observe((u64)claims.size());
+  ch.observe(f_from_u64((u64)claims.size()));
   for (auto& c : claims) {
-    ch.observe((u64)c.size());
+    ch.observe(f_from_u64((u64)c.size()));
     for (u64 x : c) ch.observe(x);
   }
-  E2 beta = ch.sample_ext();
+  EF beta = ch.sample_ext();
   ch.observe_ext(beta);
-  E2 gamma = ch.sample_ext();
+  EF gamma = ch.sample_ext();
   ch.observe_ext(gamma);
   ch.observe_cap(proof.stage2_commit);
   for (auto& a : proof.intermediate_accumulators) ch.observe_ext(a);
-  E2 acc = claims_accumulator(claims, beta, gamma);
-  E2 alpha = ch.sample_ext();
+  EF acc = claims_accumulator(claims, beta, gamma);
+  EF alpha = ch.sample_ext();
   ch.observe_cap(proof.quotient_commit);
-  E2 zeta = ch.sample_ext();
+  EF zeta = ch.sample_ext();
 
   std::vector<RoundClaim> rounds(3);
   rounds[0].commit = proof.stage1_commit;
@@ -993,7 +985,7 @@ VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claim
   rounds[2].commit = proof.quotient_commit;
   for (size_t pos = 0; pos < na; pos++) {
     unsigned ld = proof.log_degrees[pos];
-    E2 zn = e2_mul_base(zeta, gl_two_adic_generator(ld));
+    EF zn = ef_mul_base(zeta, f_two_adic_generator(ld));
     rounds[0].log_n.push_back(ld);
     rounds[0].mats.push_back({{zeta, proof.stage1_opened[pos][0]}, {zn, proof.stage1_opened[pos][1]}});
     rounds[1].log_n.push_back(ld);
@@ -1009,7 +1001,7 @@ VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claim
       if (slot < 0) continue;
       if (active_pos[ci] >= 0) {
         unsigned ld = proof.log_degrees[active_pos[ci]];
-        E2 zn = e2_mul_base(zeta, gl_two_adic_generator(ld));
+        EF zn = ef_mul_base(zeta, f_two_adic_generator(ld));
         r0.log_n.push_back(ld);
         r0.mats.push_back({{zeta, proof.pre_opened[slot][0]}, {zn, proof.pre_opened[slot][1]}});
       } else {
@@ -1026,22 +1018,20 @@ VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claim
     size_t ci = active_idx[pos];
     const Circuit& c = sys.circuits[ci];
     unsigned ld = proof.log_degrees[pos];
-    E2 next_acc = proof.intermediate_accumulators[pos];
+    EF next_acc = proof.intermediate_accumulators[pos];
     // selectors_at_point [UPSTREAM-RECALL]: z_h = zeta^n - 1
-    u64 g_inv = gl_inv(gl_two_adic_generator(ld));
-    E2 zh = e2_sub(e2_exp_pow2(zeta, ld), e2(1));
-    E2 is_first = e2_mul(zh, e2_inv(e2_sub(zeta, e2(1))));
-    E2 is_last = e2_mul(zh, e2_inv(e2_sub(zeta, e2(g_inv))));
-    E2 is_trans = e2_sub(zeta, e2(g_inv));
-    E2 inv_van = e2_inv(zh);
-    u64 n_val = (u64(1) << ld) % GL_P;
-    u64 inj_norm = gl_inv(gl_mul(n_val, gl_two_adic_generator(ld)));
-    E2 publics[8];
-    const E2 four[4] = {beta, gamma, acc, next_acc};
-    for (int k = 0; k < 4; k++) {
-      publics[2 * k] = e2(four[k].c0);
-      publics[2 * k + 1] = e2(four[k].c1);
-    }
+    u64 g_inv = f_inv(f_two_adic_generator(ld));
+    EF zh = ef_sub(ef_exp_pow2(zeta, ld), ef(1));
+    EF is_first = ef_mul(zh, ef_inv(ef_sub(zeta, ef(1))));
+    EF is_last = ef_mul(zh, ef_inv(ef_sub(zeta, ef(g_inv))));
+    EF is_trans = ef_sub(zeta, ef(g_inv));
+    EF inv_van = ef_inv(zh);
+    u64 n_val = (u64(1) << ld) % F_P;
+    u64 inj_norm = f_inv(f_mul(n_val, f_two_adic_generator(ld)));
+    EF publics[4 * EXT_D];
+    const EF four[4] = {beta, gamma, acc, next_acc};
+    for (int k = 0; k < 4; k++)
+      for (unsigned d = 0; d < EXT_D; d++) publics[EXT_D * k + d] = ef(four[k].c[d]);
     int slot = sys.pre_indices[ci];
     View<ExtOps> v;
     v.pre[0] = slot >= 0 ? proof.pre_opened[slot][0].data() : nullptr;
@@ -1054,24 +1044,26 @@ VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claim
     v.is_first = is_first;
     v.is_last = is_last;
     v.is_trans = is_trans;
-    std::vector<E2> buf, cv;
+    std::vector<EF> buf, cv;
     sweep<ExtOps>(c, v, buf, c.nodes.size());
     for (auto z : c.zeros) cv.push_back(buf[z]);
-    E2 delta_scaled[2] = {e2_mul_base(e2_sub(publics[6], publics[4]), inj_norm),
-                          e2_mul_base(e2_sub(publics[7], publics[5]), inj_norm)};
+    EF delta_scaled[EXT_D];
+    for (unsigned d = 0; d < EXT_D; d++)
+      delta_scaled[d] = ef_mul_base(ef_sub(publics[3 * EXT_D + d], publics[2 * EXT_D + d]), inj_norm);
     logup_constraint_values<ExtOps>(c, buf, v.s2[0], v.s2[1], publics, delta_scaled, is_last, cv);
     if (cv.size() != c.constraint_count) return V_INVALID_SYSTEM;
-    E2 comp = e2(0);
-    for (auto& x : cv) comp = e2_add(e2_mul(comp, alpha), x);
+    EF comp = ef(0);
+    for (auto& x : cv) comp = ef_add(ef_mul(comp, alpha), x);
     // Q(zeta) = sum_i zeta^{i n} c_i(zeta), c_i = sum_k coord_k * X^k
-    const std::vector<E2>& qrow = proof.quotient_opened[pos][0];
-    E2 zpn = e2_exp_pow2(zeta, ld), zp = e2(1), quot = e2(0);
+    const std::vector<EF>& qrow = proof.quotient_opened[pos][0];
+    EF zpn = ef_exp_pow2(zeta, ld), zp = ef(1), quot = ef(0);
     for (size_t i = 0; i < qdeg[pos]; i++) {
-      E2 chunk = e2_add(qrow[2 * i], e2_mul(qrow[2 * i + 1], E2{0, 1}));
-      quot = e2_add(quot, e2_mul(zp, chunk));
-      zp = e2_mul(zp, zpn);
+      EF chunk = ef(0);
+      for (unsigned d = 0; d < EXT_D; d++) chunk = ef_add(chunk, ef_mul(qrow[EXT_D * i + d], ef_basis(d)));
+      quot = ef_add(quot, ef_mul(zp, chunk));
+      zp = ef_mul(zp, zpn);
     }
-    if (!e2_eq(e2_mul(comp, inv_van), quot)) return V_OOD_MISMATCH;
+    if (!ef_eq(ef_mul(comp, inv_van), quot)) return V_OOD_MISMATCH;
     acc = next_acc;
   }
   return V_OK;

@@ -1,5 +1,7 @@
 """ctypes wrapper over oracle/libms_oracle.so (the CPU restatement). Test infrastructure only:
-imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product."""
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product.
+The same file, executed under the module name `oracle_bb` (tests/oracle_bb.py), binds oracle/libms_oracle_bb.so: the
+restatement compiled for the reference's BabyBear / Poseidon2 configuration (extension degree 4)."""
 import ctypes as C
 import os
 import subprocess
@@ -8,7 +10,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "libms_oracle.so")
+BABYBEAR = __name__.endswith("oracle_bb")
+LIB_PATH = os.path.join(ORACLE_DIR, "libms_oracle_bb.so" if BABYBEAR else "libms_oracle.so")
+D = 4 if BABYBEAR else 2  # extension degree: Ext values cross the C surface as D consecutive u64
 
 # libgomp's default active spinning stalls badly when the container's CPUs are oversubscribed
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
@@ -45,6 +49,11 @@ def lib():
         L.mso_prove.restype = C.c_long
         L.mso_challenger_sample_bits.restype = C.c_uint64
         L.mso_challenger_grind.restype = C.c_uint64
+        L.mso_field_order.restype = C.c_uint64
+        assert L.mso_ext_degree() == D
+        if BABYBEAR:
+            L.mso_to_wire.restype = C.c_uint64
+            L.mso_to_wire.argtypes = [C.c_uint64]
         _lib = L
     return _lib
 
@@ -71,6 +80,20 @@ def _b(a):
 
 def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def set_poseidon2(constants141):
+    """BabyBear configuration only: the permutation's round constants (process-wide in the oracle)"""
+    k = _u64(constants141).reshape(-1)
+    assert k.size == 141
+    if lib().mso_set_poseidon2(_p(k)):
+        raise RuntimeError("non-canonical round constant")
+
+
+def poseidon2_permute(state16):
+    st = _u64(state16).copy()
+    lib().mso_poseidon2_permute(_p(st))
+    return st
 
 
 def hash_bytes(data: bytes) -> bytes:
@@ -101,7 +124,7 @@ def dft_batch(m, inverse=False):
     return out
 
 
-def coset_lde_bitrev(m, log_blowup, shift=7):
+def coset_lde_bitrev(m, log_blowup, shift=31 if BABYBEAR else 7):
     m = _u64(m)
     out = np.empty((m.shape[0] << log_blowup, m.shape[1]), dtype=np.uint64)
     if lib().mso_coset_lde_bitrev(_p(m), C.c_size_t(m.shape[0]), C.c_size_t(m.shape[1]), C.c_uint(log_blowup),
@@ -177,9 +200,9 @@ class Challenger:
         lib().mso_challenger_observe_bytes(C.c_void_p(self.h), _b(a), C.c_size_t(len(b)))
 
     def sample_ext(self):
-        o = np.zeros(2, dtype=np.uint64)
+        o = np.zeros(D, dtype=np.uint64)
         lib().mso_challenger_sample_ext(C.c_void_p(self.h), _p(o))
-        return int(o[0]), int(o[1])
+        return tuple(int(x) for x in o)
 
     def sample_bits(self, bits):
         return int(lib().mso_challenger_sample_bits(C.c_void_p(self.h), C.c_uint(bits)))
@@ -260,25 +283,25 @@ class System:
 def stage2_trace(mult, arg_offsets, args, beta, gamma, acc_in):
     mult, args, arg_offsets = _u64(mult), _u64(args), _u64(arg_offsets)
     h, L = mult.shape
-    tr = np.zeros((h, max(L, 1) * 2), dtype=np.uint64)
-    acc = np.zeros(2, dtype=np.uint64)
+    tr = np.zeros((h, max(L, 1) * D), dtype=np.uint64)
+    acc = np.zeros(D, dtype=np.uint64)
     if lib().mso_stage2_trace(C.c_size_t(h), C.c_size_t(L), _p(mult), _p(arg_offsets), _p(args), _p(_u64(beta)),
                               _p(_u64(gamma)), _p(_u64(acc_in)), _p(tr), _p(acc)):
         raise RuntimeError(_err())
-    return tr, (int(acc[0]), int(acc[1]))
+    return tr, tuple(int(x) for x in acc)
 
 
 def claims_accumulator(claims_packed, beta, gamma):
     offs, data = claims_packed
-    acc = np.zeros(2, dtype=np.uint64)
+    acc = np.zeros(D, dtype=np.uint64)
     if lib().mso_claims_accumulator(C.c_size_t(len(offs) - 1), _p(offs), _p(data), _p(_u64(beta)), _p(_u64(gamma)), _p(acc)):
         raise RuntimeError(_err())
-    return int(acc[0]), int(acc[1])
+    return tuple(int(x) for x in acc)
 
 
 def quotient_values(system, ci, publics8, log_n, log_q, pre_q, s1_q, s2_q, alpha):
     N = 1 << (log_n + log_q)
-    out = np.zeros((N, 2), dtype=np.uint64)
+    out = np.zeros((N, D), dtype=np.uint64)
     pre = _u64(pre_q) if pre_q is not None else np.zeros(1, dtype=np.uint64)
     if lib().mso_quotient_values(C.c_void_p(system.h), C.c_size_t(ci), _p(_u64(publics8)), C.c_uint(log_n), C.c_uint(log_q),
                                  _p(pre), _p(_u64(s1_q)), _p(_u64(s2_q)), _p(_u64(alpha)), _p(out)):
