@@ -11,6 +11,7 @@ import os
 import numpy as np
 
 from . import frontend  # noqa: F401
+from . import babybear  # noqa: F401  (the reference's second configuration, include/mstark_bb.h)
 from .frontend import Params, bench_params, test_params, compile_circuit, system_blob, pack_claims  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))

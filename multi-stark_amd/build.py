@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmstark_hip.so")
-SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "prover.hip", "verifier.hip", "witness_gen.hip", "capi.hip"]
+SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "prover.hip", "verifier.hip", "witness_gen.hip", "capi.hip",
+           "bb_kernels.hip", "bb_prover.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,6 +25,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mstark.h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "mstark_bb.h"))
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
     hipcc = _hipcc()
     jobs = []

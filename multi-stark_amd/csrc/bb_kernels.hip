@@ -1,0 +1,764 @@
+// HIP kernels (gfx950) of the BabyBear / Poseidon2 path: transforms, Poseidon2 Merkle trees, logUp stage-2 traces,
+// quotient evaluation, barycentric / DEEP / FRI-fold kernels. See bb.h for the data layout. Every kernel is integer
+// VALU work on 32-bit Montgomery words; nothing here is shaped for MFMA.
+#include <algorithm>
+
+#include "bb.h"
+
+namespace msbb {
+
+using msamd::PNode;
+
+static inline unsigned blocks_for(size_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+
+__device__ __forceinline__ size_t bitrev_dev(size_t x, unsigned bits) { return bits ? (size_t)(__brevll((unsigned long long)x) >> (64 - bits)) : 0; }
+
+// ------------------------------------------------------------------ layout / conversion
+__global__ void upload_rows_k(const u32* __restrict__ in, size_t h, size_t w, u32* __restrict__ out, size_t ld) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= h * w) return;
+  size_t r = idx / w, c = idx % w;
+  out[c * ld + r] = bb_to_monty(in[idx]);
+}
+__global__ void download_rows_k(const u32* __restrict__ in, size_t ld, size_t h, size_t w, unsigned log_h, int bitrev, u32* __restrict__ out) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= h * w) return;
+  size_t r = idx / w, c = idx % w;
+  size_t src = bitrev ? bitrev_dev(r, log_h) : r;
+  out[idx] = bb_from_monty(in[c * ld + src]);
+}
+void bb_upload_rows(Ctx& ctx, const u32* host, size_t h, size_t w, BMat& out) {
+  out = bmat(ctx, h, w);
+  if (!h || !w) return;
+  DBuf<u32> tmp(ctx, h * w);
+  ctx.h2d(tmp.p, host, h * w * 4);
+  upload_rows_k<<<blocks_for(h * w, 256), 256, 0, ctx.stream>>>(tmp.p, h, w, out.buf.p, out.ld);
+  ctx.sync();
+}
+static unsigned log2_host(size_t n) {
+  unsigned l = 0;
+  while ((size_t(1) << l) < n) l++;
+  return l;
+}
+void bb_download_rows(Ctx& ctx, const BMat& m, bool bitrev_rows, u32* host) {
+  if (!m.h || !m.w) return;
+  DBuf<u32> tmp(ctx, m.h * m.w);
+  download_rows_k<<<blocks_for(m.h * m.w, 256), 256, 0, ctx.stream>>>(m.buf.p, m.ld, m.h, m.w, log2_host(m.h), bitrev_rows ? 1 : 0, tmp.p);
+  ctx.d2h(host, tmp.p, m.h * m.w * 4);
+}
+
+// ------------------------------------------------------------------ transforms
+// Twiddle table of the order-2^n root: w^j, j < 2^(n-1), Montgomery form. Cached per size in a process-wide map keyed
+// by (device, n); the tables are small next to the matrices (half a column).
+__global__ void twiddles_k(u32* out, size_t count, u32 w) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) out[j] = bb_pow(w, j);
+}
+struct TwCache {
+  std::map<std::pair<int, unsigned>, u32*> t;
+};
+static TwCache& tw_cache() {
+  static TwCache c;
+  return c;
+}
+static const u32* twiddles(Ctx& ctx, unsigned log_n) {
+  auto key = std::make_pair(ctx.device, log_n);
+  auto it = tw_cache().t.find(key);
+  if (it != tw_cache().t.end()) return it->second;
+  size_t count = log_n ? (size_t(1) << (log_n - 1)) : 1;
+  u32* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, count * 4));
+  twiddles_k<<<blocks_for(count, 256), 256, 0, ctx.stream>>>(p, count, bb_two_adic_generator(log_n));
+  tw_cache().t[key] = p;
+  return p;
+}
+
+// DIF layers [l0, l0 + K) of a size-2^n transform; tile = 2^K values of the "middle" index bits x T consecutive low
+// indices (128-byte runs), staged through LDS. Column = blockIdx.y.
+template <int K, int T>
+__global__ __launch_bounds__(256) void ntt_strided_k(u32* __restrict__ data, size_t ld, unsigned n, unsigned l0, const u32* __restrict__ tw) {
+  __shared__ u32 s[(1 << K) * T];
+  u32* col = data + (size_t)blockIdx.y * ld;
+  const unsigned sbits = n - l0 - K;
+  const size_t lo_tiles = (size_t(1) << sbits) / T;
+  const size_t H = blockIdx.x / lo_tiles, lo0 = (blockIdx.x % lo_tiles) * T;
+  const size_t base = (H << (n - l0)) + lo0;
+  for (unsigned e = threadIdx.x; e < (1u << K) * T; e += 256) s[e] = col[base + ((size_t)(e / T) << sbits) + (e % T)];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < K; u++) {
+    const int bit = K - 1 - u;
+    for (unsigned b = threadIdx.x; b < (1u << (K - 1)) * T; b += 256) {
+      unsigned t = b % T, m = b / T;
+      unsigned mlo = m & ((1u << bit) - 1), mhi = m >> bit;
+      unsigned m0 = (mhi << (bit + 1)) | mlo, m1 = m0 | (1u << bit);
+      u32 x = s[m0 * T + t], y = s[m1 * T + t];
+      size_t j = ((size_t)mlo << sbits) | (lo0 + t);
+      u32 w = tw[j << (l0 + u)];
+      s[m0 * T + t] = bb_add(x, y);
+      s[m1 * T + t] = bb_mul(bb_sub(x, y), w);
+    }
+    __syncthreads();
+  }
+  for (unsigned e = threadIdx.x; e < (1u << K) * T; e += 256) col[base + ((size_t)(e / T) << sbits) + (e % T)] = s[e];
+}
+// last layers [l0, n) on contiguous tiles of `ts` = min(4096, 2^n) elements (whole groups of 2^(n - l0) elements)
+__global__ __launch_bounds__(256) void ntt_contig_k(u32* __restrict__ data, size_t ld, unsigned n, unsigned l0, unsigned log_ts, const u32* __restrict__ tw) {
+  __shared__ u32 s[4096];
+  u32* col = data + (size_t)blockIdx.y * ld;
+  const unsigned ts = 1u << log_ts;
+  const size_t base = (size_t)blockIdx.x << log_ts;
+  for (unsigned e = threadIdx.x; e < ts; e += 256) s[e] = col[base + e];
+  __syncthreads();
+  for (unsigned l = l0; l < n; l++) {
+    const unsigned lh = n - l - 1;  // log2 of the butterfly distance
+    for (unsigned b = threadIdx.x; b < ts / 2; b += 256) {
+      unsigned lo = b & ((1u << lh) - 1), hi = b >> lh;
+      unsigned e0 = (hi << (lh + 1)) | lo, e1 = e0 | (1u << lh);
+      u32 x = s[e0], y = s[e1];
+      u32 w = tw[(size_t)lo << l];
+      s[e0] = bb_add(x, y);
+      s[e1] = bb_mul(bb_sub(x, y), w);
+    }
+    __syncthreads();
+  }
+  for (unsigned e = threadIdx.x; e < ts; e += 256) col[base + e] = s[e];
+}
+void bb_dif(Ctx& ctx, u32* data, size_t ld, unsigned n, size_t ncols) {
+  if (n == 0 || ncols == 0) return;
+  if (n > BB_TWO_ADICITY) throw std::runtime_error("transform larger than the two-adicity of BabyBear");
+  const u32* tw = twiddles(ctx, n);
+  unsigned l0 = 0;
+  while (n - l0 > 12) {  // 7 layers per strided pass; the rest (6..12 layers) in the contiguous pass
+    dim3 grid((unsigned)((size_t(1) << n) >> 12), (unsigned)ncols);
+    ntt_strided_k<7, 32><<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, tw);
+    l0 += 7;
+  }
+  unsigned log_ts = std::min(n, 12u);
+  dim3 grid((unsigned)((size_t(1) << n) >> log_ts), (unsigned)ncols);
+  ntt_contig_k<<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, log_ts, tw);
+}
+
+// Inverse transform + coset scaling + zero padding in one gather: with X = DFT(x) held bit-reversed (DIF output),
+// coefficient k = X[(n - k) mod n] / n; out[k] = coefficient k * shift^k for k < n, 0 for n <= k < N.
+__global__ void idft_gather_k(const u32* __restrict__ src, size_t src_ld, unsigned log_n, u32* __restrict__ dst, size_t dst_ld, size_t N,
+                              u32 n_inv, u32 shift) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const u32* s = src + (size_t)blockIdx.y * src_ld;
+  u32* d = dst + (size_t)blockIdx.y * dst_ld;
+  size_t n = size_t(1) << log_n;
+  if (k >= n) {
+    d[k] = 0;
+    return;
+  }
+  size_t j = (n - k) & (n - 1);
+  d[k] = bb_mul(bb_mul(s[bitrev_dev(j, log_n)], n_inv), bb_pow(shift, k));
+}
+void bb_coset_lde(Ctx& ctx, const BMat& evals, unsigned lb, BMat& out) {
+  size_t n = evals.h, N = n << lb, w = evals.w;
+  unsigned log_n = log2_host(n);
+  out = bmat(ctx, N, w);
+  if (!w) return;
+  DBuf<u32> tmp(ctx, n * w);
+  HIP_CHECK(hipMemcpy2DAsync(tmp.p, n * 4, evals.buf.p, evals.ld * 4, n * 4, w, hipMemcpyDeviceToDevice, ctx.stream));
+  bb_dif(ctx, tmp.p, n, log_n, w);
+  u32 n_inv = bb_inv(bb_to_monty((u32)(n % BB_P)));
+  dim3 grid(blocks_for(N, 256), (unsigned)w);
+  idft_gather_k<<<grid, 256, 0, ctx.stream>>>(tmp.p, n, log_n, out.buf.p, out.ld, N, n_inv, bb_to_monty(BB_GENERATOR));
+  bb_dif(ctx, out.buf.p, out.ld, log_n + lb, w);
+  ctx.sync();  // tmp goes back to the pool
+}
+
+// shifted_quotient_slices + zero padding (src/prover.rs:631-679, 709-717): X = DFT(q) bit-reversed; padded column
+// (chunk * 4 + c), row r < n = X_c[(N - (chunk n + r)) mod N] * GENERATOR^(-n chunk) / N
+__global__ void quotient_slices_k(const u32* __restrict__ src, size_t src_ld, unsigned log_n, unsigned log_q, u32* __restrict__ dst, size_t dst_ld,
+                                  size_t rows_out, u32 weight0, u32 weight_step) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows_out) return;
+  unsigned colid = blockIdx.y;  // chunk * 4 + c
+  unsigned chunk = colid >> 2, c = colid & 3;
+  u32* d = dst + (size_t)colid * dst_ld;
+  size_t n = size_t(1) << log_n, N = n << log_q;
+  if (r >= n) {
+    d[r] = 0;
+    return;
+  }
+  size_t j = (size_t)chunk * n + r;
+  size_t srci = bitrev_dev((N - j) & (N - 1), log_n + log_q);
+  u32 wgt = bb_mul(weight0, bb_pow(weight_step, chunk));
+  d[r] = bb_mul(src[(size_t)c * src_ld + srci], wgt);
+}
+void bb_quotient_lde(Ctx& ctx, BMat& q_evals, unsigned log_n, unsigned log_q, unsigned lb, BMat& out) {
+  size_t n = size_t(1) << log_n, q = size_t(1) << log_q, N = n * q, rows_out = n << lb;
+  bb_dif(ctx, q_evals.buf.p, q_evals.ld, log_n + log_q, 4);
+  out = bmat(ctx, rows_out, 4 * q);
+  u32 g = bb_to_monty(BB_GENERATOR);
+  u32 weight0 = bb_inv(bb_to_monty((u32)(N % BB_P)));
+  u32 weight_step = bb_inv(bb_pow(g, n));
+  dim3 grid(blocks_for(rows_out, 256), (unsigned)(4 * q));
+  quotient_slices_k<<<grid, 256, 0, ctx.stream>>>(q_evals.buf.p, q_evals.ld, log_n, log_q, out.buf.p, out.ld, rows_out, weight0, weight_step);
+  bb_dif(ctx, out.buf.p, out.ld, log_n + lb, 4 * q);
+}
+
+// ------------------------------------------------------------------ Poseidon2 hashing
+// PaddingFreeSponge<Perm, 16, 8, 8>: row r of the concatenated columns, 8 words per absorbed block
+__global__ __launch_bounds__(256) void leaf_hash_k(const u32* const* __restrict__ cols, unsigned W, size_t rows, const Poseidon2* __restrict__ perm,
+                                                   Digest8* __restrict__ out) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  u32 st[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) st[i] = 0;
+  for (unsigned b = 0; b < W; b += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (b + i < W) st[i] = cols[b + i][r];
+    bb_poseidon2(*perm, st);
+  }
+  Digest8 d;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d.w[i] = st[i];
+  out[r] = d;
+}
+// FRI layer leaves: row i = 8 consecutive words (two E4)
+__global__ __launch_bounds__(256) void leaf_hash8_k(const u32* __restrict__ rows8, size_t rows, const Poseidon2* __restrict__ perm, Digest8* __restrict__ out) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  u32 st[16];
+  const uint4* p = (const uint4*)(rows8 + r * 8);
+  uint4 a = p[0], b = p[1];
+  st[0] = a.x, st[1] = a.y, st[2] = a.z, st[3] = a.w, st[4] = b.x, st[5] = b.y, st[6] = b.z, st[7] = b.w;
+#pragma unroll
+  for (int i = 8; i < 16; i++) st[i] = 0;
+  bb_poseidon2(*perm, st);
+  Digest8 d;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d.w[i] = st[i];
+  out[r] = d;
+}
+// TruncatedPermutation<Perm, 2, 8, 16>: parent = permute(left || right)[..8]; with injection of a shorter matrix's
+// row digest: parent = compress(parent, inject[i])
+__global__ __launch_bounds__(256) void compress_k(const Digest8* __restrict__ prev, size_t n_out, const Digest8* __restrict__ inject,
+                                                  const Poseidon2* __restrict__ perm, Digest8* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  u32 st[16];
+  Digest8 l = prev[2 * i], r = prev[2 * i + 1];
+#pragma unroll
+  for (int k = 0; k < 8; k++) st[k] = l.w[k], st[8 + k] = r.w[k];
+  bb_poseidon2(*perm, st);
+  if (inject) {
+    Digest8 x = inject[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[8 + k] = x.w[k];
+    bb_poseidon2(*perm, st);
+  }
+  Digest8 d;
+#pragma unroll
+  for (int k = 0; k < 8; k++) d.w[k] = st[k];
+  out[i] = d;
+}
+__global__ void permute_batch_k(u32* states, size_t n, const Poseidon2* __restrict__ perm) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 st[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) st[k] = states[16 * i + k];
+  bb_poseidon2(*perm, st);
+#pragma unroll
+  for (int k = 0; k < 16; k++) states[16 * i + k] = st[k];
+}
+void bb_permute_batch(Ctx& ctx, const Poseidon2* d_perm, u32* d_states, size_t n) {
+  if (n) permute_batch_k<<<blocks_for(n, 256), 256, 0, ctx.stream>>>(d_states, n, d_perm);
+}
+
+static void hash_group(Ctx& ctx, const Poseidon2* d_perm, const std::vector<const BMat*>& group, size_t rows, Digest8* out) {
+  std::vector<const u32*> cols;
+  for (auto m : group)
+    for (size_t c = 0; c < m->w; c++) cols.push_back(m->col(c));
+  DBuf<const u32*> d_cols(ctx, std::max<size_t>(cols.size(), 1));
+  if (!cols.empty()) ctx.h2d(d_cols.p, cols.data(), cols.size() * sizeof(const u32*));
+  leaf_hash_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(d_cols.p, (unsigned)cols.size(), rows, d_perm, out);
+  ctx.sync();  // the column-pointer table is released with d_cols
+}
+static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const std::vector<const BMat*>& order, size_t pos) {
+  while (t.sizes.back() > 1) {
+    size_t nl = t.sizes.back() / 2;
+    std::vector<const BMat*> group;
+    while (pos < order.size() && order[pos]->h == nl) group.push_back(order[pos++]);
+    DBuf<Digest8> inj;
+    if (!group.empty()) {
+      inj = DBuf<Digest8>(ctx, nl);
+      hash_group(ctx, d_perm, group, nl, inj.p);
+    }
+    DBuf<Digest8> next(ctx, nl);
+    compress_k<<<blocks_for(nl, 256), 256, 0, ctx.stream>>>(t.layers.back().p, nl, group.empty() ? nullptr : inj.p, d_perm, next.p);
+    if (!group.empty()) ctx.sync();
+    t.layers.push_back(std::move(next));
+    t.sizes.push_back(nl);
+  }
+  if (pos != order.size()) throw std::runtime_error("mmcs commit: a matrix height was never reached");
+}
+void bb_commit(Ctx& ctx, const Poseidon2* d_perm, std::vector<BMat>&& ldes, unsigned cap_height, BPcsData& out) {
+  out.ldes = std::move(ldes);
+  BTree& t = out.tree;
+  t = BTree();
+  t.cap_height = cap_height;
+  if (out.ldes.empty()) throw std::runtime_error("mmcs commit: no matrices");
+  std::vector<const BMat*> order;
+  for (auto& m : out.ldes) {
+    if (m.h == 0 || (m.h & (m.h - 1))) throw std::runtime_error("mmcs commit: heights must be powers of two");
+    order.push_back(&m);
+  }
+  std::stable_sort(order.begin(), order.end(), [](const BMat* a, const BMat* b) { return a->h > b->h; });
+  size_t pos = 0, maxh = order[0]->h;
+  std::vector<const BMat*> group;
+  while (pos < order.size() && order[pos]->h == maxh) group.push_back(order[pos++]);
+  t.layers.emplace_back(ctx, maxh);
+  t.sizes.push_back(maxh);
+  hash_group(ctx, d_perm, group, maxh, t.layers[0].p);
+  build_upper_layers(ctx, d_perm, t, order, pos);
+}
+void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& t) {
+  t = BTree();
+  t.cap_height = cap_height;
+  t.layers.emplace_back(ctx, rows);
+  t.sizes.push_back(rows);
+  leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
+  build_upper_layers(ctx, d_perm, t, {}, 0);
+}
+
+// ------------------------------------------------------------------ node programs
+void bb_build_program(Ctx& ctx, const std::vector<PNode>& nodes, BProgram& out) {
+  size_t n = nodes.size();
+  std::vector<u32> k(n), a(n), b(n);
+  for (size_t i = 0; i < n; i++) {
+    k[i] = nodes[i].kind | (nodes[i].source << 8) | (nodes[i].offset << 16);
+    a[i] = nodes[i].kind == msamd::OP_CONST ? bb_to_monty((u32)nodes[i].a) : (u32)nodes[i].a;
+    b[i] = (u32)nodes[i].b;
+  }
+  out.n = n;
+  out.kind = DBuf<u32>(ctx, std::max<size_t>(n, 1));
+  out.a = DBuf<u32>(ctx, std::max<size_t>(n, 1));
+  out.b = DBuf<u32>(ctx, std::max<size_t>(n, 1));
+  if (n) {
+    ctx.h2d(out.kind.p, k.data(), n * 4);
+    ctx.h2d(out.a.p, a.data(), n * 4);
+    ctx.h2d(out.b.p, b.data(), n * 4);
+    ctx.sync();
+  }
+}
+
+// One sweep of the node program (src/eval.rs:36-111) for one row; node values go to a per-thread slot column in global
+// scratch (slot s of thread t at scratch[s * stride + t]: coalesced across the wave).
+struct RowView {
+  const u32 *pre0, *pre1, *main0, *main1, *s20, *s21;  // element c of a row at ptr[c * ld]
+  size_t pre_ld, main_ld, s2_ld;
+  const u32* publics;  // 16 base coordinates (may be null)
+  u32 is_first, is_last, is_trans;
+};
+__device__ __forceinline__ void sweep(const u32* __restrict__ kind, const u32* __restrict__ na, const u32* __restrict__ nb, unsigned len, const RowView& v,
+                                      u32* __restrict__ slots, size_t stride) {
+  for (unsigned i = 0; i < len; i++) {
+    u32 k = kind[i], a = na[i], val;
+    switch (k & 0xff) {
+      case msamd::OP_CONST: val = a; break;
+      case msamd::OP_VAR: {
+        unsigned src = (k >> 8) & 0xff, off = (k >> 16) & 0xff;
+        if (src == 0)
+          val = (off ? v.pre1 : v.pre0)[(size_t)a * v.pre_ld];
+        else if (src == 1)
+          val = (off ? v.main1 : v.main0)[(size_t)a * v.main_ld];
+        else
+          val = (off ? v.s21 : v.s20)[(size_t)a * v.s2_ld];
+        break;
+      }
+      case msamd::OP_PUBLIC: val = v.publics ? v.publics[a] : 0; break;
+      case msamd::OP_IS_FIRST: val = v.is_first; break;
+      case msamd::OP_IS_LAST: val = v.is_last; break;
+      case msamd::OP_IS_TRANS: val = v.is_trans; break;
+      case msamd::OP_ADD: val = bb_add(slots[(size_t)a * stride], slots[(size_t)nb[i] * stride]); break;
+      case msamd::OP_SUB: val = bb_sub(slots[(size_t)a * stride], slots[(size_t)nb[i] * stride]); break;
+      case msamd::OP_MUL: val = bb_mul(slots[(size_t)a * stride], slots[(size_t)nb[i] * stride]); break;
+      default: val = bb_neg(slots[(size_t)a * stride]); break;
+    }
+    slots[(size_t)i * stride] = val;
+  }
+}
+
+// ------------------------------------------------------------------ stage 2 (src/lookup.rs:472-555)
+struct Stage2Args {
+  const u32 *kind, *na, *nb;
+  unsigned prefix_len;
+  const u32 *lk_mult, *lk_off, *lk_args;
+  unsigned L;
+  const u32* trace;
+  size_t trace_ld;
+  const u32* pre;
+  size_t pre_ld;
+  size_t n;
+  E4 beta, gamma;
+  u32* scratch;
+  E4* terms;  // n * L, row-major (row, lookup)
+};
+__global__ __launch_bounds__(256) void stage2_terms_k(Stage2Args p) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n) return;
+  size_t rn = r + 1 == p.n ? 0 : r + 1;
+  RowView v;
+  v.pre0 = p.pre ? p.pre + r : nullptr, v.pre1 = p.pre ? p.pre + rn : nullptr, v.pre_ld = p.pre_ld;
+  v.main0 = p.trace + r, v.main1 = p.trace + rn, v.main_ld = p.trace_ld;
+  v.s20 = v.s21 = nullptr, v.s2_ld = 0;
+  v.publics = nullptr;
+  v.is_first = r == 0 ? BB_R1 : 0;
+  v.is_last = r + 1 == p.n ? BB_R1 : 0;
+  v.is_trans = r + 1 == p.n ? 0 : BB_R1;
+  u32* slots = p.scratch + r;
+  sweep(p.kind, p.na, p.nb, p.prefix_len, v, slots, p.n);
+  for (unsigned l = 0; l < p.L; l++) {
+    E4 f = e4_zero();
+    for (unsigned k = p.lk_off[l + 1]; k-- > p.lk_off[l];) {  // Horner over the reversed arguments, src/lookup.rs:375-384
+      f = e4_mul(f, p.gamma);
+      f.c[0] = bb_add(f.c[0], slots[(size_t)p.lk_args[k] * p.n]);
+    }
+    E4 msg = e4_add(f, p.beta);
+    p.terms[r * p.L + l] = e4_mul_base(e4_inv(msg), slots[(size_t)p.lk_mult[l] * p.n]);
+  }
+}
+// exclusive prefix sums of E4 in three steps: per-block (1024 elements) local scan + block totals, serial scan of the
+// totals (one thread: a few thousand additions), write-out with the block offsets into the stage-2 columns
+__global__ __launch_bounds__(256) void scan_local_k(E4* __restrict__ v, size_t n, E4* __restrict__ block_tot) {
+  __shared__ E4 s[256];
+  size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  E4 x[4], run = e4_zero();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    x[i] = base + i < n ? v[base + i] : e4_zero();
+    E4 t = x[i];
+    x[i] = run;
+    run = e4_add(run, t);
+  }
+  s[threadIdx.x] = run;
+  __syncthreads();
+  for (unsigned d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan of the thread totals
+    E4 t = threadIdx.x >= d ? s[threadIdx.x - d] : e4_zero();
+    __syncthreads();
+    s[threadIdx.x] = e4_add(s[threadIdx.x], t);
+    __syncthreads();
+  }
+  E4 off = threadIdx.x ? s[threadIdx.x - 1] : e4_zero();
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (base + i < n) v[base + i] = e4_add(x[i], off);
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = s[255];
+}
+__global__ void scan_totals_k(E4* block_tot, size_t nb, E4* total) {
+  E4 run = e4_zero();
+  for (size_t i = 0; i < nb; i++) {
+    E4 t = block_tot[i];
+    block_tot[i] = run;
+    run = e4_add(run, t);
+  }
+  *total = run;
+}
+__global__ void stage2_write_k(const E4* __restrict__ v, const E4* __restrict__ block_off, size_t n_rows, unsigned L, u32* __restrict__ out, size_t ld) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rows * L) return;
+  size_t r = idx / L, l = idx % L;
+  E4 x = e4_add(v[idx], block_off[idx >> 10]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[(4 * l + k) * ld + r] = x.c[k];
+}
+void bb_stage2(Ctx& ctx, const BProgram& prog, size_t prefix_len, const BLookupsDev& lk, const BMat& trace, const BMat* pre, E4 beta, E4 gamma,
+               BMat& out, E4* total) {
+  size_t n = trace.h, L = lk.L;
+  out = bmat(ctx, n, 4 * std::max<size_t>(L, 1));
+  *total = e4_zero();
+  if (L == 0) {  // pass-through accumulator column: zeros (src/lookup.rs:520-523)
+    HIP_CHECK(hipMemsetAsync(out.buf.p, 0, n * 4 * 4, ctx.stream));
+    return;
+  }
+  DBuf<u32> scratch(ctx, std::max<size_t>(prefix_len, 1) * n);
+  DBuf<E4> terms(ctx, n * L);
+  size_t nb = (n * L + 1023) / 1024;
+  DBuf<E4> tot(ctx, nb + 1);
+  Stage2Args a;
+  a.kind = prog.kind.p, a.na = prog.a.p, a.nb = prog.b.p, a.prefix_len = (unsigned)prefix_len;
+  a.lk_mult = lk.mult.p, a.lk_off = lk.arg_off.p, a.lk_args = lk.args.p, a.L = (unsigned)L;
+  a.trace = trace.buf.p, a.trace_ld = trace.ld;
+  a.pre = pre ? pre->buf.p : nullptr, a.pre_ld = pre ? pre->ld : 0;
+  a.n = n, a.beta = beta, a.gamma = gamma, a.scratch = scratch.p, a.terms = terms.p;
+  stage2_terms_k<<<blocks_for(n, 256), 256, 0, ctx.stream>>>(a);
+  scan_local_k<<<(unsigned)nb, 256, 0, ctx.stream>>>(terms.p, n * L, tot.p);
+  scan_totals_k<<<1, 1, 0, ctx.stream>>>(tot.p, nb, tot.p + nb);
+  stage2_write_k<<<blocks_for(n * L, 256), 256, 0, ctx.stream>>>(terms.p, tot.p, n, (unsigned)L, out.buf.p, out.ld);
+  ctx.d2h(total, tot.p + nb, sizeof(E4));
+}
+
+// ------------------------------------------------------------------ quotient (src/prover.rs:756-962)
+struct QuotArgs {
+  const u32 *kind, *na, *nb;
+  unsigned n_nodes;
+  const u32* zeros;
+  unsigned n_zeros;
+  const u32 *lk_mult, *lk_off, *lk_args;
+  unsigned L;
+  const u32 *pre, *s1, *s2;
+  size_t pre_ld, s1_ld, s2_ld;
+  unsigned log_n, log_q;
+  u32 publics[16], delta[4];
+  const E4* apow;  // constraint_count weights: alpha^(count - 1 - j) for constraint j (src/prover.rs:798-808)
+  u32* out;
+  size_t out_ld;
+  u32* scratch;
+  size_t row0, rows, stride;
+  u32 g, w_big, gn_inv, g_pow_n, w_q;
+};
+__global__ __launch_bounds__(256) void quotient_k(QuotArgs p) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.rows) return;
+  const unsigned log_big = p.log_n + p.log_q;
+  const size_t N = size_t(1) << log_big, q = size_t(1) << p.log_q;
+  size_t st = p.row0 + t;               // storage row of the LDEs
+  size_t i = bitrev_dev(st, log_big);   // natural index on the quotient domain GENERATOR * H_N
+  size_t st_next = bitrev_dev((i + q) & (N - 1), log_big);
+  // selectors at x = g w^i (p3 selectors_on_coset; normalisation pinned by src/lookup.rs:697-756)
+  u32 x = bb_mul(p.g, bb_pow(p.w_big, i));
+  u32 zh = bb_sub(bb_mul(p.g_pow_n, bb_pow(p.w_q, i & (q - 1))), BB_R1);
+  u32 d1 = bb_sub(x, BB_R1), d2 = bb_sub(x, p.gn_inv);
+  u32 d12 = bb_mul(d1, d2);
+  u32 all_inv = bb_inv(bb_mul(d12, zh));
+  u32 inv_zh = bb_mul(all_inv, d12);
+  u32 inv12 = bb_mul(all_inv, zh);
+  u32 inv_d1 = bb_mul(inv12, d2), inv_d2 = bb_mul(inv12, d1);
+  RowView v;
+  v.pre0 = p.pre ? p.pre + st : nullptr, v.pre1 = p.pre ? p.pre + st_next : nullptr, v.pre_ld = p.pre_ld;
+  v.main0 = p.s1 + st, v.main1 = p.s1 + st_next, v.main_ld = p.s1_ld;
+  v.s20 = p.s2 + st, v.s21 = p.s2 + st_next, v.s2_ld = p.s2_ld;
+  v.publics = p.publics;
+  v.is_first = bb_mul(zh, inv_d1);
+  v.is_last = bb_mul(zh, inv_d2);
+  v.is_trans = d2;
+  u32* slots = p.scratch + t;
+  sweep(p.kind, p.na, p.nb, p.n_nodes, v, slots, p.stride);
+  E4 acc = e4_zero();
+  unsigned cj = 0;
+  for (unsigned z = 0; z < p.n_zeros; z++) acc = e4_add(acc, e4_mul_base(p.apow[cj++], slots[(size_t)p.zeros[z] * p.stride]));
+  // logUp constraints (src/lookup.rs:152-256): on this domain every working value is a base element, so the coordinate
+  // products of the reference are the products of E4 values assembled from those coordinates
+  E4 beta = E4{{p.publics[0], p.publics[1], p.publics[2], p.publics[3]}};
+  E4 gamma = E4{{p.publics[4], p.publics[5], p.publics[6], p.publics[7]}};
+  E4 inj;
+#pragma unroll
+  for (int k = 0; k < 4; k++) inj.c[k] = bb_mul(v.is_last, p.delta[k]);
+  auto s2_at = [&](const u32* rowp, unsigned slot) {
+    E4 e;
+#pragma unroll
+    for (int k = 0; k < 4; k++) e.c[k] = rowp[(size_t)(4 * slot + k) * p.s2_ld];
+    return e;
+  };
+  if (p.L == 0) {
+    E4 c = e4_add(e4_sub(s2_at(v.s21, 0), s2_at(v.s20, 0)), inj);
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc = e4_add(acc, e4_mul_base(p.apow[cj++], c.c[k]));
+  } else {
+    for (unsigned j = 0; j < p.L; j++) {
+      E4 src = s2_at(v.s20, j);
+      E4 tgt = j + 1 < p.L ? s2_at(v.s20, j + 1) : e4_add(s2_at(v.s21, 0), inj);
+      E4 f = e4_zero();
+      for (unsigned k = p.lk_off[j + 1]; k-- > p.lk_off[j];) {
+        f = e4_mul(f, gamma);
+        f.c[0] = bb_add(f.c[0], slots[(size_t)p.lk_args[k] * p.stride]);
+      }
+      E4 c = e4_mul(e4_add(f, beta), e4_sub(tgt, src));
+      c.c[0] = bb_sub(c.c[0], slots[(size_t)p.lk_mult[j] * p.stride]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc = e4_add(acc, e4_mul_base(p.apow[cj++], c.c[k]));
+    }
+  }
+  acc = e4_mul_base(acc, inv_zh);
+#pragma unroll
+  for (int k = 0; k < 4; k++) p.out[(size_t)k * p.out_ld + i] = acc.c[k];
+}
+void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals) {
+  unsigned log_big = in.log_n + in.log_q;
+  size_t N = size_t(1) << log_big, n = size_t(1) << in.log_n;
+  q_evals = bmat(ctx, N, 4);
+  // reversed alpha powers
+  std::vector<E4> apow(in.constraint_count);
+  E4 a = e4_one();
+  for (size_t i = 0; i < in.constraint_count; i++) {
+    apow[in.constraint_count - 1 - i] = a;
+    a = e4_mul(a, in.alpha);
+  }
+  DBuf<E4> d_apow(ctx, std::max<size_t>(apow.size(), 1));
+  if (!apow.empty()) ctx.h2d(d_apow.p, apow.data(), apow.size() * sizeof(E4));
+  QuotArgs p;
+  p.kind = in.prog->kind.p, p.na = in.prog->a.p, p.nb = in.prog->b.p, p.n_nodes = (unsigned)in.prog->n;
+  p.zeros = in.d_zeros, p.n_zeros = (unsigned)in.n_zeros;
+  p.lk_mult = in.lk->mult.p, p.lk_off = in.lk->arg_off.p, p.lk_args = in.lk->args.p, p.L = (unsigned)in.lk->L;
+  p.pre = in.pre ? in.pre->buf.p : nullptr, p.pre_ld = in.pre ? in.pre->ld : 0;
+  p.s1 = in.s1->buf.p, p.s1_ld = in.s1->ld, p.s2 = in.s2->buf.p, p.s2_ld = in.s2->ld;
+  p.log_n = in.log_n, p.log_q = in.log_q;
+  for (int k = 0; k < 4; k++)
+    for (int d = 0; d < 4; d++) p.publics[4 * k + d] = in.publics[k].c[d];
+  u32 g_n = bb_two_adic_generator(in.log_n);
+  u32 inj_norm = bb_inv(bb_mul(bb_to_monty((u32)(n % BB_P)), g_n));  // 1 / (n g), src/prover.rs:815-823
+  for (int d = 0; d < 4; d++) p.delta[d] = bb_mul(bb_sub(in.publics[3].c[d], in.publics[2].c[d]), inj_norm);
+  p.apow = d_apow.p;
+  p.out = q_evals.buf.p, p.out_ld = q_evals.ld;
+  p.g = bb_to_monty(BB_GENERATOR), p.w_big = bb_two_adic_generator(log_big), p.gn_inv = bb_inv(g_n);
+  p.g_pow_n = bb_exp_pow2(p.g, in.log_n), p.w_q = bb_two_adic_generator(in.log_q);
+  // rows in chunks, so that the slot file (nodes x rows words) stays bounded
+  size_t chunk = std::min<size_t>(N, std::max<size_t>(256, (size_t(1) << 28) / std::max<size_t>(in.prog->n, 1) / 256 * 256));
+  DBuf<u32> scratch(ctx, std::max<size_t>(in.prog->n, 1) * chunk);
+  p.scratch = scratch.p, p.stride = chunk;
+  for (size_t row0 = 0; row0 < N; row0 += chunk) {
+    p.row0 = row0, p.rows = std::min(chunk, N - row0);
+    quotient_k<<<blocks_for(p.rows, 256), 256, 0, ctx.stream>>>(p);
+  }
+  ctx.sync();
+}
+
+// ------------------------------------------------------------------ opening
+__global__ void inv_denoms_k(E4 z, unsigned log_h, size_t count, u32 g, u32 w, E4* __restrict__ d_inv, E4* __restrict__ d_wgt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  u32 x = bb_mul(g, bb_pow(w, bitrev_dev(i, log_h)));
+  E4 d = z;
+  d.c[0] = bb_sub(d.c[0], x);
+  E4 inv = e4_inv(d);
+  d_inv[i] = inv;
+  if (d_wgt) d_wgt[i] = e4_mul_base(inv, x);
+}
+void bb_inv_denoms(Ctx& ctx, E4 z, unsigned log_h, size_t count, E4* d_inv, E4* d_wgt) {
+  inv_denoms_k<<<blocks_for(count, 256), 256, 0, ctx.stream>>>(z, log_h, count, bb_to_monty(BB_GENERATOR), bb_two_adic_generator(log_h), d_inv, d_wgt);
+}
+static constexpr size_t BARY_ROWS = 8192;
+__global__ __launch_bounds__(256) void bary_partial_k(const u32* __restrict__ m, size_t ld, size_t h, const E4* __restrict__ wgt, E4* __restrict__ part, size_t nchunks) {
+  __shared__ E4 s[256];
+  const u32* col = m + (size_t)blockIdx.y * ld;
+  size_t r0 = (size_t)blockIdx.x * BARY_ROWS, r1 = min(h, r0 + BARY_ROWS);
+  E4 acc = e4_zero();
+  for (size_t r = r0 + threadIdx.x; r < r1; r += 256) acc = e4_add(acc, e4_mul_base(wgt[r], col[r]));
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (unsigned d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) s[threadIdx.x] = e4_add(s[threadIdx.x], s[threadIdx.x + d]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * nchunks + blockIdx.x] = s[0];
+}
+void bb_bary(Ctx& ctx, const BMat& m, size_t h, const E4* d_wgt, std::vector<E4>& sums) {
+  sums.assign(m.w, e4_zero());
+  if (!m.w) return;
+  size_t nch = (h + BARY_ROWS - 1) / BARY_ROWS;
+  DBuf<E4> part(ctx, m.w * nch);
+  dim3 grid((unsigned)nch, (unsigned)m.w);
+  bary_partial_k<<<grid, 256, 0, ctx.stream>>>(m.buf.p, m.ld, h, d_wgt, part.p, nch);
+  std::vector<E4> hp(m.w * nch);
+  ctx.d2h(hp.data(), part.p, hp.size() * sizeof(E4));
+  for (size_t c = 0; c < m.w; c++)
+    for (size_t k = 0; k < nch; k++) sums[c] = e4_add(sums[c], hp[c * nch + k]);
+}
+struct DeepArgs {
+  const u32* m;
+  size_t ld, h;
+  unsigned w;
+  const E4* apow;
+  int npoints;
+  const E4* inv[2];
+  E4 K[2], off[2];
+  E4* ro;
+};
+__global__ __launch_bounds__(256) void deep_k(DeepArgs p) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.h) return;
+  E4 comp = e4_zero();
+  for (unsigned c = 0; c < p.w; c++) comp = e4_add(comp, e4_mul_base(p.apow[c], p.m[(size_t)c * p.ld + i]));
+  E4 r = p.ro[i];
+  for (int k = 0; k < p.npoints; k++) r = e4_add(r, e4_mul(p.inv[k][i], e4_sub(p.K[k], e4_mul(p.off[k], comp))));
+  p.ro[i] = r;
+}
+void bb_deep(Ctx& ctx, const BMat& m, const E4* d_apow, int npoints, const E4* const* d_inv, const E4* K, const E4* off, E4* d_ro) {
+  if (npoints == 0 || m.h == 0) return;
+  DeepArgs p;
+  p.m = m.buf.p, p.ld = m.ld, p.h = m.h, p.w = (unsigned)m.w, p.apow = d_apow, p.npoints = npoints, p.ro = d_ro;
+  for (int k = 0; k < 2; k++) {
+    p.inv[k] = k < npoints ? d_inv[k] : nullptr;
+    p.K[k] = k < npoints ? K[k] : e4_zero();
+    p.off[k] = k < npoints ? off[k] : e4_zero();
+  }
+  deep_k<<<blocks_for(m.h, 256), 256, 0, ctx.stream>>>(p);
+}
+// FRI fold of one layer (p3 TwoAdicFriFolding::fold_matrix, arity 2): rows (lo, hi) are the values at (x, -x) with
+// x = w^bitrev(i) of the order-2 rows subgroup; out = (lo + hi) / 2 + beta (lo - hi) / (2 x); then the roll-in of a
+// reduced opening of the same height with factor beta^2
+__global__ void fri_fold_k(const E4* __restrict__ cur, size_t rows, unsigned log_rows, E4 half_beta, u32 half, u32 g_inv, const E4* __restrict__ roll, E4 beta2,
+                           E4* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  u32 gp = bb_pow(g_inv, bitrev_dev(i, log_rows));
+  E4 pw = e4_mul_base(half_beta, gp);
+  E4 lo = cur[2 * i], hi = cur[2 * i + 1];
+  E4 a = pw, b = e4_neg(pw);
+  a.c[0] = bb_add(a.c[0], half);
+  b.c[0] = bb_add(b.c[0], half);
+  E4 r = e4_add(e4_mul(a, lo), e4_mul(b, hi));
+  if (roll) r = e4_add(r, e4_mul(beta2, roll[i]));
+  out[i] = r;
+}
+void bb_fri_fold(Ctx& ctx, const E4* cur, size_t rows, E4 beta, const E4* roll_in, E4* out) {
+  unsigned lr = log2_host(rows);
+  u32 half = bb_inv(bb_to_monty(2));
+  fri_fold_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(cur, rows, lr, e4_mul_base(beta, half), half, bb_inv(bb_two_adic_generator(lr + 1)), roll_in,
+                                                            e4_square(beta), out);
+}
+
+__global__ void gather_k(const GatherSeg* __restrict__ segs, size_t nsegs, u32* __restrict__ out) {
+  size_t s = blockIdx.x;
+  if (s >= nsegs) return;
+  GatherSeg g = segs[s];
+  for (u32 k = threadIdx.x; k < g.n; k += blockDim.x) out[g.dst + k] = g.src[(size_t)k * g.stride];
+}
+void bb_gather(Ctx& ctx, const std::vector<GatherSeg>& segs, std::vector<u32>& out) {
+  size_t total = 0;
+  for (auto& s : segs) total = std::max<size_t>(total, (size_t)s.dst + s.n);
+  out.assign(total, 0);
+  if (segs.empty()) return;
+  DBuf<GatherSeg> d_segs(ctx, segs.size());
+  DBuf<u32> d_out(ctx, std::max<size_t>(total, 1));
+  ctx.h2d(d_segs.p, segs.data(), segs.size() * sizeof(GatherSeg));
+  gather_k<<<(unsigned)segs.size(), 64, 0, ctx.stream>>>(d_segs.p, segs.size(), d_out.p);
+  ctx.d2h(out.data(), d_out.p, total * 4);
+}
+
+// element-wise field ops for known-answer tests: 0 add, 1 sub, 2 mul, 3 inverse(a), 4 ext4 mul (quads), 5 ext4 inverse
+__global__ void field_op_k(int op, const u32* a, const u32* b, size_t n, u32* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op < 4) {
+    u32 x = bb_to_monty(a[i]), y = b ? bb_to_monty(b[i]) : 0;
+    u32 r = op == 0 ? bb_add(x, y) : op == 1 ? bb_sub(x, y) : op == 2 ? bb_mul(x, y) : bb_inv(x);
+    out[i] = bb_from_monty(r);
+  } else {
+    E4 x, y = e4_zero();
+    for (int k = 0; k < 4; k++) x.c[k] = bb_to_monty(a[4 * i + k]);
+    if (op == 4)
+      for (int k = 0; k < 4; k++) y.c[k] = bb_to_monty(b[4 * i + k]);
+    E4 r = op == 4 ? e4_mul(x, y) : e4_inv(x);
+    for (int k = 0; k < 4; k++) out[4 * i + k] = bb_from_monty(r.c[k]);
+  }
+}
+void bb_field_op(Ctx& ctx, int op, const u32* a, const u32* b, size_t n, u32* out) {
+  size_t words = op >= 4 ? 4 * n : n;
+  DBuf<u32> da(ctx, std::max<size_t>(words, 1)), db(ctx, std::max<size_t>(words, 1)), dout(ctx, std::max<size_t>(words, 1));
+  if (!n) return;
+  ctx.h2d(da.p, a, words * 4);
+  if (b) ctx.h2d(db.p, b, words * 4);
+  field_op_k<<<blocks_for(n, 256), 256, 0, ctx.stream>>>(op, da.p, b ? db.p : nullptr, n, dout.p);
+  ctx.d2h(out, dout.p, words * 4);
+}
+
+}  // namespace msbb

@@ -1,0 +1,1071 @@
+// Host side of the BabyBear / Poseidon2 path: System / witness mirrors, the DuplexChallenger transcript and
+// System::prove_multiple_claims (/root/reference/src/prover.rs:290-603) instantiated for the reference's second
+// configuration (src/test_circuits/baby_bear_config.rs:28-127). The transcript runs on the host (a few hundred
+// Poseidon2 permutations per proof); every heavy step is a launch into bb_kernels.hip. The C ABI is include/mstark_bb.h.
+#include <algorithm>
+#include <chrono>
+#include <map>
+
+#include "../../include/mstark_bb.h"
+#include "bb.h"
+
+namespace msbb {
+
+using msamd::PNode;
+
+static unsigned log2_strict(size_t n) {
+  unsigned l = 0;
+  while ((size_t(1) << l) < n) l++;
+  return l;
+}
+static size_t bitrev_host(size_t x, unsigned bits) {
+  size_t r = 0;
+  for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// DuplexChallenger<BabyBear, Poseidon2BabyBear<16>, 16, 8> (baby_bear_config.rs:37), values in Montgomery form
+struct Challenger {
+  const Poseidon2* perm;
+  u32 state[16];
+  std::vector<u32> input, output;
+  explicit Challenger(const Poseidon2* p) : perm(p) {
+    for (auto& x : state) x = 0;
+  }
+  void duplexing() {
+    for (size_t i = 0; i < input.size(); i++) state[i] = input[i];
+    input.clear();
+    bb_poseidon2(*perm, state);
+    output.assign(state, state + 8);
+  }
+  void observe(u32 m) {
+    output.clear();
+    input.push_back(m);
+    if (input.size() == 8) duplexing();
+  }
+  void observe_usize(u64 x) { observe(bb_to_monty((u32)(x % BB_P))); }  // Val::from_usize
+  void observe_e4(E4 e) {
+    for (int k = 0; k < 4; k++) observe(e.c[k]);
+  }
+  void observe_cap(const std::vector<Digest8>& cap) {
+    for (auto& d : cap)
+      for (int k = 0; k < 8; k++) observe(d.w[k]);
+  }
+  u32 sample() {
+    if (!input.empty() || output.empty()) duplexing();
+    u32 v = output.back();
+    output.pop_back();
+    return v;
+  }
+  E4 sample_e4() {
+    E4 e;
+    for (int k = 0; k < 4; k++) e.c[k] = sample();
+    return e;
+  }
+  size_t sample_bits(unsigned bits) { return (size_t)(bb_from_monty(sample()) & ((1u << bits) - 1)); }
+  // smallest witness (canonical value); ZERO at 0 bits - the deterministic rule of src/types.rs:72-81
+  u32 grind(unsigned bits) {
+    if (bits == 0) return 0;
+    for (u32 w = 0; w < BB_P; w++) {
+      Challenger c = *this;
+      c.observe(bb_to_monty(w));
+      if (c.sample_bits(bits) == 0) {
+        observe(bb_to_monty(w));
+        sample_bits(bits);
+        return w;
+      }
+    }
+    throw std::runtime_error("grind: no witness");
+  }
+};
+
+struct Params {
+  u64 log_blowup = 1, cap_height = 0, log_final_poly_len = 0, max_log_arity = 1, num_queries = 1, commit_pow_bits = 0, query_pow_bits = 0;
+};
+struct BCircuit {
+  std::vector<PNode> nodes;
+  std::vector<uint32_t> degrees, zeros;
+  std::vector<std::pair<uint32_t, std::vector<uint32_t>>> lookups;
+  size_t main_width = 0, pre_width = 0, pre_height = 0, num_lookups = 0, stage2_width = 0, constraint_count = 0, max_constraint_degree = 0,
+         args_width = 0, lookup_prefix_len = 0;
+  BProgram prog;
+  BLookupsDev lk;
+  DBuf<u32> d_zeros;
+  BMat pre;  // preprocessed trace (column-major, Montgomery), for witness preparation
+  size_t quotient_degree() const {
+    size_t d = (max_constraint_degree > 2 ? max_constraint_degree : 2) - 1, q = 1;
+    while (q < d) q <<= 1;
+    return q;
+  }
+};
+struct BSystem {
+  Ctx* ctx = nullptr;
+  Params params;
+  Poseidon2 perm;
+  DBuf<Poseidon2> d_perm;
+  std::vector<BCircuit> circuits;
+  bool has_pre = false;
+  std::vector<Digest8> pre_commit;
+  std::vector<int> pre_indices;
+  BPcsData pre_data;
+  std::vector<u32> seed;  // Montgomery form
+};
+struct BWitness {
+  BSystem* sys = nullptr;
+  std::vector<size_t> heights;
+  std::vector<BMat> traces;
+  std::vector<std::vector<u32>> claims;  // canonical
+};
+
+static std::vector<Digest8> tree_cap(Ctx& ctx, const BTree& t) {
+  size_t l = t.cap_layer();
+  std::vector<Digest8> cap(t.sizes[l]);
+  ctx.d2h(cap.data(), t.layers[l].p, cap.size() * sizeof(Digest8));
+  return cap;
+}
+
+namespace {
+struct Reader {
+  const uint8_t* p;
+  size_t n, off = 0;
+  u64 word() {
+    if (off + 8 > n) throw std::runtime_error("system blob truncated");
+    u64 v = 0;
+    for (int k = 0; k < 8; k++) v |= (u64)p[off + k] << (8 * k);
+    off += 8;
+    return v;
+  }
+};
+}  // namespace
+static const u64 BLOB_MAGIC = 0x31304259534D0000ULL;  // "\0\0MSYB01"
+
+static void set_internal_diag(Poseidon2& k) {
+  auto m = [](u32 canonical) { return bb_to_monty(canonical); };
+  u32 half = bb_inv(m(2)), i8 = bb_inv(m(256)), i27 = bb_inv(m(1u << 27));
+  u32 t[16] = {bb_neg(m(2)), m(1), m(2), half, m(3), m(4), bb_neg(half), bb_neg(m(3)), bb_neg(m(4)), i8, bb_inv(m(4)), bb_inv(m(8)), i27,
+               bb_neg(i8), bb_neg(bb_inv(m(16))), bb_neg(i27)};
+  for (int i = 0; i < 16; i++) k.diag[i] = t[i];
+}
+
+std::unique_ptr<BSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t len) {
+  HIP_CHECK(hipSetDevice(ctx.device));
+  Reader rd{blob, len};
+  if (rd.word() != BLOB_MAGIC) throw std::runtime_error("bad system blob magic (expected a BabyBear / Poseidon2 system)");
+  std::unique_ptr<BSystem> sys(new BSystem());
+  sys->ctx = &ctx;
+  Params& p = sys->params;
+  p.log_blowup = rd.word(), p.cap_height = rd.word(), p.log_final_poly_len = rd.word(), p.max_log_arity = rd.word();
+  p.num_queries = rd.word(), p.commit_pow_bits = rd.word(), p.query_pow_bits = rd.word();
+  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 (binary folding) is supported");
+  if (p.log_blowup < 1 || p.log_blowup > 8) throw std::runtime_error("log_blowup out of range");
+  if (p.commit_pow_bits > 24 || p.query_pow_bits > 24) throw std::runtime_error("proof-of-work bits out of range");
+  for (int r = 0; r < 8; r++)
+    for (int i = 0; i < 16; i++) {
+      u64 v = rd.word();
+      if (v >= BB_P) throw std::runtime_error("non-canonical round constant");
+      sys->perm.external[r][i] = bb_to_monty((u32)v);
+    }
+  for (int r = 0; r < 13; r++) {
+    u64 v = rd.word();
+    if (v >= BB_P) throw std::runtime_error("non-canonical round constant");
+    sys->perm.internal[r] = bb_to_monty((u32)v);
+  }
+  set_internal_diag(sys->perm);
+  sys->d_perm = DBuf<Poseidon2>(ctx, 1);
+  ctx.h2d(sys->d_perm.p, &sys->perm, sizeof(Poseidon2));
+  {
+    const char* tag = "multi-stark/v0";  // baby_bear_config.rs:72-86
+    for (int i = 0; i < 14; i++) sys->seed.push_back(bb_to_monty((u32)(uint8_t)tag[i]));
+    const u64 ps[7] = {p.log_blowup, p.cap_height, p.log_final_poly_len, p.max_log_arity, p.num_queries, p.commit_pow_bits, p.query_pow_bits};
+    for (u64 x : ps) sys->seed.push_back(bb_to_monty((u32)(x % BB_P)));
+  }
+  const size_t D = 4;
+  size_t nc = rd.word();
+  std::vector<BMat> pre_ldes;
+  for (size_t ci = 0; ci < nc; ci++) {
+    sys->circuits.emplace_back();
+    BCircuit& c = sys->circuits.back();
+    c.main_width = rd.word(), c.pre_width = rd.word(), c.pre_height = rd.word();
+    size_t nn = rd.word(), nz = rd.word(), nl = rd.word();
+    c.num_lookups = nl;
+    c.stage2_width = std::max<size_t>(nl, 1) * D;  // src/lookup.rs:90-92
+    c.nodes.resize(nn);
+    c.degrees.resize(nn);
+    for (size_t i = 0; i < nn; i++) {
+      u64 w0 = rd.word();
+      PNode& nd = c.nodes[i];
+      nd.kind = (uint32_t)(w0 & 0xff), nd.source = (uint32_t)((w0 >> 8) & 0xff), nd.offset = (uint32_t)((w0 >> 16) & 0xff);
+      nd.a = rd.word(), nd.b = rd.word();
+      auto child = [&](u64 id) -> uint32_t {
+        if (id >= i) throw std::runtime_error("node program is not topologically ordered");
+        return c.degrees[id];
+      };
+      uint32_t deg = 0;
+      switch (nd.kind) {  // src/graph.rs:242-252
+        case msamd::OP_CONST:
+          if (nd.a >= BB_P) throw std::runtime_error("non-canonical constant in node program");
+          break;
+        case msamd::OP_PUBLIC:
+          if (nd.a >= 4 * D) throw std::runtime_error("public index out of range");
+          break;
+        case msamd::OP_IS_TRANS: break;
+        case msamd::OP_VAR: {
+          size_t width = nd.source == 0 ? c.pre_width : nd.source == 1 ? c.main_width : c.stage2_width;
+          if (nd.source > 2 || nd.offset > 1 || nd.a >= width) throw std::runtime_error("column reference out of range");
+          deg = 1;
+          break;
+        }
+        case msamd::OP_IS_FIRST:
+        case msamd::OP_IS_LAST: deg = 1; break;
+        case msamd::OP_ADD:
+        case msamd::OP_SUB: deg = std::max(child(nd.a), child(nd.b)); break;
+        case msamd::OP_MUL: deg = child(nd.a) + child(nd.b); break;
+        case msamd::OP_NEG: deg = child(nd.a); break;
+        default: throw std::runtime_error("bad node kind");
+      }
+      c.degrees[i] = deg;
+    }
+    uint32_t graph_deg = 0;
+    for (size_t i = 0; i < nz; i++) {
+      u64 z = rd.word();
+      if (z >= nn) throw std::runtime_error("constraint root out of range");
+      c.zeros.push_back((uint32_t)z);
+      graph_deg = std::max(graph_deg, c.degrees[z]);
+    }
+    uint32_t logup_deg = nl ? 0 : 1;  // src/lookup.rs:262-278
+    std::vector<u32> lk_mult, lk_off(1, 0), lk_args;
+    for (size_t j = 0; j < nl; j++) {
+      u64 m = rd.word();
+      if (m >= nn) throw std::runtime_error("lookup node out of range");
+      size_t na = rd.word();
+      std::vector<uint32_t> args;
+      uint32_t msg = 0;
+      c.lookup_prefix_len = std::max<size_t>(c.lookup_prefix_len, m + 1);
+      for (size_t k = 0; k < na; k++) {
+        u64 a = rd.word();
+        if (a >= nn) throw std::runtime_error("lookup node out of range");
+        args.push_back((uint32_t)a);
+        lk_args.push_back((u32)a);
+        msg = std::max(msg, c.degrees[a]);
+        c.lookup_prefix_len = std::max<size_t>(c.lookup_prefix_len, a + 1);
+      }
+      lk_mult.push_back((u32)m);
+      lk_off.push_back((u32)lk_args.size());
+      c.args_width += na;
+      logup_deg = std::max(logup_deg, std::max(msg + 1, c.degrees[m]));
+      c.lookups.emplace_back((uint32_t)m, std::move(args));
+    }
+    for (size_t i = 0; i < c.lookup_prefix_len; i++)  // src/graph.rs: the lookup prefix lives in the base context
+      if (c.nodes[i].kind == msamd::OP_PUBLIC || (c.nodes[i].kind == msamd::OP_VAR && c.nodes[i].source == 2))
+        throw std::runtime_error("lookup expressions may only read trace columns and row selectors");
+    c.constraint_count = nz + std::max<size_t>(nl, 1) * D;  // src/system.rs:151
+    c.max_constraint_degree = std::max(graph_deg, logup_deg);
+    if (c.quotient_degree() > (size_t(1) << p.log_blowup))  // src/system.rs:171-178
+      throw std::runtime_error("circuit " + std::to_string(ci) + ": constraint degree needs a quotient degree beyond the blowup");
+    bb_build_program(ctx, c.nodes, c.prog);
+    c.lk.L = nl;
+    c.lk.mult = DBuf<u32>(ctx, std::max<size_t>(nl, 1));
+    c.lk.arg_off = DBuf<u32>(ctx, nl + 1);
+    c.lk.args = DBuf<u32>(ctx, std::max<size_t>(lk_args.size(), 1));
+    c.d_zeros = DBuf<u32>(ctx, std::max<size_t>(nz, 1));
+    if (nl) ctx.h2d(c.lk.mult.p, lk_mult.data(), nl * 4);
+    ctx.h2d(c.lk.arg_off.p, lk_off.data(), (nl + 1) * 4);
+    if (!lk_args.empty()) ctx.h2d(c.lk.args.p, lk_args.data(), lk_args.size() * 4);
+    if (nz) ctx.h2d(c.d_zeros.p, c.zeros.data(), nz * 4);
+    ctx.sync();
+    if (c.pre_width) {
+      if (c.pre_height == 0 || (c.pre_height & (c.pre_height - 1))) throw std::runtime_error("preprocessed height must be a power of two");
+      if (log2_strict(c.pre_height) + p.log_blowup > BB_TWO_ADICITY) throw std::runtime_error("preprocessed trace too tall");
+      std::vector<u32> rows(c.pre_height * c.pre_width);
+      for (auto& x : rows) {
+        u64 v = rd.word();
+        if (v >= BB_P) throw std::runtime_error("non-canonical preprocessed value");
+        x = (u32)v;
+      }
+      bb_upload_rows(ctx, rows.data(), c.pre_height, c.pre_width, c.pre);
+      sys->pre_indices.push_back((int)pre_ldes.size());
+      pre_ldes.emplace_back();
+      bb_coset_lde(ctx, c.pre, (unsigned)p.log_blowup, pre_ldes.back());
+    } else {
+      c.pre_height = 0;
+      sys->pre_indices.push_back(-1);
+    }
+  }
+  if (rd.off != len) throw std::runtime_error("trailing bytes in system blob");
+  if (!pre_ldes.empty()) {
+    sys->has_pre = true;
+    bb_commit(ctx, sys->d_perm.p, std::move(pre_ldes), (unsigned)p.cap_height, sys->pre_data);
+    sys->pre_commit = tree_cap(ctx, sys->pre_data.tree);
+  }
+  ctx.sync();
+  return sys;
+}
+
+std::unique_ptr<BWitness> witness_create(BSystem& sys, const u32* const* traces, const u64* heights, size_t n_claims, const u64* claim_offsets,
+                                         const u32* claim_data) {
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  std::unique_ptr<BWitness> w(new BWitness());
+  w->sys = &sys;
+  size_t C = sys.circuits.size();
+  for (size_t ci = 0; ci < C; ci++) {
+    const BCircuit& c = sys.circuits[ci];
+    size_t h = (size_t)heights[ci];
+    w->heights.push_back(h);
+    w->traces.emplace_back();
+    if (h == 0) continue;
+    if (h & (h - 1)) throw std::runtime_error("trace height must be a power of two");
+    if (log2_strict(h) + log2_strict(c.quotient_degree()) + sys.params.log_blowup > BB_TWO_ADICITY)  // baby_bear_config.rs:87
+      throw std::runtime_error("trace too tall for the two-adicity of BabyBear");
+    if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    if (!traces[ci]) throw std::runtime_error("missing trace");
+    for (size_t i = 0; i < h * c.main_width; i++)
+      if (traces[ci][i] >= BB_P) throw std::runtime_error("non-canonical trace value");
+    bb_upload_rows(ctx, traces[ci], h, c.main_width, w->traces.back());
+  }
+  for (size_t i = 0; i < n_claims; i++) {
+    w->claims.emplace_back(claim_data + claim_offsets[i], claim_data + claim_offsets[i + 1]);
+    for (u32 x : w->claims.back())
+      if (x >= BB_P) throw std::runtime_error("non-canonical claim value");
+  }
+  return w;
+}
+
+// ------------------------------------------------------------------ proof bytes (Proof::to_bytes, src/prover.rs:241-248)
+namespace {
+struct W {
+  std::vector<uint8_t> b;
+  void u8(uint8_t x) { b.push_back(x); }
+  void u64_(u64 x) {
+    for (int k = 0; k < 8; k++) b.push_back((uint8_t)(x >> (8 * k)));
+  }
+  void fe(u32 monty) {  // MontyField31 serialises its Montgomery word
+    for (int k = 0; k < 4; k++) b.push_back((uint8_t)(monty >> (8 * k)));
+  }
+  void ext(E4 e) {
+    for (int k = 0; k < 4; k++) fe(e.c[k]);
+  }
+  void dig(const Digest8& d) {
+    for (int k = 0; k < 8; k++) fe(d.w[k]);
+  }
+  void cap(const std::vector<Digest8>& c) {
+    u64_(c.size());
+    for (auto& d : c) dig(d);
+  }
+};
+typedef std::vector<std::vector<std::vector<E4>>> OpenedRound;  // matrix -> point -> column
+void write_round(W& w, const OpenedRound& r) {
+  w.u64_(r.size());
+  for (auto& m : r) {
+    w.u64_(m.size());
+    for (auto& pt : m) {
+      w.u64_(pt.size());
+      for (auto& e : pt) w.ext(e);
+    }
+  }
+}
+struct OpenRound {
+  const BPcsData* data;
+  std::vector<std::vector<E4>> points;  // per matrix
+};
+struct E4Less {
+  bool operator()(const E4& a, const E4& b) const {
+    for (int k = 0; k < 4; k++)
+      if (a.c[k] != b.c[k]) return a.c[k] < b.c[k];
+    return false;
+  }
+};
+struct FriOut {
+  std::vector<std::vector<Digest8>> commits;
+  std::vector<u32> pow_witnesses;  // canonical
+  std::vector<E4> final_poly;
+  u32 query_pow_witness = 0;
+  std::vector<uint8_t> query_bytes;  // the serialised Vec<QueryProof> body (without its length)
+};
+
+// TwoAdicFriPcs::open + prove_fri (p3-fri 0.5.1: open, prover::prove_fri / commit_phase / answer_query, TwoAdicFriFolding)
+void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, FriOut& fri) {
+  Ctx& ctx = *sys.ctx;
+  const Params& prm = sys.params;
+  unsigned lb = (unsigned)prm.log_blowup;
+  size_t gmax = 0, gw = 0;
+  for (auto& r : rounds)
+    for (auto& m : r.data->ldes) gmax = std::max(gmax, m.h), gw = std::max(gw, m.w);
+  if (!gmax) throw std::runtime_error("no matrices supplied");
+  unsigned log_gmax = log2_strict(gmax);
+
+  // 1 / (z - x_i) and x_i / (z - x_i) per distinct point, for the tallest matrix opened there
+  std::map<E4, size_t, E4Less> max_h;
+  for (auto& r : rounds)
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++)
+      for (auto& z : r.points[mi]) {
+        size_t& h = max_h[z];
+        h = std::max(h, r.data->ldes[mi].h);
+      }
+  struct Denoms {
+    DBuf<E4> inv, wgt;
+  };
+  std::map<E4, Denoms, E4Less> denoms;
+  for (auto& kv : max_h) {
+    Denoms d;
+    d.inv = DBuf<E4>(ctx, kv.second);
+    d.wgt = DBuf<E4>(ctx, kv.second);
+    bb_inv_denoms(ctx, kv.first, log2_strict(kv.second), kv.second, d.inv.p, d.wgt.p);
+    denoms.emplace(kv.first, std::move(d));
+  }
+  // opened values: barycentric interpolation over the first h = height / blowup storage rows (the coset g H_h)
+  u32 g = bb_to_monty(BB_GENERATOR);
+  opened.clear();
+  for (auto& r : rounds) {
+    OpenedRound orr;
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+      const BMat& mat = r.data->ldes[mi];
+      size_t h = mat.h >> lb;
+      unsigned log_h = log2_strict(h);
+      std::vector<std::vector<E4>> per_point;
+      for (auto& z : r.points[mi]) {
+        std::vector<E4> sums;
+        bb_bary(ctx, mat, h, denoms.at(z).wgt.p, sums);
+        u32 s_pow = bb_exp_pow2(g, log_h);
+        E4 vanish = e4_exp_pow2(z, log_h);
+        vanish.c[0] = bb_sub(vanish.c[0], s_pow);
+        E4 scale = e4_mul_base(vanish, bb_inv(bb_mul(s_pow, bb_to_monty((u32)(h % BB_P)))));
+        for (auto& y : sums) {
+          y = e4_mul(y, scale);
+          ch.observe_e4(y);
+        }
+        per_point.push_back(std::move(sums));
+      }
+      orr.push_back(std::move(per_point));
+    }
+    opened.push_back(std::move(orr));
+  }
+
+  E4 alpha = ch.sample_e4();
+  std::vector<E4> apow(gw + 1);
+  apow[0] = e4_one();
+  for (size_t i = 1; i <= gw; i++) apow[i] = e4_mul(apow[i - 1], alpha);
+  DBuf<E4> d_apow(ctx, apow.size());
+  ctx.h2d(d_apow.p, apow.data(), apow.size() * sizeof(E4));
+
+  // reduced openings per height (DEEP quotients)
+  std::vector<size_t> num_reduced(33, 0);
+  std::vector<DBuf<E4>> reduced(33);
+  std::vector<size_t> reduced_len(33, 0);
+  for (size_t ri = 0; ri < rounds.size(); ri++) {
+    auto& r = rounds[ri];
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+      const BMat& mat = r.data->ldes[mi];
+      unsigned lh = log2_strict(mat.h);
+      if (!reduced_len[lh]) {
+        reduced_len[lh] = mat.h;
+        reduced[lh] = DBuf<E4>(ctx, mat.h);
+        HIP_CHECK(hipMemsetAsync(reduced[lh].p, 0, mat.h * sizeof(E4), ctx.stream));
+      }
+      size_t np = r.points[mi].size();
+      if (np == 0) continue;
+      if (np > 2) throw std::runtime_error("more than two opening points per matrix");
+      const E4* inv[2] = {nullptr, nullptr};
+      E4 K[2], off[2];
+      for (size_t pi = 0; pi < np; pi++) {
+        const std::vector<E4>& ys = opened[ri][mi][pi];
+        off[pi] = e4_pow(alpha, num_reduced[lh]);
+        E4 red_z = e4_zero();
+        for (size_t c = 0; c < mat.w; c++) red_z = e4_add(red_z, e4_mul(apow[c], ys[c]));
+        K[pi] = e4_mul(off[pi], red_z);
+        inv[pi] = denoms.at(r.points[mi][pi]).inv.p;
+        num_reduced[lh] += mat.w;
+      }
+      bb_deep(ctx, mat, d_apow.p, (int)np, inv, K, off, reduced[lh].p);
+    }
+  }
+  std::vector<std::pair<E4*, size_t>> inputs;
+  for (int lh = 32; lh >= 0; lh--)
+    if (reduced_len[lh]) inputs.emplace_back(reduced[lh].p, reduced_len[lh]);
+
+  // ---- prove_fri: commit phase
+  size_t final_len = size_t(1) << prm.log_final_poly_len;
+  size_t stop = (size_t(1) << lb) * final_len;
+  if (prm.log_final_poly_len > 0) {  // p3 prove_fri: every input must be taller than blowup * final length
+    size_t min_h = inputs[0].second;
+    for (auto& in : inputs) min_h = std::min(min_h, in.second);
+    if (min_h <= stop) throw std::runtime_error("FRI: a committed matrix is not taller than blowup * final polynomial length");
+  }
+  std::vector<DBuf<E4>> layers;  // layers[i]: the vector folded in round i (its pairs are the leaves of FRI tree i)
+  std::vector<BTree> fri_trees;
+  std::vector<size_t> layer_len;
+  E4* cur = inputs[0].first;
+  size_t cur_len = inputs[0].second;
+  size_t next_in = 1;
+  unsigned log_max_height = log2_strict(cur_len);
+  while (cur_len > stop) {
+    size_t rows = cur_len / 2;
+    fri_trees.emplace_back();
+    bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back());
+    std::vector<Digest8> cap = tree_cap(ctx, fri_trees.back());
+    ch.observe_cap(cap);
+    fri.commits.push_back(cap);
+    fri.pow_witnesses.push_back(ch.grind((unsigned)prm.commit_pow_bits));
+    E4 beta = ch.sample_e4();
+    const E4* roll = nullptr;
+    if (next_in < inputs.size() && inputs[next_in].second == rows) roll = inputs[next_in++].first;
+    DBuf<E4> out(ctx, rows);
+    bb_fri_fold(ctx, cur, rows, beta, roll, out.p);
+    // keep the folded-from vector alive for the query openings
+    if (layers.empty()) {
+      layers.emplace_back();  // layer 0 is inputs[0] (owned by `reduced`)
+      layer_len.push_back(cur_len);
+    }
+    layers.push_back(std::move(out));
+    layer_len.push_back(rows);
+    cur = layers.back().p;
+    cur_len = rows;
+  }
+  if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
+  // final polynomial: first final_len entries, undo the bit reversal, inverse DFT (tiny: on the host)
+  {
+    unsigned lf = (unsigned)prm.log_final_poly_len;
+    std::vector<E4> head(final_len), nat(final_len);
+    ctx.d2h(head.data(), cur, final_len * sizeof(E4));
+    for (size_t i = 0; i < final_len; i++) nat[bitrev_host(i, lf)] = head[i];
+    u32 w_inv = bb_inv(bb_two_adic_generator(lf)), n_inv = bb_inv(bb_to_monty((u32)final_len));
+    fri.final_poly.resize(final_len);
+    for (size_t k = 0; k < final_len; k++) {
+      E4 acc = e4_zero();
+      u32 step = bb_pow(w_inv, k), tw = BB_R1;
+      for (size_t j = 0; j < final_len; j++) {
+        acc = e4_add(acc, e4_mul_base(nat[j], tw));
+        tw = bb_mul(tw, step);
+      }
+      fri.final_poly[k] = e4_mul_base(acc, n_inv);
+      ch.observe_e4(fri.final_poly[k]);
+    }
+  }
+  fri.query_pow_witness = ch.grind((unsigned)prm.query_pow_bits);
+
+  // ---- query phase: one gather of every opened row, sibling value and authentication path
+  std::vector<GatherSeg> segs;
+  u32 pos = 0;
+  auto add_seg = [&](const u32* src, u32 n, u32 stride) {
+    segs.push_back(GatherSeg{src, pos, n, stride});
+    u32 at = pos;
+    pos += n;
+    return at;
+  };
+  struct TreeOpen {
+    std::vector<std::pair<u32, u32>> rows;  // (offset, width) per matrix
+    u32 path_at, path_len;
+  };
+  auto open_tree_path = [&](const BTree& t, size_t index, TreeOpen& o) {
+    unsigned log_max = log2_strict(t.sizes[0]);
+    size_t ch_eff = std::min<size_t>(t.cap_height, t.layers.size() - 1);
+    o.path_len = (u32)(log_max - ch_eff);
+    o.path_at = pos;
+    for (size_t i = 0; i + ch_eff < log_max; i++) add_seg((const u32*)(t.layers[i].p + ((index >> i) ^ 1)), 8, 1);
+  };
+  std::vector<size_t> indices;
+  std::vector<std::vector<TreeOpen>> input_opens, fri_opens;
+  std::vector<std::vector<u32>> sib_at;
+  for (size_t qi = 0; qi < prm.num_queries; qi++) {
+    size_t index = ch.sample_bits(log_max_height);
+    indices.push_back(index);
+    input_opens.emplace_back();
+    for (auto& r : rounds) {
+      const BTree& t = r.data->tree;
+      unsigned lmh = log2_strict(t.sizes[0]);
+      size_t idx = index >> (log_gmax - lmh);
+      TreeOpen o;
+      for (auto& m : r.data->ldes) {
+        size_t row = idx >> (lmh - log2_strict(m.h));
+        o.rows.emplace_back(add_seg(m.buf.p + row, (u32)m.w, (u32)m.ld), (u32)m.w);
+      }
+      open_tree_path(t, idx, o);
+      input_opens.back().push_back(std::move(o));
+    }
+    fri_opens.emplace_back();
+    sib_at.emplace_back();
+    for (size_t i = 0; i < fri_trees.size(); i++) {
+      size_t index_i = index >> i, sib = index_i ^ 1, pair = index_i >> 1;
+      const E4* vec = i == 0 ? inputs[0].first : layers[i].p;
+      sib_at.back().push_back(add_seg((const u32*)(vec + sib), 4, 1));
+      TreeOpen o;
+      open_tree_path(fri_trees[i], pair, o);
+      fri_opens.back().push_back(std::move(o));
+    }
+  }
+  std::vector<u32> g_out;
+  bb_gather(ctx, segs, g_out);
+  W w;
+  for (size_t qi = 0; qi < prm.num_queries; qi++) {
+    w.u64_(rounds.size());
+    for (auto& o : input_opens[qi]) {
+      w.u64_(o.rows.size());
+      for (auto& rw : o.rows) {
+        w.u64_(rw.second);
+        for (u32 k = 0; k < rw.second; k++) w.fe(g_out[rw.first + k]);
+      }
+      w.u64_(o.path_len);
+      for (u32 k = 0; k < o.path_len * 8; k++) w.fe(g_out[o.path_at + k]);
+    }
+    w.u64_(fri_trees.size());
+    for (size_t i = 0; i < fri_trees.size(); i++) {
+      w.u8(1);  // log_arity
+      w.u64_(1);
+      for (u32 k = 0; k < 4; k++) w.fe(g_out[sib_at[qi][i] + k]);
+      const TreeOpen& o = fri_opens[qi][i];
+      w.u64_(o.path_len);
+      for (u32 k = 0; k < o.path_len * 8; k++) w.fe(g_out[o.path_at + k]);
+    }
+  }
+  fri.query_bytes = std::move(w.b);
+}
+}  // namespace
+
+std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  double t_begin = now_ms(), t0;
+  const Params& prm = sys.params;
+  unsigned lb = (unsigned)prm.log_blowup;
+  size_t C = sys.circuits.size();
+  if (wit.traces.size() != C) throw std::runtime_error("witness/circuit count mismatch");
+  Challenger ch(&sys.perm);
+  for (u32 v : sys.seed) ch.observe(v);
+  // System::observe_shape, src/system.rs:211-222
+  ch.observe_usize(C);
+  for (auto& c : sys.circuits) {
+    ch.observe_usize(c.constraint_count), ch.observe_usize(c.max_constraint_degree), ch.observe_usize(c.pre_height);
+    ch.observe_usize(c.pre_width), ch.observe_usize(c.main_width), ch.observe_usize(c.stage2_width);
+  }
+  std::vector<uint8_t> active;
+  std::vector<size_t> active_idx;
+  std::vector<int> active_pos(C, -1);
+  for (size_t i = 0; i < C; i++) {
+    bool a = wit.heights[i] > 0;
+    active.push_back(a);
+    ch.observe(a ? BB_R1 : 0);
+    if (a) {
+      active_pos[i] = (int)active_idx.size();
+      active_idx.push_back(i);
+    }
+  }
+  if (active_idx.empty()) throw std::runtime_error("cannot prove with every circuit deactivated");
+
+  // ---- stage 1 commit
+  t0 = now_ms();
+  std::vector<unsigned> log_degrees;
+  BPcsData s1;
+  {
+    std::vector<BMat> ldes;
+    for (size_t ci : active_idx) {
+      log_degrees.push_back(log2_strict(wit.heights[ci]));
+      ldes.emplace_back();
+      bb_coset_lde(ctx, wit.traces[ci], lb, ldes.back());
+    }
+    bb_commit(ctx, sys.d_perm.p, std::move(ldes), (unsigned)prm.cap_height, s1);
+  }
+  std::vector<Digest8> s1_cap = tree_cap(ctx, s1.tree);
+  if (stage_ms) stage_ms[0] = now_ms() - t0;
+  if (sys.has_pre) ch.observe_cap(sys.pre_commit);
+  ch.observe_cap(s1_cap);
+  for (unsigned ld : log_degrees) ch.observe_usize(ld);
+  ch.observe_usize(wit.claims.size());
+  for (auto& c : wit.claims) {
+    ch.observe_usize(c.size());
+    for (u32 x : c) ch.observe(bb_to_monty(x));
+  }
+  E4 beta = ch.sample_e4();
+  ch.observe_e4(beta);
+  E4 gamma = ch.sample_e4();
+  ch.observe_e4(gamma);
+  // claims accumulator, src/prover.rs:382-387 (host: the reference's second configuration carries few claims)
+  E4 acc = e4_zero();
+  for (auto& c : wit.claims) {
+    E4 f = e4_zero();
+    for (size_t k = c.size(); k-- > 0;) {
+      f = e4_mul(f, gamma);
+      f.c[0] = bb_add(f.c[0], bb_to_monty(c[k]));
+    }
+    acc = e4_add(acc, e4_inv(e4_add(beta, f)));
+  }
+
+  // ---- lookup construction + stage 2 commit
+  t0 = now_ms();
+  std::vector<E4> accumulators;
+  BPcsData s2;
+  {
+    std::vector<BMat> s2_traces;
+    E4 running = acc;
+    for (size_t ci : active_idx) {
+      const BCircuit& c = sys.circuits[ci];
+      s2_traces.emplace_back();
+      E4 total;
+      bb_stage2(ctx, c.prog, c.lookup_prefix_len, c.lk, wit.traces[ci], c.pre_width ? &c.pre : nullptr, beta, gamma, s2_traces.back(), &total);
+      running = e4_add(running, total);
+      accumulators.push_back(running);
+    }
+    if (stage_ms) stage_ms[1] = now_ms() - t0;
+    t0 = now_ms();
+    std::vector<BMat> ldes;
+    for (auto& t : s2_traces) {
+      ldes.emplace_back();
+      bb_coset_lde(ctx, t, lb, ldes.back());
+    }
+    bb_commit(ctx, sys.d_perm.p, std::move(ldes), (unsigned)prm.cap_height, s2);
+  }
+  std::vector<Digest8> s2_cap = tree_cap(ctx, s2.tree);
+  if (stage_ms) stage_ms[2] = now_ms() - t0;
+  ch.observe_cap(s2_cap);
+  for (auto& a : accumulators) ch.observe_e4(a);
+  E4 alpha = ch.sample_e4();
+
+  // ---- quotient
+  t0 = now_ms();
+  BPcsData qd;
+  {
+    std::vector<BMat> q_ldes;
+    E4 cur_acc = acc;
+    for (size_t pos = 0; pos < active_idx.size(); pos++) {
+      size_t ci = active_idx[pos];
+      const BCircuit& c = sys.circuits[ci];
+      unsigned log_q = log2_strict(c.quotient_degree());
+      BQuotientIn in;
+      in.prog = &c.prog, in.lk = &c.lk, in.d_zeros = c.d_zeros.p, in.n_zeros = c.zeros.size(), in.constraint_count = c.constraint_count;
+      in.pre = sys.has_pre && sys.pre_indices[ci] >= 0 ? &sys.pre_data.ldes[sys.pre_indices[ci]] : nullptr;
+      in.s1 = &s1.ldes[pos], in.s2 = &s2.ldes[pos];
+      in.log_n = log_degrees[pos], in.log_q = log_q, in.log_blowup = lb;
+      in.publics[0] = beta, in.publics[1] = gamma, in.publics[2] = cur_acc, in.publics[3] = accumulators[pos];
+      in.alpha = alpha;
+      BMat q_evals;
+      bb_quotient(ctx, in, q_evals);
+      q_ldes.emplace_back();
+      bb_quotient_lde(ctx, q_evals, log_degrees[pos], log_q, lb, q_ldes.back());
+      ctx.sync();
+      cur_acc = accumulators[pos];
+    }
+    bb_commit(ctx, sys.d_perm.p, std::move(q_ldes), (unsigned)prm.cap_height, qd);
+  }
+  std::vector<Digest8> q_cap = tree_cap(ctx, qd.tree);
+  ch.observe_cap(q_cap);
+  if (stage_ms) stage_ms[3] = now_ms() - t0;
+
+  // ---- opening
+  t0 = now_ms();
+  E4 zeta = ch.sample_e4();
+  std::vector<OpenRound> rounds(3);
+  rounds[0].data = &s1, rounds[1].data = &s2, rounds[2].data = &qd;
+  for (unsigned ld : log_degrees) {
+    E4 zn = e4_mul_base(zeta, bb_two_adic_generator(ld));
+    rounds[0].points.push_back({zeta, zn});
+    rounds[1].points.push_back({zeta, zn});
+    rounds[2].points.push_back({zeta});
+  }
+  if (sys.has_pre) {
+    OpenRound r0;
+    r0.data = &sys.pre_data;
+    for (size_t ci = 0; ci < C; ci++) {
+      if (sys.pre_indices[ci] < 0) continue;
+      if (active_pos[ci] >= 0) {
+        E4 zn = e4_mul_base(zeta, bb_two_adic_generator(log_degrees[active_pos[ci]]));
+        r0.points.push_back({zeta, zn});
+      } else {
+        r0.points.push_back({});
+      }
+    }
+    rounds.push_back(std::move(r0));
+  }
+  std::vector<OpenedRound> opened;
+  FriOut fri;
+  pcs_open(sys, rounds, ch, opened, fri);
+
+  // ---- Proof::to_bytes
+  W w;
+  w.u64_(active.size());
+  for (auto a : active) w.u8(a ? 1 : 0);
+  w.cap(s1_cap), w.cap(s2_cap), w.cap(q_cap);
+  w.u64_(accumulators.size());
+  for (auto& e : accumulators) w.ext(e);
+  w.u64_(log_degrees.size());
+  for (auto d : log_degrees) w.u8((uint8_t)d);
+  w.u64_(fri.commits.size());
+  for (auto& c : fri.commits) w.cap(c);
+  w.u64_(fri.pow_witnesses.size());
+  for (u32 x : fri.pow_witnesses) w.fe(bb_to_monty(x));
+  w.u64_(prm.num_queries);
+  w.b.insert(w.b.end(), fri.query_bytes.begin(), fri.query_bytes.end());
+  w.u64_(fri.final_poly.size());
+  for (auto& e : fri.final_poly) w.ext(e);
+  w.fe(bb_to_monty(fri.query_pow_witness));
+  write_round(w, opened[2]);
+  w.u8(sys.has_pre ? 1 : 0);
+  if (sys.has_pre) write_round(w, opened[3]);
+  write_round(w, opened[0]);
+  write_round(w, opened[1]);
+  if (stage_ms) {
+    stage_ms[4] = now_ms() - t0;
+    stage_ms[5] = now_ms() - t_begin;
+  }
+  return std::move(w.b);
+}
+
+}  // namespace msbb
+
+// ------------------------------------------------------------------ C ABI (include/mstark_bb.h)
+using namespace msbb;
+
+namespace msamd {  // capi.hip
+void set_last_error(const char* what);
+Ctx* ctx_of(ms_ctx* c);
+void ctx_retain(ms_ctx* c);
+void ctx_release(ms_ctx* c);
+}  // namespace msamd
+// Handle lifetimes as in include/mstark.h: a system keeps its context alive, a witness its system, an mmcs its context.
+struct msbb_system {
+  ms_ctx* owner = nullptr;
+  std::unique_ptr<BSystem> sys;
+  int refs = 1;
+};
+static void system_unref(msbb_system* s) {
+  if (s && --s->refs == 0) {
+    ms_ctx* c = s->owner;
+    s->sys.reset();
+    delete s;
+    msamd::ctx_release(c);
+  }
+}
+struct msbb_witness {
+  msbb_system* owner = nullptr;
+  std::unique_ptr<BWitness> w;
+};
+struct msbb_mmcs {
+  ms_ctx* owner = nullptr;
+  Ctx* ctx = nullptr;
+  BPcsData data;
+};
+// a process-wide permutation for the PCS-level entry points (msbb_set_poseidon2)
+struct PermHolder {
+  Poseidon2 host;
+  Poseidon2* dev = nullptr;
+  bool set = false;
+};
+static PermHolder& perm_holder() {
+  static PermHolder h;
+  return h;
+}
+
+#define BB_TRY try {
+#define BB_CATCH                                  \
+  }                                               \
+  catch (const std::exception& e) {               \
+    msamd::set_last_error(e.what());              \
+    return MS_ERR;                                \
+  }                                               \
+  catch (...) {                                   \
+    msamd::set_last_error("unknown error");       \
+    return MS_ERR;                                \
+  }
+
+extern "C" {
+
+int32_t msbb_system_create(ms_ctx* ctx, const uint8_t* blob, size_t len, msbb_system** out) {
+  BB_TRY
+  if (!ctx || !blob || !out) throw std::runtime_error("null argument");
+  std::unique_ptr<msbb_system> s(new msbb_system());
+  s->sys = system_from_blob(*msamd::ctx_of(ctx), blob, len);
+  s->owner = ctx;
+  msamd::ctx_retain(ctx);
+  *out = s.release();
+  return MS_OK;
+  BB_CATCH
+}
+void msbb_system_destroy(msbb_system* sys) { system_unref(sys); }
+int32_t msbb_system_preprocessed_commit(const msbb_system* sys, uint32_t* out, size_t cap_words, size_t* n_digests) {
+  BB_TRY
+  if (!sys || !n_digests) throw std::runtime_error("null argument");
+  const BSystem& s = *sys->sys;
+  *n_digests = s.has_pre ? s.pre_commit.size() : 0;
+  if (*n_digests * 8 > cap_words) return MS_ERR_BUFFER;
+  for (size_t i = 0; i < *n_digests; i++)
+    for (int k = 0; k < 8; k++) out[8 * i + k] = bb_from_monty(s.pre_commit[i].w[k]);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_system_circuit_info(const msbb_system* sys, size_t circuit, uint64_t out9[9]) {
+  BB_TRY
+  if (!sys || circuit >= sys->sys->circuits.size()) throw std::runtime_error("circuit index out of range");
+  const BCircuit& c = sys->sys->circuits[circuit];
+  const uint64_t v[9] = {c.main_width,       c.pre_width,           c.pre_height,         c.num_lookups, c.stage2_width,
+                         c.constraint_count, c.max_constraint_degree, c.quotient_degree(), c.args_width};
+  for (int i = 0; i < 9; i++) out9[i] = v[i];
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_witness_create(msbb_system* sys, const uint32_t* const* traces, const uint64_t* heights, size_t n_claims,
+                            const uint64_t* claim_offsets, const uint32_t* claim_data, msbb_witness** out) {
+  BB_TRY
+  if (!sys || !traces || !heights || !out) throw std::runtime_error("null argument");
+  std::unique_ptr<msbb_witness> w(new msbb_witness());
+  w->w = witness_create(*sys->sys, traces, heights, n_claims, claim_offsets, claim_data);
+  w->owner = sys;
+  sys->refs++;
+  *out = w.release();
+  return MS_OK;
+  BB_CATCH
+}
+void msbb_witness_destroy(msbb_witness* w) {
+  if (!w) return;
+  msbb_system* s = w->owner;
+  w->w.reset();
+  delete w;
+  system_unref(s);
+}
+int32_t msbb_prove(msbb_system* sys, msbb_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms) {
+  BB_TRY
+  if (!sys || !w || !proof_len) throw std::runtime_error("null argument");
+  if (w->w->sys != sys->sys.get()) throw std::runtime_error("witness belongs to another system");
+  std::vector<uint8_t> bytes = prove(*sys->sys, *w->w, stage_ms);
+  *proof_len = bytes.size();
+  if (bytes.size() > cap || !proof_out) return MS_ERR_BUFFER;
+  memcpy(proof_out, bytes.data(), bytes.size());
+  return MS_OK;
+  BB_CATCH
+}
+
+// ---- PCS-level entry points
+int32_t msbb_set_poseidon2(ms_ctx* ctx, const uint32_t* k141) {
+  BB_TRY
+  Ctx& c = *msamd::ctx_of(ctx);
+  PermHolder& h = perm_holder();
+  for (int i = 0; i < 141; i++)
+    if (k141[i] >= BB_P) throw std::runtime_error("non-canonical round constant");
+  for (int r = 0; r < 8; r++)
+    for (int i = 0; i < 16; i++) h.host.external[r][i] = bb_to_monty(k141[16 * r + i]);
+  for (int r = 0; r < 13; r++) h.host.internal[r] = bb_to_monty(k141[128 + r]);
+  set_internal_diag(h.host);
+  if (!h.dev) HIP_CHECK(hipMalloc(&h.dev, sizeof(Poseidon2)));
+  c.h2d(h.dev, &h.host, sizeof(Poseidon2));
+  c.sync();
+  h.set = true;
+  return MS_OK;
+  BB_CATCH
+}
+static const Poseidon2* need_perm() {
+  if (!perm_holder().set) throw std::runtime_error("msbb_set_poseidon2 has not been called");
+  return perm_holder().dev;
+}
+int32_t msbb_poseidon2_permute(ms_ctx* ctx, uint32_t* states, size_t n) {
+  BB_TRY
+  Ctx& c = *msamd::ctx_of(ctx);
+  const Poseidon2* perm = need_perm();
+  if (!n) return MS_OK;
+  std::vector<u32> m(16 * n);
+  for (size_t i = 0; i < 16 * n; i++) {
+    if (states[i] >= BB_P) throw std::runtime_error("non-canonical state word");
+    m[i] = bb_to_monty(states[i]);
+  }
+  DBuf<u32> d(c, 16 * n);
+  c.h2d(d.p, m.data(), m.size() * 4);
+  bb_permute_batch(c, perm, d.p, n);
+  c.d2h(m.data(), d.p, m.size() * 4);
+  for (size_t i = 0; i < 16 * n; i++) states[i] = bb_from_monty(m[i]);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_dft_batch(ms_ctx* ctx, const uint32_t* in, size_t h, size_t w, int32_t inverse, uint32_t* out) {
+  BB_TRY
+  Ctx& c = *msamd::ctx_of(ctx);
+  if (h == 0 || (h & (h - 1))) throw std::runtime_error("height must be a power of two");
+  if (!w) return MS_OK;
+  unsigned log_h = log2_strict(h);
+  BMat m;
+  bb_upload_rows(c, in, h, w, m);
+  bb_dif(c, m.buf.p, m.ld, log_h, w);
+  std::vector<u32> rows(h * w);
+  bb_download_rows(c, m, true, rows.data());  // DIF leaves the result bit-reversed
+  if (!inverse) {
+    memcpy(out, rows.data(), rows.size() * 4);
+    return MS_OK;
+  }
+  // x[k] = X[(h - k) mod h] / h with X the forward transform
+  u32 h_inv = bb_inv(bb_to_monty((u32)(h % BB_P)));
+  for (size_t k = 0; k < h; k++)
+    for (size_t j = 0; j < w; j++) out[k * w + j] = bb_from_monty(bb_mul(bb_to_monty(rows[((h - k) & (h - 1)) * w + j]), h_inv));
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_coset_lde_batch(ms_ctx* ctx, const uint32_t* in, size_t h, size_t w, uint32_t log_blowup, uint32_t* out) {
+  BB_TRY
+  Ctx& c = *msamd::ctx_of(ctx);
+  if (h == 0 || (h & (h - 1))) throw std::runtime_error("height must be a power of two");
+  if (log2_strict(h) + log_blowup > BB_TWO_ADICITY) throw std::runtime_error("LDE taller than the two-adicity of BabyBear");
+  if (!w) return MS_OK;
+  BMat m, lde;
+  bb_upload_rows(c, in, h, w, m);
+  bb_coset_lde(c, m, log_blowup, lde);
+  bb_download_rows(c, lde, false, out);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_mmcs_commit(ms_ctx* ctx, size_t n, const uint32_t* const* mats, const uint64_t* heights, const uint64_t* widths,
+                         uint32_t cap_height, uint32_t* cap_out, msbb_mmcs** out) {
+  BB_TRY
+  Ctx& c = *msamd::ctx_of(ctx);
+  const Poseidon2* perm = need_perm();
+  std::unique_ptr<msbb_mmcs> h(new msbb_mmcs());
+  h->ctx = &c;
+  std::vector<BMat> ms(n);
+  for (size_t i = 0; i < n; i++) bb_upload_rows(c, mats[i], (size_t)heights[i], (size_t)widths[i], ms[i]);
+  bb_commit(c, perm, std::move(ms), cap_height, h->data);
+  std::vector<Digest8> cap = tree_cap(c, h->data.tree);
+  for (size_t i = 0; i < cap.size(); i++)
+    for (int k = 0; k < 8; k++) cap_out[8 * i + k] = bb_from_monty(cap[i].w[k]);
+  h->owner = ctx;
+  msamd::ctx_retain(ctx);
+  *out = h.release();
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_mmcs_open(msbb_mmcs* m, size_t index, uint32_t* vals_out, uint32_t* proof_out, size_t* n_siblings) {
+  BB_TRY
+  Ctx& c = *m->ctx;
+  const BTree& t = m->data.tree;
+  unsigned log_max = log2_strict(t.sizes[0]);
+  if (index >= t.sizes[0]) throw std::runtime_error("index out of range");
+  std::vector<GatherSeg> segs;
+  u32 pos = 0;
+  for (auto& mat : m->data.ldes) {
+    size_t row = index >> (log_max - log2_strict(mat.h));
+    segs.push_back(GatherSeg{mat.buf.p + row, pos, (u32)mat.w, (u32)mat.ld});
+    pos += (u32)mat.w;
+  }
+  u32 vals = pos;
+  size_t ch_eff = std::min<size_t>(t.cap_height, t.layers.size() - 1);
+  for (size_t i = 0; i + ch_eff < log_max; i++) {
+    segs.push_back(GatherSeg{(const u32*)(t.layers[i].p + ((index >> i) ^ 1)), pos, 8, 1});
+    pos += 8;
+  }
+  std::vector<u32> g;
+  bb_gather(c, segs, g);
+  for (u32 k = 0; k < vals; k++) vals_out[k] = bb_from_monty(g[k]);
+  for (u32 k = vals; k < pos; k++) proof_out[k - vals] = bb_from_monty(g[k]);
+  *n_siblings = log_max - ch_eff;
+  return MS_OK;
+  BB_CATCH
+}
+void msbb_mmcs_destroy(msbb_mmcs* m) {
+  if (!m) return;
+  ms_ctx* c = m->owner;
+  m->data = BPcsData();
+  delete m;
+  msamd::ctx_release(c);
+}
+int32_t msbb_field_op(ms_ctx* ctx, int32_t op, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  BB_TRY
+  if (op < 0 || op > 5) throw std::runtime_error("bad op");
+  bb_field_op(*msamd::ctx_of(ctx), op, a, b, n, out);
+  return MS_OK;
+  BB_CATCH
+}
+
+}  // extern "C"

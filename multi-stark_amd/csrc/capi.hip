@@ -77,6 +77,20 @@ void check_pow2(size_t h) {
 }
 }  // namespace
 
+// hooks for the other C-ABI translation unit (bb_prover.hip, include/mstark_bb.h): one error string, one context type
+namespace msamd {
+void set_last_error(const char* what) {
+  g_err = what;
+  (void)hipGetLastError();
+}
+Ctx* ctx_of(ms_ctx* c) {
+  if (!c) throw std::runtime_error("null context");
+  return &c->ctx;
+}
+void ctx_retain(ms_ctx* c) { c->refs++; }
+void ctx_release(ms_ctx* c) { ctx_unref(c); }
+}  // namespace msamd
+
 extern "C" {
 
 const char* ms_last_error(void) { return g_err.c_str(); }

@@ -769,7 +769,7 @@ def pack_claims(claims):
     """list of sequences (or 2-D array) -> (offsets uint64[n+1], data uint64[total])."""
     if isinstance(claims, np.ndarray) and claims.ndim == 2:
         n, w = claims.shape
-        return np.arange(0, (n + 1) * w, w, dtype=np.uint64), np.ascontiguousarray(claims, dtype=np.uint64).ravel()
+        return np.arange(0, (n + 1) * w, w, dtype=np.uint64), np.ascontiguousarray(claims.astype(np.uint64) % np.uint64(P)).ravel()
     offs = np.zeros(len(claims) + 1, dtype=np.uint64)
     for i, c in enumerate(claims):
         offs[i + 1] = offs[i] + len(c)

@@ -25,6 +25,18 @@ def test_header_symbols_are_exported(pkg):
     assert sorted(pkg.exported_symbols()) == declared
 
 
+def test_babybear_header_symbols_are_exported(pkg):
+    """include/mstark_bb.h: the reference's second configuration (BabyBear / Poseidon2)"""
+    txt = open(os.path.join(ROOT, "include", "mstark_bb.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(msbb_[a-z0-9_]+)\s*\(", txt)))
+    L = ctypes.CDLL(pkg.LIB_PATH)
+    assert len(declared) >= 15
+    for sym in declared:
+        assert hasattr(L, sym), "include/mstark_bb.h declares %s but the library does not export it" % sym
+    assert sorted(pkg.babybear.exported_symbols()) == declared
+
+
 def test_kernel_names_available_without_gpu(pkg):
     L = pkg.lib()
     n = L.ms_kernel_count()
