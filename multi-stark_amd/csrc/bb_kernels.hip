@@ -273,18 +273,133 @@ void bb_permute_batch(Ctx& ctx, const Poseidon2* d_perm, u32* d_states, size_t n
   if (n) permute_batch_k<<<blocks_for(n, 256), 256, 0, ctx.stream>>>(d_states, n, d_perm);
 }
 
+
+// ---- one permutation spread over 16 lanes (lane l holds state word l; a DPP row is exactly 16 lanes). A permutation
+// done by one lane is a dependent chain of ~10k instructions (~25 us): fine when a layer has > 10^5 nodes to overlap,
+// far too slow for the small upper layers of every tree, which are pure latency. Spread out, the chain is ~1.2k
+// instructions: the S-boxes of a full round run in parallel, M4 and the column sums are quad / row rotations.
+template <int CTRL>
+__device__ __forceinline__ u32 dppx(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+#else
+  return v;
+#endif
+}
+__device__ __forceinline__ u32 coop_mds(u32 s) {
+  u32 nxt = dppx<0x39>(s);               // quad_perm [1,2,3,0]: the next word of my 4-chunk
+  u32 t = bb_add(s, dppx<0xB1>(s));      // quad_perm [1,0,3,2]
+  u32 sum = bb_add(t, dppx<0x4E>(t));    // quad_perm [2,3,0,1]: chunk sum
+  u32 v = bb_add(bb_add(sum, s), bb_add(nxt, nxt));  // row r of M4: sum + s_r + 2 s_(r+1)
+  u32 c = bb_add(v, dppx<0x128>(v));     // row_ror:8
+  c = bb_add(c, dppx<0x124>(c));         // row_ror:4 -> sum of the four chunks' word r
+  return bb_add(v, c);
+}
+__device__ __forceinline__ u32 coop_poseidon2(const Poseidon2& k, u32 s, int l) {
+  s = coop_mds(s);
+#pragma unroll
+  for (int r = 0; r < 4; r++) s = coop_mds(bb_sbox7(bb_add(s, k.external[r][l])));
+  const u32 dg = k.diag[l];
+#pragma unroll
+  for (int r = 0; r < 13; r++) {
+    u32 x = bb_sbox7(bb_add(s, k.internal[r]));
+    s = l == 0 ? x : s;
+    u32 t = bb_add(s, dppx<0x128>(s));
+    t = bb_add(t, dppx<0x124>(t));
+    t = bb_add(t, dppx<0x122>(t));
+    t = bb_add(t, dppx<0x121>(t));  // every lane: the sum of the 16 words
+    s = bb_add(t, bb_mul(dg, s));
+  }
+#pragma unroll
+  for (int r = 4; r < 8; r++) s = coop_mds(bb_sbox7(bb_add(s, k.external[r][l])));
+  return s;
+}
+__global__ __launch_bounds__(256) void compress_coop_k(const Digest8* __restrict__ prev, size_t n_out, const Digest8* __restrict__ inject,
+                                                       const Poseidon2* __restrict__ perm, Digest8* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t node = t >> 4;
+  int l = (int)(t & 15);
+  if (node >= n_out) return;
+  u32 s = ((const u32*)prev)[node * 16 + l];  // left || right are adjacent digests
+  s = coop_poseidon2(*perm, s, l);
+  if (inject) {
+    if (l >= 8) s = inject[node].w[l - 8];
+    s = coop_poseidon2(*perm, s, l);
+  }
+  if (l < 8) out[node].w[l] = s;
+}
+__global__ __launch_bounds__(256) void leaf_hash_coop_k(const u32* const* __restrict__ cols, unsigned W, size_t rows, const Poseidon2* __restrict__ perm,
+                                                        Digest8* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t r = t >> 4;
+  int l = (int)(t & 15);
+  if (r >= rows) return;
+  u32 s = 0;
+  for (unsigned b = 0; b < W; b += 8) {
+    if (l < 8 && b + l < W) s = cols[b + l][r];
+    s = coop_poseidon2(*perm, s, l);
+  }
+  if (l < 8) out[r].w[l] = s;
+}
+__global__ __launch_bounds__(256) void leaf_hash8_coop_k(const u32* __restrict__ rows8, size_t rows, const Poseidon2* __restrict__ perm, Digest8* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t r = t >> 4;
+  int l = (int)(t & 15);
+  if (r >= rows) return;
+  u32 s = l < 8 ? rows8[r * 8 + l] : 0;
+  s = coop_poseidon2(*perm, s, l);
+  if (l < 8) out[r].w[l] = s;
+}
+// the top of a tree in one launch: levels[0] (n0 <= 128 digests) -> levels[1] -> ... -> a single digest
+struct TailArgs {
+  Digest8* level[9];
+  int n_levels;  // level[0] is the input; level[k] has n0 >> k digests
+  unsigned n0;
+};
+__global__ __launch_bounds__(1024) void tree_tail_k(TailArgs a, const Poseidon2* __restrict__ perm) {
+  const int l = threadIdx.x & 15;
+  const unsigned group = threadIdx.x >> 4;  // 64 groups
+  for (int k = 1; k < a.n_levels; k++) {
+    unsigned n_out = a.n0 >> k;
+    if (group < n_out) {  // n_out <= 64
+      u32 s = ((const u32*)a.level[k - 1])[group * 16 + l];
+      s = coop_poseidon2(*perm, s, l);
+      if (l < 8) a.level[k][group].w[l] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+static constexpr size_t COOP_MAX = size_t(1) << 15;  // below this many nodes a layer cannot hide the single-lane latency
+
 static void hash_group(Ctx& ctx, const Poseidon2* d_perm, const std::vector<const BMat*>& group, size_t rows, Digest8* out) {
   std::vector<const u32*> cols;
   for (auto m : group)
     for (size_t c = 0; c < m->w; c++) cols.push_back(m->col(c));
   DBuf<const u32*> d_cols(ctx, std::max<size_t>(cols.size(), 1));
   if (!cols.empty()) ctx.h2d(d_cols.p, cols.data(), cols.size() * sizeof(const u32*));
-  leaf_hash_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(d_cols.p, (unsigned)cols.size(), rows, d_perm, out);
-  ctx.sync();  // the column-pointer table is released with d_cols
+  if (rows <= COOP_MAX)
+    leaf_hash_coop_k<<<blocks_for(rows * 16, 256), 256, 0, ctx.stream>>>(d_cols.p, (unsigned)cols.size(), rows, d_perm, out);
+  else
+    leaf_hash_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(d_cols.p, (unsigned)cols.size(), rows, d_perm, out);
 }
 static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const std::vector<const BMat*>& order, size_t pos) {
   while (t.sizes.back() > 1) {
-    size_t nl = t.sizes.back() / 2;
+    size_t cur = t.sizes.back(), nl = cur / 2;
+    if (pos == order.size() && cur <= 128) {  // nothing left to inject: the rest of the tree in one launch
+      TailArgs a;
+      a.n0 = (unsigned)cur;
+      a.level[0] = t.layers.back().p;
+      a.n_levels = 1;
+      for (size_t n = nl; n >= 1; n /= 2) {
+        t.layers.emplace_back(ctx, n);
+        t.sizes.push_back(n);
+        a.level[a.n_levels++] = t.layers.back().p;
+        if (n == 1) break;
+      }
+      tree_tail_k<<<1, 1024, 0, ctx.stream>>>(a, d_perm);
+      break;
+    }
     std::vector<const BMat*> group;
     while (pos < order.size() && order[pos]->h == nl) group.push_back(order[pos++]);
     DBuf<Digest8> inj;
@@ -293,8 +408,10 @@ static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, cons
       hash_group(ctx, d_perm, group, nl, inj.p);
     }
     DBuf<Digest8> next(ctx, nl);
-    compress_k<<<blocks_for(nl, 256), 256, 0, ctx.stream>>>(t.layers.back().p, nl, group.empty() ? nullptr : inj.p, d_perm, next.p);
-    if (!group.empty()) ctx.sync();
+    if (nl <= COOP_MAX)
+      compress_coop_k<<<blocks_for(nl * 16, 256), 256, 0, ctx.stream>>>(t.layers.back().p, nl, group.empty() ? nullptr : inj.p, d_perm, next.p);
+    else
+      compress_k<<<blocks_for(nl, 256), 256, 0, ctx.stream>>>(t.layers.back().p, nl, group.empty() ? nullptr : inj.p, d_perm, next.p);
     t.layers.push_back(std::move(next));
     t.sizes.push_back(nl);
   }
@@ -325,7 +442,10 @@ void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t 
   t.cap_height = cap_height;
   t.layers.emplace_back(ctx, rows);
   t.sizes.push_back(rows);
-  leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
+  if (rows <= COOP_MAX)
+    leaf_hash8_coop_k<<<blocks_for(rows * 16, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
+  else
+    leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
   build_upper_layers(ctx, d_perm, t, {}, 0);
 }
 
@@ -453,14 +573,29 @@ __global__ __launch_bounds__(256) void scan_local_k(E4* __restrict__ v, size_t n
     if (base + i < n) v[base + i] = e4_add(x[i], off);
   if (threadIdx.x == 255) block_tot[blockIdx.x] = s[255];
 }
-__global__ void scan_totals_k(E4* block_tot, size_t nb, E4* total) {
-  E4 run = e4_zero();
-  for (size_t i = 0; i < nb; i++) {
-    E4 t = block_tot[i];
-    block_tot[i] = run;
-    run = e4_add(run, t);
+__global__ __launch_bounds__(1024) void scan_totals_k(E4* block_tot, size_t nb, E4* total) {
+  __shared__ E4 s[1024];
+  __shared__ E4 carry;
+  if (threadIdx.x == 0) carry = e4_zero();
+  __syncthreads();
+  for (size_t base = 0; base < nb; base += 1024) {
+    size_t i = base + threadIdx.x;
+    E4 mine = i < nb ? block_tot[i] : e4_zero();
+    s[threadIdx.x] = mine;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+      E4 t = threadIdx.x >= d ? s[threadIdx.x - d] : e4_zero();
+      __syncthreads();
+      s[threadIdx.x] = e4_add(s[threadIdx.x], t);
+      __syncthreads();
+    }
+    E4 c = carry;
+    if (i < nb) block_tot[i] = e4_add(c, e4_sub(s[threadIdx.x], mine));  // exclusive
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = e4_add(c, s[1023]);
+    __syncthreads();
   }
-  *total = run;
+  if (threadIdx.x == 0) *total = carry;
 }
 __global__ void stage2_write_k(const E4* __restrict__ v, const E4* __restrict__ block_off, size_t n_rows, unsigned L, u32* __restrict__ out, size_t ld) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,7 +626,7 @@ void bb_stage2(Ctx& ctx, const BProgram& prog, size_t prefix_len, const BLookups
   a.n = n, a.beta = beta, a.gamma = gamma, a.scratch = scratch.p, a.terms = terms.p;
   stage2_terms_k<<<blocks_for(n, 256), 256, 0, ctx.stream>>>(a);
   scan_local_k<<<(unsigned)nb, 256, 0, ctx.stream>>>(terms.p, n * L, tot.p);
-  scan_totals_k<<<1, 1, 0, ctx.stream>>>(tot.p, nb, tot.p + nb);
+  scan_totals_k<<<1, 1024, 0, ctx.stream>>>(tot.p, nb, tot.p + nb);
   stage2_write_k<<<blocks_for(n * L, 256), 256, 0, ctx.stream>>>(terms.p, tot.p, n, (unsigned)L, out.buf.p, out.ld);
   ctx.d2h(total, tot.p + nb, sizeof(E4));
 }
