@@ -17,8 +17,7 @@
  *   msbb_dft_batch / msbb_coset_lde_batch    Radix2DitParallel<BabyBear>   baby_bear_config.rs:38; src/prover.rs:350,419,650,716
  *   msbb_mmcs_*      MerkleTreeMmcs<.., PaddingFreeSponge<Perm,16,8,8>, TruncatedPermutation<Perm,2,8,16>, 2, 8>   baby_bear_config.rs:30-33
  *   msbb_poseidon2_permute   Poseidon2BabyBear<16>::permute           baby_bear_config.rs:29
- * Verification of these proofs is the reference's own System::verify_multiple_claims (src/verifier.rs) - unchanged, as
- * the north star keeps verifier.rs untouched; the product verifier of mstark.h covers the Goldilocks configuration only.
+ *   msbb_verify      System::<SC>::verify_multiple_claims             src/verifier.rs:208-532
  */
 #ifndef MSTARK_BB_H
 #define MSTARK_BB_H
@@ -49,6 +48,11 @@ void msbb_witness_destroy(msbb_witness* w);
 
 /* Writes Proof::to_bytes (src/prover.rs:241-248). stage_ms (optional, 6 doubles) as for ms_prove. */
 int32_t msbb_prove(msbb_system* sys, msbb_witness* w, uint8_t* proof_out, size_t cap, size_t* proof_len, double* stage_ms);
+
+/* System::<SC>::verify_multiple_claims (src/verifier.rs:208-532, shape checks :536-695) on the bytes msbb_prove wrote;
+ * *verdict as for ms_verify (MS_VERDICT_*). Host code. */
+int32_t msbb_verify(msbb_system* sys, size_t n_claims, const uint64_t* claim_offsets, const uint32_t* claim_data,
+                    const uint8_t* proof, size_t proof_len, int32_t* verdict);
 
 /* ---- PCS-level entry points (host buffers in and out, canonical u32) */
 /* the permutation used by msbb_poseidon2_permute / msbb_mmcs_commit: 141 canonical round constants */

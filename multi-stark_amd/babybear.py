@@ -18,7 +18,7 @@ P = frontend.BABYBEAR["P"]
 def exported_symbols():
     """Every entry point include/mstark_bb.h declares (used by the CPU-side ABI test)."""
     return ["msbb_system_create", "msbb_system_destroy", "msbb_system_preprocessed_commit", "msbb_system_circuit_info",
-            "msbb_witness_create", "msbb_witness_destroy", "msbb_prove", "msbb_set_poseidon2", "msbb_poseidon2_permute",
+            "msbb_witness_create", "msbb_witness_destroy", "msbb_prove", "msbb_verify", "msbb_set_poseidon2", "msbb_poseidon2_permute",
             "msbb_dft_batch", "msbb_coset_lde_batch", "msbb_mmcs_commit", "msbb_mmcs_open", "msbb_mmcs_destroy", "msbb_field_op"]
 
 
@@ -115,6 +115,19 @@ class System:
 
     def witness(self, traces, claims_packed):
         return Witness(self, traces, claims_packed)
+
+    def verify_multiple_claims(self, claims_packed, proof: bytes):
+        """0 = accepted, otherwise the reference's VerificationError variant (MS_VERDICT_*)"""
+        offs, data = claims_packed
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        data = np.ascontiguousarray(data, dtype=np.uint32)
+        a = np.frombuffer(proof, dtype=np.uint8) if proof else np.zeros(1, dtype=np.uint8)
+        verdict = C.c_int32()
+        _check(_lib().msbb_verify(self.h, C.c_size_t(len(offs) - 1), offs.ctypes.data_as(u64p), _p32(data), a.ctypes.data_as(u8p),
+                                  C.c_size_t(len(proof)), C.byref(verdict)))
+        return verdict.value
+
+    verify = verify_multiple_claims
 
     def prove_multiple_claims(self, witness, want_times=False):
         cap = 1 << 22

@@ -4,6 +4,7 @@
 // Poseidon2 permutations per proof); every heavy step is a launch into bb_kernels.hip. The C ABI is include/mstark_bb.h.
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <map>
 
 #include "../../include/mstark_bb.h"
@@ -809,6 +810,571 @@ std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
   return std::move(w.b);
 }
 
+
+// ------------------------------------------------------------------ verify
+// System::verify_multiple_claims (/root/reference/src/verifier.rs:208-532, shape checks :536-695) for this
+// configuration, over the bytes msbb_prove writes. All host code (a verification is a few thousand permutations);
+// written against the reference's verifier, independently of the oracle's. Codes: the VerificationError variants
+// (src/verifier.rs:176-192) as in include/mstark.h.
+namespace {
+enum : int { V_OK = 0, V_INVALID_OPENING = 2, V_INVALID_SHAPE = 3, V_INVALID_SYSTEM = 4, V_OOD_MISMATCH = 5, V_UNBALANCED = 6 };
+struct Malformed {};
+struct PReader {
+  const uint8_t* p;
+  size_t n, pos = 0;
+  void need(size_t k) const {
+    if (k > n - pos) throw Malformed();
+  }
+  uint8_t u8() {
+    need(1);
+    return p[pos++];
+  }
+  u64 u64_() {
+    need(8);
+    u64 v;
+    memcpy(&v, p + pos, 8);
+    pos += 8;
+    return v;
+  }
+  size_t count(size_t elem_bytes) {
+    u64 c = u64_();
+    if (elem_bytes && c > (n - pos) / elem_bytes) throw Malformed();
+    return (size_t)c;
+  }
+  u32 field() {  // the Montgomery word of a MontyField31; serde rejects words >= p
+    need(4);
+    u32 v;
+    memcpy(&v, p + pos, 4);
+    pos += 4;
+    if (v >= BB_P) throw Malformed();
+    return v;
+  }
+  E4 ext() {
+    E4 e;
+    for (int k = 0; k < 4; k++) e.c[k] = field();
+    return e;
+  }
+  Digest8 digest() {
+    Digest8 d;
+    for (int k = 0; k < 8; k++) d.w[k] = field();
+    return d;
+  }
+  std::vector<Digest8> cap() {
+    std::vector<Digest8> v(count(32));
+    for (auto& d : v) d = digest();
+    return v;
+  }
+};
+OpenedRound read_round(PReader& r) {
+  OpenedRound out(r.count(8));
+  for (auto& m : out) {
+    m.resize(r.count(8));
+    for (auto& pt : m) {
+      pt.resize(r.count(16));
+      for (auto& e : pt) e = r.ext();
+    }
+  }
+  return out;
+}
+struct VBatchOpening {
+  std::vector<std::vector<u32>> rows;
+  std::vector<Digest8> path;
+};
+struct VFriStep {
+  E4 sibling;
+  std::vector<Digest8> path;
+};
+struct VQuery {
+  std::vector<VBatchOpening> inputs;
+  std::vector<VFriStep> steps;
+};
+struct VProof {
+  std::vector<uint8_t> active, log_degrees;
+  std::vector<Digest8> s1, s2, q;
+  std::vector<E4> accs;
+  std::vector<std::vector<Digest8>> commits;
+  std::vector<u32> pow;
+  std::vector<VQuery> queries;
+  std::vector<E4> final_poly;
+  u32 query_pow = 0;
+  OpenedRound q_opened, pre_opened, s1_opened, s2_opened;
+  bool has_pre = false;
+};
+VProof parse_proof(const uint8_t* bytes, size_t len) {
+  PReader r{bytes, len};
+  VProof p;
+  p.active.resize(r.count(1));
+  for (auto& a : p.active) {
+    a = r.u8();
+    if (a > 1) throw Malformed();
+  }
+  p.s1 = r.cap(), p.s2 = r.cap(), p.q = r.cap();
+  p.accs.resize(r.count(16));
+  for (auto& a : p.accs) a = r.ext();
+  p.log_degrees.resize(r.count(1));
+  for (auto& l : p.log_degrees) l = r.u8();
+  p.commits.resize(r.count(8));
+  for (auto& c : p.commits) c = r.cap();
+  p.pow.resize(r.count(4));
+  for (auto& w : p.pow) w = r.field();
+  p.queries.resize(r.count(8));
+  for (auto& q : p.queries) {
+    q.inputs.resize(r.count(8));
+    for (auto& bo : q.inputs) {
+      bo.rows.resize(r.count(8));
+      for (auto& row : bo.rows) {
+        row.resize(r.count(4));
+        for (auto& v : row) v = r.field();
+      }
+      bo.path.resize(r.count(32));
+      for (auto& d : bo.path) d = r.digest();
+    }
+    q.steps.resize(r.count(8));
+    for (auto& st : q.steps) {
+      if (r.u8() != 1) throw Malformed();    // log_arity
+      if (r.u64_() != 1) throw Malformed();  // one sibling value
+      st.sibling = r.ext();
+      st.path.resize(r.count(32));
+      for (auto& d : st.path) d = r.digest();
+    }
+  }
+  p.final_poly.resize(r.count(16));
+  for (auto& e : p.final_poly) e = r.ext();
+  p.query_pow = r.field();
+  p.q_opened = read_round(r);
+  {
+    const uint8_t tag = r.u8();
+    if (tag > 1) throw Malformed();
+    p.has_pre = tag != 0;
+  }
+  if (p.has_pre) p.pre_opened = read_round(r);
+  p.s1_opened = read_round(r);
+  p.s2_opened = read_round(r);
+  if (r.pos != len) throw Malformed();
+  return p;
+}
+bool e4_is_zero(E4 a) { return !(a.c[0] | a.c[1] | a.c[2] | a.c[3]); }
+
+// PaddingFreeSponge / TruncatedPermutation on the host
+Digest8 hash_words(const Poseidon2& perm, const std::vector<u32>& v) {
+  u32 st[16] = {0};
+  for (size_t i = 0; i < v.size(); i += 8) {
+    size_t k = std::min<size_t>(8, v.size() - i);
+    for (size_t j = 0; j < k; j++) st[j] = v[i + j];
+    bb_poseidon2(perm, st);
+  }
+  Digest8 d;
+  for (int j = 0; j < 8; j++) d.w[j] = st[j];
+  return d;
+}
+Digest8 compress_host(const Poseidon2& perm, const Digest8& l, const Digest8& r) {
+  u32 st[16];
+  for (int j = 0; j < 8; j++) st[j] = l.w[j], st[8 + j] = r.w[j];
+  bb_poseidon2(perm, st);
+  Digest8 d;
+  for (int j = 0; j < 8; j++) d.w[j] = st[j];
+  return d;
+}
+struct Dim {
+  size_t w, h;
+};
+bool mmcs_verify_batch(const Poseidon2& perm, const std::vector<Digest8>& cap, const std::vector<Dim>& dims, size_t index, const VBatchOpening& o) {
+  if (dims.size() != o.rows.size() || dims.empty()) return false;
+  std::vector<size_t> order(dims.size());
+  for (size_t i = 0; i < dims.size(); i++) {
+    order[i] = i;
+    if (o.rows[i].size() != dims[i].w) return false;
+    if (dims[i].h == 0 || (dims[i].h & (dims[i].h - 1))) return false;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dims[a].h > dims[b].h; });
+  size_t pos = 0, cur = dims[order[0]].h;
+  const unsigned log_max = log2_strict(cur);
+  auto hash_group = [&](size_t height) {
+    std::vector<u32> buf;
+    while (pos < order.size() && dims[order[pos]].h == height) {
+      auto& v = o.rows[order[pos]];
+      buf.insert(buf.end(), v.begin(), v.end());
+      pos++;
+    }
+    return hash_words(perm, buf);
+  };
+  Digest8 root = hash_group(cur);
+  const size_t capn = cap.size();
+  if (capn == 0 || (capn & (capn - 1))) return false;
+  const unsigned chh = log2_strict(capn);
+  if (chh > log_max || o.path.size() != log_max - chh) return false;
+  size_t idx = index;
+  if (idx >= (size_t(1) << log_max)) return false;
+  for (auto& sib : o.path) {
+    root = (idx & 1) ? compress_host(perm, sib, root) : compress_host(perm, root, sib);
+    idx >>= 1;
+    cur >>= 1;
+    if (pos < order.size() && dims[order[pos]].h == cur) root = compress_host(perm, root, hash_group(cur));
+  }
+  if (pos != order.size()) return false;
+  return memcmp(root.w, cap[idx].w, 32) == 0;
+}
+bool check_witness(Challenger& ch, unsigned bits, u32 monty_witness) {
+  if (bits == 0) return true;
+  ch.observe(monty_witness);
+  return ch.sample_bits(bits) == 0;
+}
+struct RoundClaim {
+  std::vector<Digest8> commit;
+  std::vector<unsigned> log_n;
+  std::vector<std::vector<std::pair<E4, const std::vector<E4>*>>> mats;
+};
+// TwoAdicFriPcs::verify + verify_fri / verify_query (p3-fri 0.5.1)
+bool pcs_verify(const BSystem& sys, const std::vector<RoundClaim>& rounds, const VProof& proof, Challenger& ch) {
+  const Params& prm = sys.params;
+  const Poseidon2& perm = sys.perm;
+  const unsigned lb = (unsigned)prm.log_blowup;
+  for (auto& r : rounds)
+    for (auto& m : r.mats)
+      for (auto& pv : m)
+        for (auto& y : *pv.second) ch.observe_e4(y);
+  const E4 alpha = ch.sample_e4();
+  const size_t nrounds = proof.commits.size();
+  if (proof.pow.size() != nrounds) return false;
+  const unsigned log_gmax = (unsigned)(nrounds + lb + prm.log_final_poly_len);
+  if (log_gmax > BB_TWO_ADICITY) return false;
+  std::vector<E4> betas;
+  for (size_t i = 0; i < nrounds; i++) {
+    ch.observe_cap(proof.commits[i]);
+    if (!check_witness(ch, (unsigned)prm.commit_pow_bits, proof.pow[i])) return false;
+    betas.push_back(ch.sample_e4());
+  }
+  if (proof.final_poly.size() != (size_t(1) << prm.log_final_poly_len)) return false;
+  for (auto& c : proof.final_poly) ch.observe_e4(c);
+  if (proof.queries.size() != prm.num_queries) return false;
+  if (!check_witness(ch, (unsigned)prm.query_pow_bits, proof.query_pow)) return false;
+  const unsigned log_final_height = (unsigned)(lb + prm.log_final_poly_len);
+  const u32 g = bb_to_monty(BB_GENERATOR);
+  for (auto& qp : proof.queries) {
+    const size_t index = ch.sample_bits(log_gmax);
+    if (qp.inputs.size() != rounds.size()) return false;
+    std::map<unsigned, std::pair<E4, E4>> ro;  // log height -> (running alpha power, reduced opening)
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+      const RoundClaim& r = rounds[ri];
+      const VBatchOpening& bo = qp.inputs[ri];
+      if (bo.rows.size() != r.mats.size()) return false;
+      std::vector<Dim> dims;
+      unsigned log_bmax = 0;
+      for (size_t mi = 0; mi < r.mats.size(); mi++) {
+        dims.push_back(Dim{bo.rows[mi].size(), size_t(1) << (r.log_n[mi] + lb)});
+        log_bmax = std::max(log_bmax, r.log_n[mi] + lb);
+      }
+      if (log_bmax > log_gmax) return false;
+      if (!mmcs_verify_batch(perm, r.commit, dims, index >> (log_gmax - log_bmax), bo)) return false;
+      for (size_t mi = 0; mi < r.mats.size(); mi++) {
+        const unsigned lh = r.log_n[mi] + lb;
+        const size_t rev = bitrev_host(index >> (log_gmax - lh), lh);
+        const u32 x = bb_mul(g, bb_pow(bb_two_adic_generator(lh), rev));
+        auto it = ro.find(lh);
+        if (it == ro.end()) it = ro.emplace(lh, std::make_pair(e4_one(), e4_zero())).first;
+        for (auto& pv : r.mats[mi]) {
+          if (pv.second->size() != bo.rows[mi].size()) return false;
+          E4 den = pv.first;
+          den.c[0] = bb_sub(den.c[0], x);
+          if (e4_is_zero(den)) return false;
+          const E4 quot = e4_inv(den);
+          for (size_t c = 0; c < pv.second->size(); c++) {
+            E4 diff = (*pv.second)[c];
+            diff.c[0] = bb_sub(diff.c[0], bo.rows[mi][c]);
+            it->second.second = e4_add(it->second.second, e4_mul(e4_mul(it->second.first, diff), quot));
+            it->second.first = e4_mul(it->second.first, alpha);
+          }
+        }
+      }
+    }
+    auto low = ro.find(lb);  // a height-1 trace gives a constant polynomial: its reduced opening must vanish
+    if (low != ro.end() && log_final_height >= lb && lb < log_gmax) {
+      if (!e4_is_zero(low->second.second)) return false;
+      ro.erase(low);
+    }
+    if (qp.steps.size() != nrounds) return false;
+    auto it = ro.rbegin();
+    if (it == ro.rend() || it->first != log_gmax) return false;
+    E4 folded = it->second.second;
+    ++it;
+    size_t idx = index;
+    for (size_t i = 0; i < nrounds; i++) {
+      const unsigned log_folded_height = log_gmax - 1 - (unsigned)i;
+      const VFriStep& st = qp.steps[i];
+      const size_t sib = idx ^ 1, pair = idx >> 1;
+      E4 evals[2];
+      evals[idx % 2] = folded;
+      evals[sib % 2] = st.sibling;
+      VBatchOpening bo;
+      bo.rows.emplace_back();
+      for (int e = 0; e < 2; e++)
+        for (int k = 0; k < 4; k++) bo.rows[0].push_back(evals[e].c[k]);  // ExtensionMmcs: flattened row
+      bo.path = st.path;
+      if (!mmcs_verify_batch(perm, proof.commits[i], {Dim{8, size_t(1) << log_folded_height}}, pair, bo)) return false;
+      idx = pair;
+      // fold_row: the line through (x0, e0), (-x0, e1) evaluated at beta; x0 = w^bitrev(idx) on the subgroup
+      const u32 x0 = bb_pow(bb_two_adic_generator(log_folded_height + 1), bitrev_host(idx, log_folded_height));
+      const u32 x1 = bb_neg(x0);
+      const E4 slope = e4_mul_base(e4_sub(evals[1], evals[0]), bb_inv(bb_sub(x1, x0)));
+      E4 bx = betas[i];
+      bx.c[0] = bb_sub(bx.c[0], x0);
+      folded = e4_add(evals[0], e4_mul(bx, slope));
+      if (it != ro.rend() && it->first == log_folded_height) {
+        folded = e4_add(folded, e4_mul(e4_square(betas[i]), it->second.second));  // roll-in factor beta^2
+        ++it;
+      }
+    }
+    if (it != ro.rend()) return false;
+    const u32 x = bb_pow(bb_two_adic_generator(log_gmax), bitrev_host(idx, log_gmax));
+    E4 eval = e4_zero();
+    for (size_t k = proof.final_poly.size(); k-- > 0;) eval = e4_add(e4_mul_base(eval, x), proof.final_poly[k]);
+    if (!e4_eq(eval, folded)) return false;
+  }
+  return true;
+}
+// src/lookup.rs:103-118 over extension-valued coordinates
+void coord_mul_e(const E4* a, const E4* b, E4* out) {
+  E4 lo[4], hi[4];
+  for (int k = 0; k < 4; k++) lo[k] = hi[k] = e4_zero();
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      E4 p = e4_mul(a[i], b[j]);
+      if (i + j < 4)
+        lo[i + j] = e4_add(lo[i + j], p);
+      else
+        hi[i + j - 4] = e4_add(hi[i + j - 4], p);
+    }
+  const u32 w = bb_to_monty(BB_EXT_W);
+  for (int k = 0; k < 4; k++) out[k] = e4_add(lo[k], e4_mul_base(hi[k], w));
+}
+}  // namespace
+
+int verify(BSystem& sys, size_t n_claims, const u64* claim_offsets, const u32* claim_data, const uint8_t* proof_bytes, size_t proof_len) {
+  const Params& prm = sys.params;
+  const size_t C = sys.circuits.size();
+  if (C == 0) return V_INVALID_SYSTEM;
+  VProof proof;
+  try {
+    proof = parse_proof(proof_bytes, proof_len);
+  } catch (const Malformed&) {
+    return V_INVALID_SHAPE;
+  }
+  // ---- verify_shape (src/verifier.rs:536-695)
+  if (proof.active.size() != C) return V_INVALID_SHAPE;
+  std::vector<size_t> aidx;
+  std::vector<int> apos(C, -1);
+  for (size_t i = 0; i < C; i++)
+    if (proof.active[i]) {
+      apos[i] = (int)aidx.size();
+      aidx.push_back(i);
+    }
+  const size_t na = aidx.size();
+  if (na == 0 || proof.log_degrees.size() != na) return V_INVALID_SHAPE;
+  size_t num_pre = 0;
+  for (int pi : sys.pre_indices) num_pre += pi >= 0;
+  if (sys.has_pre != (num_pre != 0)) return V_INVALID_SYSTEM;
+  if ((proof.has_pre ? proof.pre_opened.size() : 0) != num_pre) return V_INVALID_SHAPE;
+  for (size_t ci = 0; ci < C; ci++)
+    if (sys.pre_indices[ci] >= 0 && !proof.active[ci] && proof.pre_opened[sys.pre_indices[ci]].size() != 0) return V_INVALID_SHAPE;
+  if (proof.s1_opened.size() != na || proof.s2_opened.size() != na || proof.q_opened.size() != na) return V_INVALID_SHAPE;
+  std::vector<size_t> qdeg;
+  for (size_t pos = 0; pos < na; pos++) {
+    const size_t ci = aidx[pos];
+    const BCircuit& c = sys.circuits[ci];
+    const int slot = sys.pre_indices[ci];
+    if (proof.s1_opened[pos].size() != 2 || proof.s2_opened[pos].size() != 2) return V_INVALID_SHAPE;
+    if (slot >= 0 && proof.pre_opened[slot].size() != 2) return V_INVALID_SHAPE;
+    for (int j = 0; j < 2; j++) {
+      if (slot >= 0 && proof.pre_opened[slot][j].size() != c.pre_width) return V_INVALID_SHAPE;
+      if (proof.s1_opened[pos][j].size() != c.main_width) return V_INVALID_SHAPE;
+      if (proof.s2_opened[pos][j].size() != c.stage2_width) return V_INVALID_SHAPE;
+    }
+    const size_t qd = c.quotient_degree();
+    if (proof.log_degrees[pos] + log2_strict(qd) > BB_TWO_ADICITY - prm.log_blowup) return V_INVALID_SHAPE;  // baby_bear_config.rs:87
+    if (c.pre_width && (size_t(1) << proof.log_degrees[pos]) != c.pre_height) return V_INVALID_SHAPE;
+    qdeg.push_back(qd);
+    if (proof.q_opened[pos].size() != 1 || proof.q_opened[pos][0].size() != qd * 4) return V_INVALID_SHAPE;
+  }
+  if (proof.accs.size() != na) return V_INVALID_SHAPE;
+  if (!e4_is_zero(proof.accs.back())) return V_UNBALANCED;  // src/verifier.rs:242-246
+
+  // ---- transcript replay (src/verifier.rs:255-326)
+  for (size_t i = 0; i < n_claims; i++)
+    if (claim_offsets[i + 1] < claim_offsets[i]) return V_INVALID_SHAPE;
+  const size_t claim_elems = n_claims ? (size_t)claim_offsets[n_claims] : 0;
+  for (size_t i = 0; i < claim_elems; i++)
+    if (claim_data[i] >= BB_P) return V_INVALID_SHAPE;
+  Challenger ch(&sys.perm);
+  for (u32 v : sys.seed) ch.observe(v);
+  ch.observe_usize(C);
+  for (auto& c : sys.circuits) {
+    ch.observe_usize(c.constraint_count), ch.observe_usize(c.max_constraint_degree), ch.observe_usize(c.pre_height);
+    ch.observe_usize(c.pre_width), ch.observe_usize(c.main_width), ch.observe_usize(c.stage2_width);
+  }
+  for (auto a : proof.active) ch.observe(a ? BB_R1 : 0);
+  if (sys.has_pre) ch.observe_cap(sys.pre_commit);
+  ch.observe_cap(proof.s1);
+  for (auto ld : proof.log_degrees) ch.observe_usize(ld);
+  ch.observe_usize(n_claims);
+  for (size_t i = 0; i < n_claims; i++) {
+    ch.observe_usize(claim_offsets[i + 1] - claim_offsets[i]);
+    for (u64 k = claim_offsets[i]; k < claim_offsets[i + 1]; k++) ch.observe(bb_to_monty(claim_data[k]));
+  }
+  const E4 beta = ch.sample_e4();
+  ch.observe_e4(beta);
+  const E4 gamma = ch.sample_e4();
+  ch.observe_e4(gamma);
+  ch.observe_cap(proof.s2);
+  for (auto& a : proof.accs) ch.observe_e4(a);
+  E4 acc = e4_zero();
+  for (size_t i = 0; i < n_claims; i++) {
+    E4 f = e4_zero();
+    for (u64 k = claim_offsets[i + 1]; k-- > claim_offsets[i];) {
+      f = e4_mul(f, gamma);
+      f.c[0] = bb_add(f.c[0], bb_to_monty(claim_data[k]));
+    }
+    const E4 m = e4_add(beta, f);
+    if (e4_is_zero(m)) return V_INVALID_SHAPE;  // the reference would divide by zero here
+    acc = e4_add(acc, e4_inv(m));
+  }
+  const E4 alpha = ch.sample_e4();
+  ch.observe_cap(proof.q);
+  const E4 zeta = ch.sample_e4();
+
+  std::vector<RoundClaim> rounds(3);
+  rounds[0].commit = proof.s1, rounds[1].commit = proof.s2, rounds[2].commit = proof.q;
+  for (size_t pos = 0; pos < na; pos++) {
+    const unsigned ld = proof.log_degrees[pos];
+    const E4 zn = e4_mul_base(zeta, bb_two_adic_generator(ld));
+    rounds[0].log_n.push_back(ld);
+    rounds[0].mats.push_back({{zeta, &proof.s1_opened[pos][0]}, {zn, &proof.s1_opened[pos][1]}});
+    rounds[1].log_n.push_back(ld);
+    rounds[1].mats.push_back({{zeta, &proof.s2_opened[pos][0]}, {zn, &proof.s2_opened[pos][1]}});
+    rounds[2].log_n.push_back(ld);
+    rounds[2].mats.push_back({{zeta, &proof.q_opened[pos][0]}});
+  }
+  if (sys.has_pre) {
+    RoundClaim r0;
+    r0.commit = sys.pre_commit;
+    for (size_t ci = 0; ci < C; ci++) {
+      const int slot = sys.pre_indices[ci];
+      if (slot < 0) continue;
+      if (apos[ci] >= 0) {
+        const unsigned ld = proof.log_degrees[apos[ci]];
+        const E4 zn = e4_mul_base(zeta, bb_two_adic_generator(ld));
+        r0.log_n.push_back(ld);
+        r0.mats.push_back({{zeta, &proof.pre_opened[slot][0]}, {zn, &proof.pre_opened[slot][1]}});
+      } else {
+        r0.log_n.push_back(log2_strict(sys.circuits[ci].pre_height));
+        r0.mats.push_back({});
+      }
+    }
+    rounds.push_back(std::move(r0));
+  }
+  if (!pcs_verify(sys, rounds, proof, ch)) return V_INVALID_OPENING;
+
+  // ---- out-of-domain check per circuit (src/verifier.rs:419-530)
+  for (size_t pos = 0; pos < na; pos++) {
+    const size_t ci = aidx[pos];
+    const BCircuit& c = sys.circuits[ci];
+    const unsigned ld = proof.log_degrees[pos];
+    const E4 next_acc = proof.accs[pos];
+    const u32 g_n = bb_two_adic_generator(ld), g_inv = bb_inv(g_n);
+    E4 zh = e4_exp_pow2(zeta, ld);  // selectors_at_point
+    zh.c[0] = bb_sub(zh.c[0], BB_R1);
+    E4 z1 = zeta, zg = zeta;
+    z1.c[0] = bb_sub(z1.c[0], BB_R1);
+    zg.c[0] = bb_sub(zg.c[0], g_inv);
+    if (e4_is_zero(zh) || e4_is_zero(z1) || e4_is_zero(zg)) return V_OOD_MISMATCH;
+    const E4 is_first = e4_mul(zh, e4_inv(z1)), is_last = e4_mul(zh, e4_inv(zg)), is_trans = zg, inv_van = e4_inv(zh);
+    const u32 inj_norm = bb_inv(bb_mul(bb_to_monty((u32)((u64(1) << ld) % BB_P)), g_n));
+    const E4 four[4] = {beta, gamma, acc, next_acc};
+    E4 publics[16];
+    for (int k = 0; k < 4; k++)
+      for (int d = 0; d < 4; d++) publics[4 * k + d] = e4_base(four[k].c[d]);
+    const int slot = sys.pre_indices[ci];
+    const std::vector<E4>* rows[3][2] = {{slot >= 0 ? &proof.pre_opened[slot][0] : nullptr, slot >= 0 ? &proof.pre_opened[slot][1] : nullptr},
+                                         {&proof.s1_opened[pos][0], &proof.s1_opened[pos][1]},
+                                         {&proof.s2_opened[pos][0], &proof.s2_opened[pos][1]}};
+    std::vector<E4> buf(c.nodes.size());
+    for (size_t i = 0; i < c.nodes.size(); i++) {  // ConstraintGraph::sweep_range over the extension field
+      const PNode& n = c.nodes[i];
+      E4 v;
+      switch (n.kind) {
+        case msamd::OP_CONST: v = e4_base(bb_to_monty((u32)n.a)); break;
+        case msamd::OP_VAR: {
+          if (n.source > 2 || n.offset > 1) return V_INVALID_SYSTEM;
+          const std::vector<E4>* row = rows[n.source][n.offset];
+          if (!row || n.a >= row->size()) return V_INVALID_SYSTEM;
+          v = (*row)[n.a];
+          break;
+        }
+        case msamd::OP_PUBLIC:
+          if (n.a >= 16) return V_INVALID_SYSTEM;
+          v = publics[n.a];
+          break;
+        case msamd::OP_IS_FIRST: v = is_first; break;
+        case msamd::OP_IS_LAST: v = is_last; break;
+        case msamd::OP_IS_TRANS: v = is_trans; break;
+        case msamd::OP_ADD: v = e4_add(buf[n.a], buf[n.b]); break;
+        case msamd::OP_SUB: v = e4_sub(buf[n.a], buf[n.b]); break;
+        case msamd::OP_MUL: v = e4_mul(buf[n.a], buf[n.b]); break;
+        default: v = e4_neg(buf[n.a]); break;
+      }
+      buf[i] = v;
+    }
+    std::vector<E4> cv;
+    for (auto z : c.zeros) cv.push_back(buf[z]);
+    // logup_constraint_values, generic-degree path (src/lookup.rs:210-256)
+    const std::vector<E4>&s2 = proof.s2_opened[pos][0], &s2n = proof.s2_opened[pos][1];
+    E4 inj[4];
+    for (int d = 0; d < 4; d++) inj[d] = e4_mul(is_last, e4_mul_base(e4_sub(publics[12 + d], publics[8 + d]), inj_norm));
+    if (c.lookups.empty()) {
+      for (int d = 0; d < 4; d++) cv.push_back(e4_add(e4_sub(s2n[d], s2[d]), inj[d]));
+    } else {
+      const size_t last = c.lookups.size() - 1;
+      for (size_t j = 0; j < c.lookups.size(); j++) {
+        const auto& l = c.lookups[j];
+        E4 diff[4], f[4], t[4];
+        for (int d = 0; d < 4; d++) {
+          const E4 tgt = j < last ? s2[4 * (j + 1) + d] : e4_add(s2n[d], inj[d]);
+          diff[d] = e4_sub(tgt, s2[4 * j + d]);
+          f[d] = e4_zero();
+        }
+        for (size_t k = l.second.size(); k-- > 0;) {
+          coord_mul_e(f, publics + 4, t);
+          for (int d = 0; d < 4; d++) f[d] = t[d];
+          f[0] = e4_add(f[0], buf[l.second[k]]);
+        }
+        for (int d = 0; d < 4; d++) f[d] = e4_add(f[d], publics[d]);
+        coord_mul_e(f, diff, t);
+        cv.push_back(e4_sub(t[0], buf[l.first]));
+        for (int d = 1; d < 4; d++) cv.push_back(t[d]);
+      }
+    }
+    if (cv.size() != c.constraint_count) return V_INVALID_SYSTEM;
+    E4 comp = e4_zero();
+    for (auto& x : cv) comp = e4_add(e4_mul(comp, alpha), x);
+    // Q(zeta) = sum_i zeta^(i n) c_i(zeta), each chunk given by its four base-field coordinate polynomials
+    const std::vector<E4>& qrow = proof.q_opened[pos][0];
+    const E4 zpn = e4_exp_pow2(zeta, ld);
+    E4 zp = e4_one(), quot = e4_zero();
+    for (size_t i = 0; i < qdeg[pos]; i++) {
+      E4 chunk = e4_zero();
+      for (int d = 0; d < 4; d++) {
+        E4 basis = e4_zero();
+        basis.c[d] = BB_R1;  // X^d
+        chunk = e4_add(chunk, e4_mul(qrow[4 * i + d], basis));
+      }
+      quot = e4_add(quot, e4_mul(zp, chunk));
+      zp = e4_mul(zp, zpn);
+    }
+    if (!e4_eq(e4_mul(comp, inv_van), quot)) return V_OOD_MISMATCH;
+    acc = next_acc;
+  }
+  return V_OK;
+}
+
 }  // namespace msbb
 
 // ------------------------------------------------------------------ C ABI (include/mstark_bb.h)
@@ -928,6 +1494,16 @@ int32_t msbb_prove(msbb_system* sys, msbb_witness* w, uint8_t* proof_out, size_t
   *proof_len = bytes.size();
   if (bytes.size() > cap || !proof_out) return MS_ERR_BUFFER;
   memcpy(proof_out, bytes.data(), bytes.size());
+  return MS_OK;
+  BB_CATCH
+}
+
+int32_t msbb_verify(msbb_system* sys, size_t n_claims, const uint64_t* claim_offsets, const uint32_t* claim_data, const uint8_t* proof,
+                    size_t proof_len, int32_t* verdict) {
+  BB_TRY
+  if (!sys || !verdict || (!proof && proof_len) || (n_claims && (!claim_offsets || !claim_data))) throw std::runtime_error("null argument");
+  static const uint64_t zero = 0;
+  *verdict = verify(*sys->sys, n_claims, n_claims ? claim_offsets : &zero, claim_data, proof, proof_len);
   return MS_OK;
   BB_CATCH
 }

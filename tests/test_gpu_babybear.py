@@ -106,7 +106,9 @@ def _prove_both(ctx, params, inputs, traces, claims):
     want = o.prove(traces, packed)
     assert len(got) == len(want)
     assert got == want, "proof bytes differ at byte %d" % next(i for i in range(len(got)) if got[i] != want[i])
-    return o.verify(packed, got), g, o, packed, got
+    verdict = o.verify(packed, got)
+    assert g.verify(packed, got) == verdict, "product verifier (msbb_verify) disagrees with the oracle's"
+    return verdict, g, o, packed, got
 
 
 def test_reference_smoke_test(ctx):
@@ -148,6 +150,36 @@ def test_preprocessed_and_mixed_heights(ctx):
         traces, claims = fe.u32_add_bench_witness(1 << 9)
         assert _prove_both(ctx, fe.Params(2, 0, 0, 1, 20, 2, 2), inputs, traces, claims)[0] == 0
         assert _prove_both(ctx, fe.Params(2, 1, 1, 1, 10, 0, 0), fe.squares_inputs(), fe.squares_traces(16), [])[0] == 0
+
+
+def test_product_verifier_agrees_with_oracle_on_corrupted_proofs(ctx):
+    """msbb_verify vs the oracle's verifier: bit flips, truncation, extension, swapped claims - same accept / reject"""
+    with fe.field(fe.BABYBEAR):
+        inputs, traces = fe.even_odd_inputs(), fe.even_odd_traces()
+        g = bb.System.new(ctx, fe.Params(2, 1, 1, 1, 9, 3, 4), inputs, K)
+        o = ob.System(g.blob)
+        packed = fe.pack_claims([[0, 4, 1]])
+    proof = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    assert g.verify(packed, proof) == 0 and o.verify(packed, proof) == 0
+    rng = np.random.default_rng(8)
+    for k in range(300):
+        bad = bytearray(proof)
+        kind = k % 4
+        if kind == 0:
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            pos = int(rng.integers(0, len(bad) - 8))
+            bad[pos:pos + 8] = int(rng.choice([0, 1, 0xFFFFFFFF, 1 << 40])).to_bytes(8, "little")
+        elif kind == 2:
+            bad = bad[: int(rng.integers(0, len(bad)))]
+        else:
+            bad += bytes(int(x) for x in rng.integers(0, 256, 5))
+        a, b = g.verify(packed, bytes(bad)), o.verify(packed, bytes(bad))
+        assert a != 0 and (a == 0) == (b == 0), (k, a, b)
+    with fe.field(fe.BABYBEAR):
+        for claims in ([[0, 4, 0]], [], [[0, 4, 1], [0, 4, 1]]):
+            pc = fe.pack_claims(claims)
+            assert g.verify(pc, proof) != 0 and o.verify(pc, proof) != 0
 
 
 def test_error_paths(ctx):
