@@ -36,6 +36,7 @@ def main():
         for k, v in p.stage_ms.items():
             stages[k] = stages.get(k, 0.0) + v / steps
     ms = (time.perf_counter() - t0) * 1e3 / steps
+    assert g.verify(packed, proof.to_bytes()) == 0, "the library's own verifier rejects the proof"
     rec = {"workload": "config 4: MulAir 2^%d rows, BabyBear/Ext4/Poseidon2, blowup 2, 64 queries" % log_rows, "ms_per_proof": round(ms, 3),
            "trace_rows_per_s": round((1 << log_rows) / ms * 1e3), "proof_bytes": len(proof.to_bytes()),
            "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
