@@ -26,6 +26,8 @@
  *   ms_claims_accumulator   the claims loop                     src/prover.rs:382-387
  *   ms_quotient_values      quotient_values(+_inner)            src/prover.rs:756-962 (sweep: src/eval.rs:67-106;
  *                                                               logUp: src/lookup.rs:152-256)
+ *   ms_pcs_commit / ms_pcs_open / ms_pcs_verify / ms_challenger_*   Pcs::commit / open / verify with the transcript as a handle
+ *                                                               src/prover.rs:350,419,580; examples/pcs_example.rs:64-121
  *   ms_blake3      Blake3 as used by the challenger             src/types.rs:28-29 (HashChallenger<u8,Blake3,32>)
  */
 #ifndef MSTARK_H
@@ -154,6 +156,34 @@ int32_t ms_mmcs_commit(ms_ctx* ctx, size_t n, const uint64_t* const* mats, const
 int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proof_out, size_t* n_siblings);
 void ms_mmcs_destroy(ms_mmcs* m);
 int32_t ms_blake3(ms_ctx* ctx, const uint8_t* bytes, size_t len, uint8_t out32[32]);
+
+/* ---- Pcs::commit / Pcs::open / Pcs::verify on their own (examples/pcs_example.rs:64-121; the calls of src/prover.rs:350,419,580
+ * for a host that keeps its own prover loop). The transcript is a handle: ms_challenger_create(params7) is
+ * config.initialise_challenger() (src/types.rs:118-130) for the seven parameter words [log_blowup, cap_height,
+ * log_final_poly_len, max_log_arity, num_queries, commit_proof_of_work_bits, query_proof_of_work_bits].
+ * ms_pcs_commit: evaluations over the natural domains (row-major, heights[i] x widths[i]) -> coset LDE + Merkle tree, all
+ * kept on the device behind ms_mmcs. ms_pcs_open: one ms_mmcs per round; n_points has one entry per matrix (rounds
+ * flattened, at most two points per matrix), points holds (c0, c1) per point; opened values are written in
+ * round -> matrix -> point -> column order (2 words each); fri_out receives the FriProof (the opening_proof field of
+ * Proof::to_bytes); MS_ERR_BUFFER with *fri_len = needed size if a capacity is too small (the challenger has then been
+ * advanced: restart from a fresh one). ms_pcs_verify: the same rounds described by their caps (32-byte digests), log2 domain
+ * sizes and widths; *accepted = 1 / 0. */
+typedef struct ms_challenger ms_challenger;
+int32_t ms_challenger_create(const uint64_t params7[7], ms_challenger** out);
+void ms_challenger_destroy(ms_challenger* ch);
+int32_t ms_challenger_observe(ms_challenger* ch, const uint64_t* elems, size_t n);
+int32_t ms_challenger_observe_digests(ms_challenger* ch, const uint8_t* digests, size_t n);
+int32_t ms_challenger_sample_ext(ms_challenger* ch, uint64_t out2[2]);
+int32_t ms_challenger_sample_bits(ms_challenger* ch, uint32_t bits, uint64_t* out);
+int32_t ms_pcs_commit(ms_ctx* ctx, uint32_t log_blowup, uint32_t cap_height, size_t n, const uint64_t* const* evals,
+                      const uint64_t* heights, const uint64_t* widths, uint8_t* cap_out, ms_mmcs** out);
+int32_t ms_pcs_open(ms_ctx* ctx, const uint64_t params7[7], size_t n_rounds, ms_mmcs* const* rounds, const uint64_t* n_points,
+                    const uint64_t* points, ms_challenger* ch, uint64_t* opened_out, size_t opened_cap_words, uint8_t* fri_out,
+                    size_t fri_cap, size_t* fri_len);
+int32_t ms_pcs_verify(const uint64_t params7[7], size_t n_rounds, const uint8_t* const* caps, const uint64_t* cap_sizes,
+                      const uint64_t* n_mats, const uint64_t* log_n, const uint64_t* widths, const uint64_t* n_points,
+                      const uint64_t* points, const uint64_t* opened, const uint8_t* fri, size_t fri_len, ms_challenger* ch,
+                      int32_t* accepted);
 
 /* ---- in-tree kernels of the reference */
 int32_t ms_stage2_trace(ms_ctx* ctx, size_t height, size_t num_lookups, const uint64_t* mult,

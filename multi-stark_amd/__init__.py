@@ -45,7 +45,9 @@ def exported_symbols():
             "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
-            "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_stage2_trace", "ms_claims_accumulator",
+            "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_pcs_commit", "ms_pcs_open", "ms_pcs_verify", "ms_challenger_create",
+            "ms_challenger_destroy", "ms_challenger_observe", "ms_challenger_observe_digests", "ms_challenger_sample_ext",
+            "ms_challenger_sample_bits", "ms_stage2_trace", "ms_claims_accumulator",
             "ms_quotient_values", "ms_field_op"]
 
 
@@ -194,6 +196,100 @@ class Mmcs:
         if getattr(self, "h", None):
             lib().ms_mmcs_destroy(self.h)
             self.h = None
+
+
+class PcsCommitment(Mmcs):
+    """Pcs::commit (examples/pcs_example.rs:64-69): evaluations over the natural domains -> coset LDE + Merkle tree on the device."""
+
+    def __init__(self, ctx, evals, log_blowup, cap_height=0):
+        self.ctx = ctx
+        self.mats = [_u64(m) for m in evals]
+        n = len(self.mats)
+        ptrs = (u64p * n)(*[_p(m) for m in self.mats])
+        hs = _u64([m.shape[0] for m in self.mats])
+        ws = _u64([m.shape[1] for m in self.mats])
+        maxh = int(hs.max()) << log_blowup
+        cap = np.zeros(32 * min(1 << cap_height, maxh), dtype=np.uint8)
+        self.h = C.c_void_p()
+        _check(lib().ms_pcs_commit(ctx.h, C.c_uint32(log_blowup), C.c_uint32(cap_height), C.c_size_t(n), ptrs, _p(hs), _p(ws), _b(cap),
+                                   C.byref(self.h)))
+        self.cap = cap.tobytes()
+        self.log_max = maxh.bit_length() - 1
+        self.widths = ws
+        self.log_n = [int(h).bit_length() - 1 for h in hs]
+
+
+class Challenger:
+    """config.initialise_challenger() as a handle (ms_challenger): src/types.rs:28-81,118-130"""
+
+    def __init__(self, params):
+        self.h = C.c_void_p()
+        _check(lib().ms_challenger_create(_p(_u64(params.words())), C.byref(self.h)))
+
+    def observe(self, elems):
+        e = _u64(np.atleast_1d(elems))
+        _check(lib().ms_challenger_observe(self.h, _p(e), C.c_size_t(e.size)))
+
+    def observe_digests(self, cap: bytes):
+        a = np.frombuffer(cap, dtype=np.uint8)
+        _check(lib().ms_challenger_observe_digests(self.h, _b(a), C.c_size_t(len(cap) // 32)))
+
+    def sample_ext(self):
+        o = np.zeros(2, dtype=np.uint64)
+        _check(lib().ms_challenger_sample_ext(self.h, _p(o)))
+        return int(o[0]), int(o[1])
+
+    def sample_bits(self, bits):
+        o = C.c_uint64()
+        _check(lib().ms_challenger_sample_bits(self.h, C.c_uint32(bits), C.byref(o)))
+        return o.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ms_challenger_destroy(self.h)
+            self.h = None
+
+
+def _flatten_points(per_round):
+    n_points, pts = [], []
+    for per_matrix in per_round:
+        for plist in per_matrix:
+            n_points.append(len(plist))
+            for z in plist:
+                pts.extend(int(x) for x in z)
+    return _u64(n_points), _u64(pts if pts else [0])
+
+
+def pcs_open(ctx, params, rounds, challenger):
+    """Pcs::open (src/prover.rs:580). rounds: [(PcsCommitment | Mmcs, [[(c0, c1), ..] per matrix])].
+    Returns (opened values flat, round -> matrix -> point -> column, 2 words each; FriProof bytes)."""
+    n_points, pts = _flatten_points([per for _, per in rounds])
+    handles = (C.c_void_p * len(rounds))(*[m.h for m, _ in rounds])
+    total = sum(len(plist) * int(m.widths[i]) for m, per in rounds for i, plist in enumerate(per))
+    opened = np.zeros(max(total, 1) * 2, dtype=np.uint64)
+    cap = 1 << 22
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t()
+    _check(lib().ms_pcs_open(ctx.h, _p(_u64(params.words())), C.c_size_t(len(rounds)), handles, _p(n_points), _p(pts), challenger.h, _p(opened),
+                             C.c_size_t(opened.size), _b(out), C.c_size_t(cap), C.byref(n)))
+    return opened[: total * 2].copy(), out[: n.value].tobytes()
+
+
+def pcs_verify(params, rounds, opened, fri: bytes, challenger):
+    """Pcs::verify. rounds: [(cap bytes, [(log_n, width)] per matrix, [[point, ..] per matrix])]; True = accepted"""
+    caps = [np.frombuffer(c, dtype=np.uint8) for c, _, _ in rounds]
+    cap_ptrs = (u8p * len(rounds))(*[_b(c) for c in caps])
+    cap_sizes = _u64([len(c) // 32 for c, _, _ in rounds])
+    n_mats = _u64([len(d) for _, d, _ in rounds])
+    log_n = _u64([ln for _, d, _ in rounds for ln, _w in d])
+    widths = _u64([w for _, d, _ in rounds for _ln, w in d])
+    n_points, pts = _flatten_points([per for _, _, per in rounds])
+    f = np.frombuffer(fri, dtype=np.uint8) if fri else np.zeros(1, dtype=np.uint8)
+    op = _u64(opened) if len(opened) else np.zeros(1, dtype=np.uint64)
+    ok = C.c_int32()
+    _check(lib().ms_pcs_verify(_p(_u64(params.words())), C.c_size_t(len(rounds)), cap_ptrs, _p(cap_sizes), _p(n_mats), _p(log_n), _p(widths),
+                               _p(n_points), _p(pts), _p(op), _b(f), C.c_size_t(len(fri)), challenger.h, C.byref(ok)))
+    return ok.value == 1
 
 
 class Proof:

@@ -303,6 +303,151 @@ int32_t ms_mmcs_commit(ms_ctx* c, size_t n, const uint64_t* const* mats, const u
   MS_CATCH
 }
 
+// ---- Pcs::commit / Pcs::open / Pcs::verify on their own, with the challenger as a handle
+int32_t ms_pcs_commit(ms_ctx* c, uint32_t log_blowup, uint32_t cap_height, size_t n, const uint64_t* const* evals, const uint64_t* heights,
+                      const uint64_t* widths, uint8_t* cap_out, ms_mmcs** out) {
+  *out = nullptr;
+  MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  if (log_blowup < 1 || log_blowup > 8) throw std::runtime_error("log_blowup out of range");
+  std::unique_ptr<ms_mmcs> m(new ms_mmcs());
+  m->ctx = &ctx;
+  std::vector<DMat> ms;
+  for (size_t i = 0; i < n; i++) {
+    check_pow2(heights[i]);
+    unsigned logn = log2_strict(heights[i]);
+    if (logn > NTT_MAX_LOG || logn + log_blowup > TW_LOG) throw std::runtime_error("matrix too tall");
+    DBuf<u64> col = upload_colmajor(ctx, evals[i], heights[i], widths[i], true);
+    DMat dm;
+    dm.h = (size_t)heights[i] << log_blowup;
+    dm.w = widths[i];
+    dm.buf = DBuf<u64>(ctx, dm.h * dm.w);
+    if (dm.w) coset_lde(ctx, col.p, dm.buf.p, logn, log_blowup, dm.w);
+    ctx.sync();
+    ms.push_back(std::move(dm));
+  }
+  commit_matrices(ctx, std::move(ms), cap_height, m->data);
+  std::vector<Digest> cap = merkle_cap(ctx, m->data.tree);
+  for (size_t i = 0; i < cap.size(); i++) memcpy(cap_out + 32 * i, cap[i].b, 32);
+  m->owner = c;
+  c->refs++;
+  *out = m.release();
+  return MS_OK;
+  MS_CATCH
+}
+
+static Params params_from7(const uint64_t* p7) {
+  Params p;
+  p.log_blowup = p7[0], p.cap_height = p7[1], p.log_final_poly_len = p7[2], p.max_log_arity = p7[3], p.num_queries = p7[4];
+  p.commit_pow_bits = p7[5], p.query_pow_bits = p7[6];
+  return p;
+}
+struct ms_challenger {
+  Challenger ch;
+  explicit ms_challenger(const std::vector<uint8_t>& seed) : ch(seed) {}
+};
+int32_t ms_challenger_create(const uint64_t params7[7], ms_challenger** out) {
+  MS_TRY const char* tag = "multi-stark/v0";  // src/types.rs:118-130
+  std::vector<uint8_t> seed(tag, tag + 14);
+  for (int i = 0; i < 7; i++)
+    for (int k = 0; k < 8; k++) seed.push_back((uint8_t)(params7[i] >> (8 * k)));
+  *out = new ms_challenger(seed);
+  return MS_OK;
+  MS_CATCH
+}
+void ms_challenger_destroy(ms_challenger* ch) { delete ch; }
+int32_t ms_challenger_observe(ms_challenger* ch, const uint64_t* elems, size_t n) {
+  MS_TRY for (size_t i = 0; i < n; i++) {
+    if (elems[i] >= GL_P) throw std::runtime_error("non-canonical field element");
+    ch->ch.observe(elems[i]);
+  }
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_challenger_observe_digests(ms_challenger* ch, const uint8_t* digests, size_t n) {
+  MS_TRY ch->ch.observe_bytes(digests, 32 * n);
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_challenger_sample_ext(ms_challenger* ch, uint64_t out2[2]) {
+  MS_TRY E2 e = ch->ch.sample_ext();
+  out2[0] = e.c0, out2[1] = e.c1;
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_challenger_sample_bits(ms_challenger* ch, uint32_t bits, uint64_t* out) {
+  MS_TRY if (bits > 63) throw std::runtime_error("too many bits");
+  *out = ch->ch.sample_bits(bits);
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_pcs_open(ms_ctx* c, const uint64_t params7[7], size_t n_rounds, ms_mmcs* const* rounds, const uint64_t* n_points, const uint64_t* points,
+                    ms_challenger* ch, uint64_t* opened_out, size_t opened_cap_words, uint8_t* fri_out, size_t fri_cap, size_t* fri_len) {
+  MS_TRY Ctx& ctx = c->ctx;
+  std::vector<PcsData*> data;
+  std::vector<std::vector<std::vector<E2>>> pts(n_rounds);
+  size_t mk = 0, pk = 0;
+  for (size_t r = 0; r < n_rounds; r++) {
+    if (rounds[r]->ctx != &ctx) throw std::runtime_error("commitment belongs to another context");
+    data.push_back(&rounds[r]->data);
+    for (size_t m = 0; m < rounds[r]->data.ldes.size(); m++) {
+      std::vector<E2> pl;
+      for (uint64_t k = 0; k < n_points[mk]; k++) {
+        if (points[2 * pk] >= GL_P || points[2 * pk + 1] >= GL_P) throw std::runtime_error("non-canonical opening point");
+        pl.push_back(E2{points[2 * pk], points[2 * pk + 1]});
+        pk++;
+      }
+      mk++;
+      pts[r].push_back(std::move(pl));
+    }
+  }
+  std::vector<E2> opened;
+  std::vector<uint8_t> fri;
+  pcs_open_standalone(ctx, params_from7(params7), data, pts, ch->ch, opened, fri);
+  *fri_len = fri.size();
+  if (opened.size() * 2 > opened_cap_words || fri.size() > fri_cap) return MS_ERR_BUFFER;
+  for (size_t i = 0; i < opened.size(); i++) opened_out[2 * i] = opened[i].c0, opened_out[2 * i + 1] = opened[i].c1;
+  memcpy(fri_out, fri.data(), fri.size());
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_pcs_verify(const uint64_t params7[7], size_t n_rounds, const uint8_t* const* caps, const uint64_t* cap_sizes, const uint64_t* n_mats,
+                      const uint64_t* log_n, const uint64_t* widths, const uint64_t* n_points, const uint64_t* points, const uint64_t* opened,
+                      const uint8_t* fri, size_t fri_len, ms_challenger* ch, int32_t* accepted) {
+  MS_TRY std::vector<std::vector<Digest>> commits(n_rounds);
+  std::vector<std::vector<unsigned>> ln(n_rounds);
+  std::vector<std::vector<size_t>> ws(n_rounds);
+  std::vector<std::vector<std::vector<E2>>> pts(n_rounds);
+  size_t mk = 0, pk = 0, total = 0;
+  *accepted = 0;
+  for (size_t r = 0; r < n_rounds; r++) {
+    commits[r].resize(cap_sizes[r]);
+    for (size_t i = 0; i < cap_sizes[r]; i++) memcpy(commits[r][i].b, caps[r] + 32 * i, 32);
+    for (uint64_t m = 0; m < n_mats[r]; m++) {
+      if (log_n[mk] > 40) return MS_OK;
+      ln[r].push_back((unsigned)log_n[mk]);
+      ws[r].push_back((size_t)widths[mk]);
+      std::vector<E2> pl;
+      for (uint64_t k = 0; k < n_points[mk]; k++) {
+        if (points[2 * pk] >= GL_P || points[2 * pk + 1] >= GL_P) return MS_OK;
+        pl.push_back(E2{points[2 * pk], points[2 * pk + 1]});
+        pk++;
+      }
+      total += pl.size() * widths[mk];
+      mk++;
+      pts[r].push_back(std::move(pl));
+    }
+  }
+  std::vector<E2> vals(total);
+  for (size_t i = 0; i < total; i++) {
+    if (opened[2 * i] >= GL_P || opened[2 * i + 1] >= GL_P) return MS_OK;
+    vals[i] = E2{opened[2 * i], opened[2 * i + 1]};
+  }
+  *accepted = pcs_verify_standalone(params_from7(params7), commits, ln, ws, pts, vals, fri, fri_len, ch->ch) ? 1 : 0;
+  return MS_OK;
+  MS_CATCH
+}
+
 int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proof_out, size_t* n_siblings) {
   MS_TRY Ctx& ctx = *m->ctx;
   const DTree& t = m->data.tree;

@@ -120,6 +120,13 @@ std::vector<uint8_t> prove_sharded(HSystem& sys, HWitness& w, const ms_comm_t* c
 // System::verify_multiple_claims (verifier.hip): 0 = accepted, otherwise the VerificationError code of include/mstark.h
 int verify(HSystem& sys, size_t n_claims, const u64* claim_offsets, const u64* claim_data, const uint8_t* proof, size_t proof_len);
 
+// Pcs::open / Pcs::verify on their own (prover.hip, verifier.hip)
+void pcs_open_standalone(Ctx& ctx, const Params& prm, const std::vector<PcsData*>& data, const std::vector<std::vector<std::vector<E2>>>& points,
+                         Challenger& ch, std::vector<E2>& opened_flat, std::vector<uint8_t>& fri_bytes);
+bool pcs_verify_standalone(const Params& prm, const std::vector<std::vector<Digest>>& commits, const std::vector<std::vector<unsigned>>& log_n,
+                           const std::vector<std::vector<size_t>>& widths, const std::vector<std::vector<std::vector<E2>>>& points,
+                           const std::vector<E2>& opened_flat, const uint8_t* fri, size_t fri_len, Challenger& ch);
+
 void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out);
 void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out);
 

@@ -1301,4 +1301,32 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
 #include "prover_sharded.inc"
 
+// Pcs::open on its own (src/prover.rs:580; examples/pcs_example.rs:88-95): the same code path as inside prove()
+void pcs_open_standalone(Ctx& ctx, const Params& prm, const std::vector<PcsData*>& data, const std::vector<std::vector<std::vector<E2>>>& points,
+                         Challenger& ch, std::vector<E2>& opened_flat, std::vector<uint8_t>& fri_bytes) {
+  HIP_CHECK(hipSetDevice(ctx.device));
+  HSystem sys;  // carries the context and the parameters only
+  sys.ctx = &ctx;
+  sys.params = prm;
+  if (prm.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 (binary folding) is supported");
+  if (prm.log_blowup < 1 || prm.log_blowup > 8) throw std::runtime_error("log_blowup out of range");
+  if (prm.commit_pow_bits > 40 || prm.query_pow_bits > 40) throw std::runtime_error("proof-of-work bits out of range");
+  std::vector<OpenRound> rounds;
+  for (size_t r = 0; r < data.size(); r++) {
+    if (points[r].size() != data[r]->ldes.size()) throw std::runtime_error("pcs_open: one list of points per matrix expected");
+    for (auto& m : data[r]->ldes)
+      if (log2_strict(m.h) < prm.log_blowup) throw std::runtime_error("pcs_open: a committed matrix is shorter than the blowup");
+    rounds.push_back(OpenRound{data[r], points[r]});
+  }
+  std::vector<OpenedRound> opened;
+  PW fri;
+  pcs_open(sys, rounds, ch, opened, fri);
+  opened_flat.clear();
+  for (auto& orr : opened)
+    for (auto& m : orr)
+      for (auto& pt : m) opened_flat.insert(opened_flat.end(), pt.begin(), pt.end());
+  fri_bytes = std::move(fri.b);
+  ctx.sync();
+}
+
 }  // namespace msamd

@@ -112,22 +112,7 @@ struct ProofV {
   bool has_pre = false;
 };
 
-ProofV parse(const uint8_t* bytes, size_t len) {
-  Reader r{bytes, len};
-  ProofV p;
-  p.active.resize(r.count(1));
-  for (auto& a : p.active) {
-    a = r.u8();
-    if (a > 1) throw Malformed();  // bincode decodes a bool from 0 or 1 only
-  }
-  p.s1 = r.cap();
-  p.s2 = r.cap();
-  p.q = r.cap();
-  p.accs.resize(r.count(16));
-  for (auto& a : p.accs) a = r.ext();
-  p.log_degrees.resize(r.count(1));
-  for (auto& l : p.log_degrees) l = r.u8();
-  FriProofV& f = p.fri;
+void parse_fri(Reader& r, FriProofV& f) {
   f.commits.resize(r.count(8));
   for (auto& c : f.commits) c = r.cap();
   f.pow.resize(r.count(8));
@@ -156,6 +141,24 @@ ProofV parse(const uint8_t* bytes, size_t len) {
   f.final_poly.resize(r.count(16));
   for (auto& e : f.final_poly) e = r.ext();
   f.query_pow = r.u64_();
+}
+
+ProofV parse(const uint8_t* bytes, size_t len) {
+  Reader r{bytes, len};
+  ProofV p;
+  p.active.resize(r.count(1));
+  for (auto& a : p.active) {
+    a = r.u8();
+    if (a > 1) throw Malformed();  // bincode decodes a bool from 0 or 1 only
+  }
+  p.s1 = r.cap();
+  p.s2 = r.cap();
+  p.q = r.cap();
+  p.accs.resize(r.count(16));
+  for (auto& a : p.accs) a = r.ext();
+  p.log_degrees.resize(r.count(1));
+  for (auto& l : p.log_degrees) l = r.u8();
+  parse_fri(r, p.fri);
   p.q_opened = read_round(r);
   {
     const uint8_t tag = r.u8();  // Option tag
@@ -344,6 +347,45 @@ void mul2e(E2 a0, E2 a1, E2 b0, E2 b1, E2& c0, E2& c1) {
 }
 
 }  // namespace
+
+// Pcs::verify on its own (examples/pcs_example.rs:111-121): rounds given as commitments, domain sizes, points and the
+// claimed values (flat: round -> matrix -> point -> column)
+bool pcs_verify_standalone(const Params& prm, const std::vector<std::vector<Digest>>& commits, const std::vector<std::vector<unsigned>>& log_n,
+                           const std::vector<std::vector<size_t>>& widths, const std::vector<std::vector<std::vector<E2>>>& points,
+                           const std::vector<E2>& opened_flat, const uint8_t* fri, size_t fri_len, Challenger& ch) {
+  if (prm.max_log_arity != 1 || prm.log_blowup < 1 || prm.log_blowup > 8) return false;
+  FriProofV proof;
+  try {
+    Reader r{fri, fri_len};
+    parse_fri(r, proof);
+    if (r.pos != fri_len) return false;
+  } catch (const Malformed&) {
+    return false;
+  }
+  std::vector<std::vector<std::vector<std::vector<E2>>>> vals(commits.size());  // round -> matrix -> point -> values
+  size_t k = 0;
+  for (size_t r = 0; r < commits.size(); r++) {
+    vals[r].resize(points[r].size());
+    for (size_t m = 0; m < points[r].size(); m++)
+      for (size_t p = 0; p < points[r][m].size(); p++) {
+        if (k + widths[r][m] > opened_flat.size()) return false;
+        vals[r][m].emplace_back(opened_flat.begin() + k, opened_flat.begin() + k + widths[r][m]);
+        k += widths[r][m];
+      }
+  }
+  if (k != opened_flat.size()) return false;
+  std::vector<RoundClaim> rounds(commits.size());
+  for (size_t r = 0; r < commits.size(); r++) {
+    rounds[r].commit = commits[r];
+    rounds[r].log_n = log_n[r];
+    for (size_t m = 0; m < points[r].size(); m++) {
+      std::vector<std::pair<E2, const std::vector<E2>*>> pv;
+      for (size_t p = 0; p < points[r][m].size(); p++) pv.emplace_back(points[r][m][p], &vals[r][m][p]);
+      rounds[r].mats.push_back(std::move(pv));
+    }
+  }
+  return pcs_verify(prm, rounds, proof, ch);
+}
 
 int verify(HSystem& sys, size_t n_claims, const u64* claim_offsets, const u64* claim_data, const uint8_t* proof_bytes, size_t proof_len) {
   Ctx& ctx = *sys.ctx;

@@ -231,6 +231,22 @@ struct Proof {
   OpenedRound pre_opened;
 };
 std::vector<uint8_t> proof_to_bytes(const Proof& p);
+std::vector<uint8_t> fri_to_bytes(const FriProof& f);  // the opening_proof field alone (PCS-level tests)
+FriProof fri_from_bytes(const uint8_t* p, size_t n);
+
+// Pcs::open / Pcs::verify on their own (examples/pcs_example.rs:76-121; src/prover.rs:580): one entry per committed batch
+struct PcsOpenRound {
+  const MerkleTree* tree;
+  std::vector<std::vector<EF>> points;  // per matrix
+};
+void pcs_open_rounds(const Params& prm, const std::vector<PcsOpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened,
+                     FriProof& proof);
+struct PcsVerifyRound {
+  std::vector<Digest> commit;
+  std::vector<unsigned> log_n;                                           // per matrix: log2 of the domain size
+  std::vector<std::vector<std::pair<EF, std::vector<EF>>>> mats;        // per matrix: (point, claimed values)
+};
+bool pcs_verify_rounds(const Params& prm, const std::vector<PcsVerifyRound>& rounds, const FriProof& proof, Challenger& ch);
 Proof proof_from_bytes(const uint8_t* p, size_t n);
 
 // per-stage wall-clock of the last prove() (seconds), reference span names (src/prover.rs:336-538)

@@ -197,6 +197,106 @@ void mso_challenger_sample_ext(void* c, u64* out2) {
 u64 mso_challenger_sample_bits(void* c, unsigned bits) { return ((Challenger*)c)->sample_bits(bits); }
 u64 mso_challenger_grind(void* c, unsigned bits) { return ((Challenger*)c)->grind(bits); }
 
+// ---- Pcs::open / Pcs::verify on their own. params7 = the seven CommitmentParameters / FriParameters words; n_points has one
+// entry per matrix (rounds flattened), points holds EXT_D words each; opened values are written / read in
+// round -> matrix -> point -> column order, EXT_D words each. mso_pcs_open returns the FRI proof length (-needed if the
+// buffer is too small, -1 on error); mso_pcs_verify returns 1 = accepted, 0 = rejected, -1 = error.
+static Params params_from(const u64* p7) {
+  Params p;
+  p.log_blowup = p7[0], p.cap_height = p7[1], p.log_final_poly_len = p7[2], p.max_log_arity = p7[3], p.num_queries = p7[4];
+  p.commit_pow_bits = p7[5], p.query_pow_bits = p7[6];
+  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 is restated");
+  return p;
+}
+long mso_pcs_open(const u64* params7, size_t n_rounds, void* const* mmcs, const u64* n_points, const u64* points, void* challenger,
+                  u64* opened_out, uint8_t* fri_out, size_t fri_cap) {
+  try {
+    Params prm = params_from(params7);
+    std::vector<PcsOpenRound> rounds;
+    size_t mk = 0, pk = 0;
+    for (size_t r = 0; r < n_rounds; r++) {
+      PcsOpenRound pr;
+      pr.tree = (const MerkleTree*)mmcs[r];
+      for (size_t m = 0; m < pr.tree->mats.size(); m++) {
+        std::vector<EF> pts;
+        for (u64 k = 0; k < n_points[mk]; k++) pts.push_back(ef_from(points + EXT_D * pk++));
+        mk++;
+        pr.points.push_back(std::move(pts));
+      }
+      rounds.push_back(std::move(pr));
+    }
+    std::vector<OpenedRound> opened;
+    FriProof proof;
+    pcs_open_rounds(prm, rounds, *(Challenger*)challenger, opened, proof);
+    size_t k = 0;
+    for (auto& orr : opened)
+      for (auto& m : orr)
+        for (auto& pt : m)
+          for (auto& e : pt) {
+            ef_to(e, opened_out + k);
+            k += EXT_D;
+          }
+    std::vector<uint8_t> bytes = fri_to_bytes(proof);
+    if (bytes.size() > fri_cap) return -(long)bytes.size();
+    memcpy(fri_out, bytes.data(), bytes.size());
+    return (long)bytes.size();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int mso_pcs_verify(const u64* params7, size_t n_rounds, const uint8_t* const* caps, const u64* cap_sizes, const u64* n_mats, const u64* log_n,
+                   const u64* widths, const u64* n_points, const u64* points, const u64* opened, const uint8_t* fri, size_t fri_len,
+                   void* challenger) {
+  TRY Params prm = params_from(params7);
+  std::vector<PcsVerifyRound> rounds;
+  size_t mk = 0, pk = 0, ok = 0;
+  for (size_t r = 0; r < n_rounds; r++) {
+    PcsVerifyRound vr;
+    vr.commit.resize(cap_sizes[r]);
+    for (size_t i = 0; i < cap_sizes[r]; i++) memcpy(vr.commit[i].b, caps[r] + 32 * i, 32);
+    for (u64 m = 0; m < n_mats[r]; m++) {
+      vr.log_n.push_back((unsigned)log_n[mk]);
+      std::vector<std::pair<EF, std::vector<EF>>> pts;
+      for (u64 k = 0; k < n_points[mk]; k++) {
+        std::vector<EF> vals;
+        for (u64 c = 0; c < widths[mk]; c++) {
+          vals.push_back(ef_from(opened + ok));
+          ok += EXT_D;
+        }
+        pts.emplace_back(ef_from(points + EXT_D * pk++), std::move(vals));
+      }
+      mk++;
+      vr.mats.push_back(std::move(pts));
+    }
+    rounds.push_back(std::move(vr));
+  }
+  FriProof proof;
+  try {
+    proof = fri_from_bytes(fri, fri_len);
+  } catch (const std::exception&) {
+    return 0;
+  }
+  return pcs_verify_rounds(prm, rounds, proof, *(Challenger*)challenger) ? 1 : 0;
+  CATCH
+}
+void mso_challenger_observe_digests(void* c, const uint8_t* d, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    Digest x;
+    memcpy(x.b, d + 32 * i, 32);
+    ((Challenger*)c)->observe_digest(x);
+  }
+}
+// config.initialise_challenger() for the seven parameters (src/types.rs:118-130; baby_bear_config.rs:72-86,108-114)
+void* mso_challenger_for_params(const u64* params7) {
+  System s;
+  s.params = Params();
+  s.params.log_blowup = params7[0], s.params.cap_height = params7[1], s.params.log_final_poly_len = params7[2];
+  s.params.max_log_arity = params7[3], s.params.num_queries = params7[4], s.params.commit_pow_bits = params7[5];
+  s.params.query_pow_bits = params7[6];
+  return new Challenger(s.new_challenger());
+}
+
 // ---- system / witness / prove / verify
 void* mso_system_create(const uint8_t* blob, size_t len) {
   try {

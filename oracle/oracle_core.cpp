@@ -749,18 +749,7 @@ struct R {
 };
 }  // namespace
 
-std::vector<uint8_t> proof_to_bytes(const Proof& p) {
-  W w;
-  w.u64_(p.active.size());
-  for (auto a : p.active) w.u8(a ? 1 : 0);
-  w.cap(p.stage1_commit);
-  w.cap(p.stage2_commit);
-  w.cap(p.quotient_commit);
-  w.u64_(p.intermediate_accumulators.size());
-  for (auto& e : p.intermediate_accumulators) w.ext(e);
-  w.u64_(p.log_degrees.size());
-  for (auto d : p.log_degrees) w.u8(d);
-  const FriProof& f = p.opening_proof;
+static void write_fri(W& w, const FriProof& f) {
   w.u64_(f.commit_phase_commits.size());
   for (auto& c : f.commit_phase_commits) w.cap(c);
   w.u64_(f.commit_pow_witnesses.size());
@@ -789,6 +778,26 @@ std::vector<uint8_t> proof_to_bytes(const Proof& p) {
   w.u64_(f.final_poly.size());
   for (auto& e : f.final_poly) w.ext(e);
   w.fe(f.query_pow_witness);
+}
+
+std::vector<uint8_t> fri_to_bytes(const FriProof& f) {
+  W w;
+  write_fri(w, f);
+  return std::move(w.b);
+}
+
+std::vector<uint8_t> proof_to_bytes(const Proof& p) {
+  W w;
+  w.u64_(p.active.size());
+  for (auto a : p.active) w.u8(a ? 1 : 0);
+  w.cap(p.stage1_commit);
+  w.cap(p.stage2_commit);
+  w.cap(p.quotient_commit);
+  w.u64_(p.intermediate_accumulators.size());
+  for (auto& e : p.intermediate_accumulators) w.ext(e);
+  w.u64_(p.log_degrees.size());
+  for (auto d : p.log_degrees) w.u8(d);
+  write_fri(w, p.opening_proof);
   w.round(p.quotient_opened);
   w.u8(p.has_pre_opened ? 1 : 0);
   if (p.has_pre_opened) w.round(p.pre_opened);
@@ -797,22 +806,8 @@ std::vector<uint8_t> proof_to_bytes(const Proof& p) {
   return std::move(w.b);
 }
 
-Proof proof_from_bytes(const uint8_t* bytes, size_t n) {
-  R r{bytes, n};
-  Proof p;
-  p.active.resize(r.len(1));
-  for (auto& a : p.active) {
-    a = r.u8();
-    if (a > 1) throw std::runtime_error("bad bool");
-  }
-  p.stage1_commit = r.cap();
-  p.stage2_commit = r.cap();
-  p.quotient_commit = r.cap();
-  p.intermediate_accumulators.resize(r.len(EXT_D * F_WIRE_BYTES));
-  for (auto& e : p.intermediate_accumulators) e = r.ext();
-  p.log_degrees.resize(r.len(1));
-  for (auto& d : p.log_degrees) d = r.u8();
-  FriProof& f = p.opening_proof;
+static FriProof read_fri(R& r) {
+  FriProof f;
   f.commit_phase_commits.resize(r.len(8));
   for (auto& c : f.commit_phase_commits) c = r.cap();
   f.commit_pow_witnesses.resize(r.len(F_WIRE_BYTES));
@@ -841,6 +836,32 @@ Proof proof_from_bytes(const uint8_t* bytes, size_t n) {
   f.final_poly.resize(r.len(EXT_D * F_WIRE_BYTES));
   for (auto& e : f.final_poly) e = r.ext();
   f.query_pow_witness = r.fe();
+  return f;
+}
+
+FriProof fri_from_bytes(const uint8_t* bytes, size_t n) {
+  R r{bytes, n};
+  FriProof f = read_fri(r);
+  if (r.off != n) throw std::runtime_error("trailing bytes in FRI proof");
+  return f;
+}
+
+Proof proof_from_bytes(const uint8_t* bytes, size_t n) {
+  R r{bytes, n};
+  Proof p;
+  p.active.resize(r.len(1));
+  for (auto& a : p.active) {
+    a = r.u8();
+    if (a > 1) throw std::runtime_error("bad bool");
+  }
+  p.stage1_commit = r.cap();
+  p.stage2_commit = r.cap();
+  p.quotient_commit = r.cap();
+  p.intermediate_accumulators.resize(r.len(EXT_D * F_WIRE_BYTES));
+  for (auto& e : p.intermediate_accumulators) e = r.ext();
+  p.log_degrees.resize(r.len(1));
+  for (auto& d : p.log_degrees) d = r.u8();
+  p.opening_proof = read_fri(r);
   p.quotient_opened = r.round();
   uint8_t tag = r.u8();
   if (tag > 1) throw std::runtime_error("bad option tag");

@@ -902,6 +902,22 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
 }
 }  // namespace
 
+void pcs_open_rounds(const Params& prm, const std::vector<PcsOpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened,
+                     FriProof& proof) {
+  std::vector<OpenRound> rs;
+  for (auto& r : rounds) rs.push_back(OpenRound{r.tree, r.points});
+  pcs_open(prm, rs, ch, opened, proof);
+}
+bool pcs_verify_rounds(const Params& prm, const std::vector<PcsVerifyRound>& rounds, const FriProof& proof, Challenger& ch) {
+  std::vector<RoundClaim> rs;
+  for (auto& r : rounds) {
+    RoundClaim c;
+    c.commit = r.commit, c.log_n = r.log_n, c.mats = r.mats;
+    rs.push_back(std::move(c));
+  }
+  return pcs_verify(prm, rs, proof, ch);
+}
+
 VerifyError verify(const System& sys, const std::vector<std::vector<u64>>& claims, const Proof& proof) {
   const Params& prm = sys.params;
   size_t C = sys.circuits.size();

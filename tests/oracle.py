@@ -49,6 +49,8 @@ def lib():
         L.mso_prove.restype = C.c_long
         L.mso_challenger_sample_bits.restype = C.c_uint64
         L.mso_challenger_grind.restype = C.c_uint64
+        L.mso_challenger_for_params.restype = C.c_void_p
+        L.mso_pcs_open.restype = C.c_long
         L.mso_field_order.restype = C.c_uint64
         assert L.mso_ext_degree() == D
         if BABYBEAR:
@@ -192,8 +194,19 @@ class Challenger:
         s = np.frombuffer(seed, dtype=np.uint8) if seed else np.zeros(0, dtype=np.uint8)
         self.h = lib().mso_challenger_new(_b(s), C.c_size_t(len(seed)))
 
+    @staticmethod
+    def for_params(params):
+        """config.initialise_challenger() (src/types.rs:118-130)"""
+        c = Challenger.__new__(Challenger)
+        c.h = lib().mso_challenger_for_params(_p(_u64(params.words())))
+        return c
+
     def observe(self, x):
         lib().mso_challenger_observe(C.c_void_p(self.h), C.c_uint64(x))
+
+    def observe_digests(self, cap: bytes):
+        a = np.frombuffer(cap, dtype=np.uint8)
+        lib().mso_challenger_observe_digests(C.c_void_p(self.h), _b(a), C.c_size_t(len(cap) // 32))
 
     def observe_bytes(self, b: bytes):
         a = np.frombuffer(b, dtype=np.uint8)
@@ -213,6 +226,53 @@ class Challenger:
     def __del__(self):
         if getattr(self, "h", None):
             lib().mso_challenger_free(C.c_void_p(self.h))
+
+
+def _flatten_points(rounds):
+    n_points, pts = [], []
+    for _mmcs, per_matrix in rounds:
+        for plist in per_matrix:
+            n_points.append(len(plist))
+            for z in plist:
+                pts.extend(int(x) for x in z)
+    return _u64(n_points), _u64(pts if pts else [0])
+
+
+def pcs_open(params, rounds, challenger):
+    """Pcs::open (examples/pcs_example.rs:88-95, src/prover.rs:580). rounds: [(Mmcs, [[point, ..] per matrix])], a point
+    = D ints. Returns (opened values flat: round -> matrix -> point -> column, D words each; FriProof bytes)."""
+    n_points, pts = _flatten_points(rounds)
+    handles = (C.c_void_p * len(rounds))(*[C.c_void_p(m.h) for m, _ in rounds])
+    total = sum(len(plist) * int(m.widths[i]) for m, per in rounds for i, plist in enumerate(per))
+    opened = np.zeros(max(total, 1) * D, dtype=np.uint64)
+    cap = 1 << 22
+    while True:
+        out = np.zeros(cap, dtype=np.uint8)
+        r = lib().mso_pcs_open(_p(_u64(params.words())), C.c_size_t(len(rounds)), handles, _p(n_points), _p(pts), C.c_void_p(challenger.h),
+                               _p(opened), _b(out), C.c_size_t(cap))
+        if r >= 0:
+            return opened[: total * D].copy(), out[:r].tobytes()
+        if r == -1:
+            raise RuntimeError(_err())
+        cap = -r
+
+
+def pcs_verify(params, rounds, opened, fri: bytes, challenger):
+    """Pcs::verify. rounds: [(cap bytes, [(log_n, width)] per matrix, [[point, ..] per matrix])]; True = accepted"""
+    caps = [np.frombuffer(c, dtype=np.uint8) for c, _, _ in rounds]
+    cap_ptrs = (u8p * len(rounds))(*[_b(c) for c in caps])
+    cap_sizes = _u64([len(c) // 32 for c, _, _ in rounds])
+    n_mats = _u64([len(d) for _, d, _ in rounds])
+    log_n = _u64([ln for _, d, _ in rounds for ln, _w in d])
+    widths = _u64([w for _, d, _ in rounds for _ln, w in d])
+    n_points, pts = _flatten_points([(None, per) for _, _, per in rounds])
+    f = np.frombuffer(fri, dtype=np.uint8) if fri else np.zeros(1, dtype=np.uint8)
+    op = _u64(opened) if len(opened) else np.zeros(1, dtype=np.uint64)
+    r = lib().mso_pcs_verify(_p(_u64(params.words())), C.c_size_t(len(rounds)), cap_ptrs, _p(cap_sizes), _p(n_mats), _p(log_n), _p(widths),
+                             _p(n_points), _p(pts), _p(op), _b(f), C.c_size_t(len(fri)), C.c_void_p(challenger.h))
+    if r < 0:
+        raise RuntimeError(_err())
+    return r == 1
 
 
 class System:

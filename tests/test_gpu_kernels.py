@@ -182,3 +182,70 @@ def test_full_size_stage2_trace(ctx, oracle):
     gt, ga = ctx.stage2_trace(mult, offs, args, beta, gamma, [3, 9])
     ot, oa = oracle.stage2_trace(mult, offs, args, beta, gamma, [3, 9])
     assert ga == oa and np.array_equal(gt, ot)
+
+
+# ---- Pcs::commit / open / verify on their own (ms_pcs_*, ms_challenger_*)
+from __graft_entry__ import load_package as _load_package  # noqa: E402
+
+_fe = _load_package().frontend
+
+def _pcs_scenario(ctx, pkg, oracle, params, mats_per_round, n_points):
+    """commit every round, observe the commitments, sample zeta, open: library vs oracle, then both verifiers on both results"""
+    lb, ch_h = params.log_blowup, params.cap_height
+    g_rounds = [pkg.PcsCommitment(ctx, mats, lb, ch_h) for mats in mats_per_round]
+    o_rounds = [oracle.Mmcs([oracle.coset_lde_bitrev(m, lb) for m in mats], ch_h) for mats in mats_per_round]
+    for g, o in zip(g_rounds, o_rounds):
+        assert g.cap == o.cap
+    gc, oc = pkg.Challenger(params), oracle.Challenger.for_params(params)
+    for g in g_rounds:
+        gc.observe_digests(g.cap)
+        oc.observe_digests(g.cap)
+    zeta = gc.sample_ext()
+    assert zeta == oc.sample_ext()
+    pts_per_round = []
+    for mats in mats_per_round:
+        per = []
+        for m in mats:
+            log_n = m.shape[0].bit_length() - 1
+            g_n = pow(oracle.lib().mso_gl_two_adic_generator(log_n), 1, P)
+            zn = (zeta[0] * g_n % P, zeta[1] * g_n % P)
+            per.append([zeta, zeta][:n_points] if n_points <= 2 and n_points != -1 else [zeta, zn])
+        pts_per_round.append(per)
+    g_open, g_fri = pkg.pcs_open(ctx, params, list(zip(g_rounds, pts_per_round)), gc)
+    o_open, o_fri = oracle.pcs_open(params, list(zip(o_rounds, pts_per_round)), oc)
+    assert np.array_equal(g_open, o_open) and g_fri == o_fri
+    assert gc.sample_bits(20) == oc.sample_bits(20)  # the transcripts end in the same state
+    desc = [(g.cap, [(m.shape[0].bit_length() - 1, m.shape[1]) for m in mats], per)
+            for g, mats, per in zip(g_rounds, mats_per_round, pts_per_round)]
+
+    def fresh(lib_side):
+        c = pkg.Challenger(params) if lib_side else oracle.Challenger.for_params(params)
+        for g in g_rounds:
+            c.observe_digests(g.cap)
+        assert c.sample_ext() == zeta
+        return c
+
+    assert pkg.pcs_verify(params, desc, g_open, g_fri, fresh(True)) and oracle.pcs_verify(params, desc, g_open, g_fri, fresh(False))
+    bad = g_open.copy()
+    bad[0] ^= 1
+    assert not pkg.pcs_verify(params, desc, bad, g_fri, fresh(True)) and not oracle.pcs_verify(params, desc, bad, g_fri, fresh(False))
+    tam = bytearray(g_fri)
+    tam[len(tam) // 3] ^= 2
+    assert not pkg.pcs_verify(params, desc, g_open, bytes(tam), fresh(True))
+    assert not oracle.pcs_verify(params, desc, g_open, bytes(tam), fresh(False))
+    assert not pkg.pcs_verify(params, desc, g_open, g_fri[:-3], fresh(True))
+
+
+def test_pcs_example(ctx, pkg, oracle):
+    """examples/pcs_example.rs: one polynomial of degree < 32 (entry i = i), blowup 2, 100 queries, opened twice at zeta"""
+    params = _fe.Params(1, 0, 0, 1, 100, 0, 0)
+    _pcs_scenario(ctx, pkg, oracle, params, [[np.arange(32, dtype=np.uint64).reshape(32, 1)]], 2)
+
+
+@pytest.mark.parametrize("params", [_fe.Params(2, 1, 1, 1, 15, 4, 5), _fe.Params(1, 0, 0, 1, 30, 0, 0), _fe.Params(3, 2, 2, 1, 9, 6, 0)])
+def test_pcs_commit_open_verify_mixed_rounds(ctx, pkg, oracle, params):
+    """two committed batches, mixed heights and widths, one point or (zeta, zeta g) per matrix"""
+    rng = np.random.default_rng(int(params.num_queries))
+    rounds = [[rand_field(rng, (1 << 10, 5)), rand_field(rng, (1 << 7, 2)), rand_field(rng, (1 << 10, 1))], [rand_field(rng, (1 << 9, 9))]]
+    _pcs_scenario(ctx, pkg, oracle, params, rounds, -1)
+    _pcs_scenario(ctx, pkg, oracle, params, rounds, 1)
