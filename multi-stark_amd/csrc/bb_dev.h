@@ -24,21 +24,23 @@ static constexpr u32 BB_GENERATOR = 31;        // canonical
 static constexpr u32 BB_TWO_ADIC_GEN = 0x1a427a41u;  // canonical, order 2^27 (= 31^15)
 static constexpr u32 BB_EXT_W = 11;            // canonical; X^4 = 11
 
+// one conditional correction as an unsigned minimum: the wrong candidate wraps around to a value above 2^31
 BB_HD u32 bb_add(u32 a, u32 b) {
-  u32 s = a + b;
-  return s >= BB_P ? s - BB_P : s;
+  u32 s = a + b, t = s - BB_P;
+  return t < s ? t : s;
 }
 BB_HD u32 bb_sub(u32 a, u32 b) {
-  u32 d = a - b;
-  return a < b ? d + BB_P : d;
+  u32 d = a - b, t = d + BB_P;
+  return t < d ? t : d;
 }
 BB_HD u32 bb_neg(u32 a) { return a ? BB_P - a : 0; }
 // Montgomery reduction of x < p * 2^32: x / 2^32 mod p
 BB_HD u32 bb_mred(u64 x) {
-  u32 t = (u32)x * BB_PINV;
-  u64 u = (u64)t * BB_P;
-  u32 r = (u32)((x - u) >> 32);
-  return x < u ? r + BB_P : r;
+  u32 lo = (u32)x, hi = (u32)(x >> 32);
+  u32 t = lo * BB_PINV;
+  u32 uh = (u32)(((u64)t * BB_P) >> 32);  // the low word of t * p equals lo by construction: only the high words differ
+  u32 r = hi - uh, r2 = r + BB_P;  // hi < uh: r wrapped and r + p is the answer; else r + p > r
+  return r2 < r ? r2 : r;
 }
 BB_HD u32 bb_mul(u32 a, u32 b) { return bb_mred((u64)a * b); }
 BB_HD u32 bb_to_monty(u32 canonical) { return bb_mul(canonical, BB_R2); }
@@ -133,6 +135,12 @@ struct Poseidon2 {
   u32 internal[13];
   u32 diag[16];  // V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
 };
+// x / 2 and x / 2^k without a general multiplication: a shift into the Montgomery reduction
+BB_HD u32 bb_halve(u32 x) { return (x & 1) ? (x + BB_P) >> 1 : x >> 1; }
+template <int K>
+BB_HD u32 bb_div2k(u32 x) {
+  return bb_mred((u64)x << (32 - K));
+}
 BB_HD u32 bb_sbox7(u32 x) {
   u32 x2 = bb_mul(x, x), x3 = bb_mul(x2, x), x4 = bb_mul(x2, x2);
   return bb_mul(x3, x4);
@@ -140,13 +148,14 @@ BB_HD u32 bb_sbox7(u32 x) {
 // M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on each 4-chunk, then every chunk += the column sums
 BB_HD void bb_mds_light16(u32* s) {
 #pragma unroll
-  for (int c = 0; c < 16; c += 4) {
+  for (int c = 0; c < 16; c += 4) {  // 9 additions + 2 doublings per chunk
     u32 a = s[c], b = s[c + 1], cc = s[c + 2], d = s[c + 3];
-    u32 sum = bb_add(bb_add(a, b), bb_add(cc, d));
-    s[c] = bb_add(bb_add(sum, a), bb_add(b, b));
-    s[c + 1] = bb_add(bb_add(sum, b), bb_add(cc, cc));
-    s[c + 2] = bb_add(bb_add(sum, cc), bb_add(d, d));
-    s[c + 3] = bb_add(bb_add(sum, d), bb_add(a, a));
+    u32 t01 = bb_add(a, b), t23 = bb_add(cc, d), t0123 = bb_add(t01, t23);
+    u32 t01123 = bb_add(t0123, b), t01233 = bb_add(t0123, d);
+    s[c + 3] = bb_add(t01233, bb_add(a, a));   // 3a + b + c + 2d
+    s[c + 1] = bb_add(t01123, bb_add(cc, cc)); // a + 2b + 3c + d
+    s[c] = bb_add(t01123, t01);                // 2a + 3b + c + d
+    s[c + 2] = bb_add(t01233, t23);            // a + b + 2c + 3d
   }
   u32 col[4];
 #pragma unroll
@@ -166,8 +175,26 @@ BB_HD void bb_poseidon2(const Poseidon2& k, u32* s) {
     u32 sum = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) sum = bb_add(sum, s[i]);
-#pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = bb_add(sum, bb_mul(k.diag[i], s[i]));
+    // state <- sum + diag(V) state, V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]:
+    // small multiples are additions, powers of 1/2 are shifts into the Montgomery reduction (k.diag holds the same
+    // constants for the lane-parallel form)
+    u32 d2, d4;
+    d2 = bb_add(s[0], s[0]), s[0] = bb_sub(sum, d2);
+    s[1] = bb_add(sum, s[1]);
+    s[2] = bb_add(sum, bb_add(s[2], s[2]));
+    s[3] = bb_add(sum, bb_halve(s[3]));
+    d2 = bb_add(s[4], s[4]), s[4] = bb_add(sum, bb_add(d2, s[4]));
+    d2 = bb_add(s[5], s[5]), s[5] = bb_add(sum, bb_add(d2, d2));
+    s[6] = bb_sub(sum, bb_halve(s[6]));
+    d2 = bb_add(s[7], s[7]), s[7] = bb_sub(sum, bb_add(d2, s[7]));
+    d2 = bb_add(s[8], s[8]), d4 = bb_add(d2, d2), s[8] = bb_sub(sum, d4);
+    s[9] = bb_add(sum, bb_div2k<8>(s[9]));
+    s[10] = bb_add(sum, bb_halve(bb_halve(s[10])));
+    s[11] = bb_add(sum, bb_div2k<3>(s[11]));
+    s[12] = bb_add(sum, bb_div2k<27>(s[12]));
+    s[13] = bb_sub(sum, bb_div2k<8>(s[13]));
+    s[14] = bb_sub(sum, bb_div2k<4>(s[14]));
+    s[15] = bb_sub(sum, bb_div2k<27>(s[15]));
   }
   for (int r = 4; r < 8; r++) {
 #pragma unroll
