@@ -71,6 +71,8 @@ struct BLookupsDev {
 // circuit's local total (added to the running accumulator by the caller)
 void bb_stage2(Ctx& ctx, const BProgram& prog, size_t prefix_len, const BLookupsDev& lk, const BMat& trace, const BMat* pre, E4 beta,
                E4 gamma, BMat& out, E4* total);
+// sum over the claims of 1 / (beta + fingerprint(gamma, claim)) (src/prover.rs:382-387); data in Montgomery form
+E4 bb_claims_accumulator(Ctx& ctx, const u32* d_data_monty, const u64* d_offs, size_t n, E4 beta, E4 gamma);
 // quotient_values (src/prover.rs:756-962) on the quotient domain; q_evals: (n q) x 4 in natural order
 struct BQuotientIn {
   const BProgram* prog;

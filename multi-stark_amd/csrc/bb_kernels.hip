@@ -631,6 +631,30 @@ void bb_stage2(Ctx& ctx, const BProgram& prog, size_t prefix_len, const BLookups
   ctx.d2h(total, tot.p + nb, sizeof(E4));
 }
 
+// claims accumulator (src/prover.rs:382-387): sum over the claims of 1 / (beta + fingerprint(gamma, claim))
+__global__ void claims_terms_k(const u32* __restrict__ data, const u64* __restrict__ offs, size_t n, E4 beta, E4 gamma, E4* __restrict__ terms) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  E4 f = e4_zero();
+  for (u64 k = offs[i + 1]; k-- > offs[i];) {
+    f = e4_mul(f, gamma);
+    f.c[0] = bb_add(f.c[0], data[k]);
+  }
+  terms[i] = e4_inv(e4_add(beta, f));
+}
+E4 bb_claims_accumulator(Ctx& ctx, const u32* d_data_monty, const u64* d_offs, size_t n, E4 beta, E4 gamma) {
+  if (!n) return e4_zero();
+  DBuf<E4> terms(ctx, n);
+  size_t nb = (n + 1023) / 1024;
+  DBuf<E4> tot(ctx, nb + 1);
+  claims_terms_k<<<blocks_for(n, 256), 256, 0, ctx.stream>>>(d_data_monty, d_offs, n, beta, gamma, terms.p);
+  scan_local_k<<<(unsigned)nb, 256, 0, ctx.stream>>>(terms.p, n, tot.p);
+  scan_totals_k<<<1, 1024, 0, ctx.stream>>>(tot.p, nb, tot.p + nb);
+  E4 total;
+  ctx.d2h(&total, tot.p + nb, sizeof(E4));
+  return total;
+}
+
 // ------------------------------------------------------------------ quotient (src/prover.rs:756-962)
 struct QuotArgs {
   const u32 *kind, *na, *nb;

@@ -116,7 +116,9 @@ struct BWitness {
   BSystem* sys = nullptr;
   std::vector<size_t> heights;
   std::vector<BMat> traces;
-  std::vector<std::vector<u32>> claims;  // canonical
+  std::vector<std::vector<u32>> claims;  // canonical (the transcript absorbs them on the host)
+  DBuf<u32> d_claim_data;                // Montgomery form, concatenated
+  DBuf<u64> d_claim_offs;
 };
 
 static std::vector<Digest8> tree_cap(Ctx& ctx, const BTree& t) {
@@ -325,10 +327,23 @@ std::unique_ptr<BWitness> witness_create(BSystem& sys, const u32* const* traces,
       if (traces[ci][i] >= BB_P) throw std::runtime_error("non-canonical trace value");
     bb_upload_rows(ctx, traces[ci], h, c.main_width, w->traces.back());
   }
+  std::vector<u32> flat;
   for (size_t i = 0; i < n_claims; i++) {
+    if (claim_offsets[i + 1] < claim_offsets[i]) throw std::runtime_error("claim offsets must not decrease");
     w->claims.emplace_back(claim_data + claim_offsets[i], claim_data + claim_offsets[i + 1]);
-    for (u32 x : w->claims.back())
+    for (u32 x : w->claims.back()) {
       if (x >= BB_P) throw std::runtime_error("non-canonical claim value");
+      flat.push_back(bb_to_monty(x));
+    }
+  }
+  if (n_claims) {
+    std::vector<u64> offs(n_claims + 1);
+    for (size_t i = 0; i <= n_claims; i++) offs[i] = claim_offsets[i] - claim_offsets[0];
+    w->d_claim_offs = DBuf<u64>(ctx, n_claims + 1);
+    w->d_claim_data = DBuf<u32>(ctx, std::max<size_t>(flat.size(), 1));
+    ctx.h2d(w->d_claim_offs.p, offs.data(), offs.size() * 8);
+    if (!flat.empty()) ctx.h2d(w->d_claim_data.p, flat.data(), flat.size() * 4);
+    ctx.sync();
   }
   return w;
 }
@@ -680,16 +695,8 @@ std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
   ch.observe_e4(beta);
   E4 gamma = ch.sample_e4();
   ch.observe_e4(gamma);
-  // claims accumulator, src/prover.rs:382-387 (host: the reference's second configuration carries few claims)
-  E4 acc = e4_zero();
-  for (auto& c : wit.claims) {
-    E4 f = e4_zero();
-    for (size_t k = c.size(); k-- > 0;) {
-      f = e4_mul(f, gamma);
-      f.c[0] = bb_add(f.c[0], bb_to_monty(c[k]));
-    }
-    acc = e4_add(acc, e4_inv(e4_add(beta, f)));
-  }
+  // claims accumulator, src/prover.rs:382-387
+  E4 acc = bb_claims_accumulator(ctx, wit.d_claim_data.p, wit.d_claim_offs.p, wit.claims.size(), beta, gamma);
 
   // ---- lookup construction + stage 2 commit
   t0 = now_ms();

@@ -143,11 +143,11 @@ def test_lookups_with_claims_and_dead_circuit(ctx):
 
 
 def test_preprocessed_and_mixed_heights(ctx):
-    """[ByteTable (preprocessed, 256 rows), U32Add (2^9 rows)] of benches/multi_stark.rs:73-165 over BabyBear, and the
+    """[ByteTable (preprocessed, 256 rows), U32Add (2^12 rows)] of benches/multi_stark.rs:73-165 over BabyBear, and the
     squares system (constraint degree 3 -> quotient degree 2)"""
     with fe.field(fe.BABYBEAR):
         inputs = fe.u32_add_system_inputs()
-        traces, claims = fe.u32_add_bench_witness(1 << 9)
+        traces, claims = fe.u32_add_bench_witness(1 << 12)  # 4096 claims: accumulated on the device
         assert _prove_both(ctx, fe.Params(2, 0, 0, 1, 20, 2, 2), inputs, traces, claims)[0] == 0
         assert _prove_both(ctx, fe.Params(2, 1, 1, 1, 10, 0, 0), fe.squares_inputs(), fe.squares_traces(16), [])[0] == 0
 
