@@ -2,6 +2,7 @@
 // quotient evaluation, barycentric / DEEP / FRI-fold kernels. See bb.h for the data layout. Every kernel is integer
 // VALU work on 32-bit Montgomery words; nothing here is shaped for MFMA.
 #include <algorithm>
+#include <cstdlib>
 
 #include "bb.h"
 
@@ -771,6 +772,7 @@ void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals) {
   p.g_pow_n = bb_exp_pow2(p.g, in.log_n), p.w_q = bb_two_adic_generator(in.log_q);
   // rows in chunks, so that the slot file (nodes x rows words) stays bounded
   size_t chunk = std::min<size_t>(N, std::max<size_t>(256, (size_t(1) << 28) / std::max<size_t>(in.prog->n, 1) / 256 * 256));
+  if (const char* e = getenv("MSBB_QUOTIENT_CHUNK")) chunk = std::min<size_t>(N, std::max<size_t>(64, (size_t)atoll(e)));  // tests
   DBuf<u32> scratch(ctx, std::max<size_t>(in.prog->n, 1) * chunk);
   p.scratch = scratch.p, p.stride = chunk;
   for (size_t row0 = 0; row0 < N; row0 += chunk) {

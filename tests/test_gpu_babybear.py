@@ -182,6 +182,15 @@ def test_product_verifier_agrees_with_oracle_on_corrupted_proofs(ctx):
             assert g.verify(pc, proof) != 0 and o.verify(pc, proof) != 0
 
 
+def test_quotient_row_chunks(ctx, monkeypatch):
+    """the quotient sweep in several row chunks (what a very large trace x node-program product triggers)"""
+    monkeypatch.setenv("MSBB_QUOTIENT_CHUNK", "192")
+    with fe.field(fe.BABYBEAR):
+        assert _prove_both(ctx, fe.Params(2, 0, 0, 1, 10, 0, 0), fe.squares_inputs(), fe.squares_traces(256), [])[0] == 0  # 1024 rows
+        inputs, trace = fe.mul_air_inputs(), fe.mul_air_trace(1 << 9)
+    assert _prove_both(ctx, fe.test_params(), inputs, [trace], [])[0] == 0
+
+
 def test_error_paths(ctx):
     with fe.field(fe.BABYBEAR):
         g = bb.System.new(ctx, fe.test_params(), fe.mul_air_inputs(), K)
