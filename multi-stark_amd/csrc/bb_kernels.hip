@@ -3,6 +3,7 @@
 // VALU work on 32-bit Montgomery words; nothing here is shaped for MFMA.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "bb.h"
 
@@ -56,6 +57,7 @@ __global__ void twiddles_k(u32* out, size_t count, u32 w) {
   if (j < count) out[j] = bb_pow(w, j);
 }
 struct TwCache {
+  std::mutex mu;  // contexts of different devices may be driven from different host threads
   std::map<std::pair<int, unsigned>, u32*> t;
 };
 static TwCache& tw_cache() {
@@ -64,6 +66,7 @@ static TwCache& tw_cache() {
 }
 static const u32* twiddles(Ctx& ctx, unsigned log_n) {
   auto key = std::make_pair(ctx.device, log_n);
+  std::lock_guard<std::mutex> lock(tw_cache().mu);
   auto it = tw_cache().t.find(key);
   if (it != tw_cache().t.end()) return it->second;
   size_t count = log_n ? (size_t(1) << (log_n - 1)) : 1;
