@@ -87,9 +87,39 @@ def proofs():
     return out
 
 
+def babybear_refs():
+    """The reference's second configuration (src/test_circuits/baby_bear_config.rs) on oracle/libms_oracle_bb.so, with the
+    documented stand-in Poseidon2 constants of frontend.poseidon2_constants(42) (the reference's own constants come from
+    an RNG stream that cannot be reproduced here)."""
+    import oracle_bb as ob
+
+    fe = load_package().frontend
+    k = fe.poseidon2_constants()
+    ob.set_poseidon2(k)
+    out = {"constants_sha256": hashlib.sha256(np.ascontiguousarray(k, dtype=np.uint64).tobytes()).hexdigest(),
+           "permute_0_to_15": [int(x) for x in ob.poseidon2_permute(np.arange(16))],
+           "leaf_1_to_11": ob.hash_elems(list(range(1, 12))).hex()}
+    ch = ob.Challenger(b"multi-stark/v0")
+    ch.observe(7)
+    out["challenger_sample_ext"] = list(ch.sample_ext())
+    out["challenger_sample_bits_20"] = ch.sample_bits(20)
+    with fe.field(fe.BABYBEAR):
+        comp = [fe.compile_circuit(c) for c in fe.mul_air_inputs()]
+        blob = fe.system_blob(fe.test_params(), comp, k)
+        s = ob.System(blob)
+        packed = fe.pack_claims([])
+        p = s.prove([fe.mul_air_smoke_trace()], packed)  # baby_bear_config.rs:159-206
+        assert s.verify(packed, p) == 0
+        out["mul_air_smoke_test"] = {"blob_sha256": hashlib.sha256(blob).hexdigest(), "proof_len": len(p),
+                                     "proof_sha256": hashlib.sha256(p).hexdigest()}
+        p = s.prove([fe.mul_air_trace(1 << 10)], packed)
+        out["mul_air_1024"] = {"proof_len": len(p), "proof_sha256": hashlib.sha256(p).hexdigest()}
+    return out
+
+
 if __name__ == "__main__":
     data = {"_note": "SELF-GENERATED by the oracle, not reference-verified (see module docstring)",
-            "pcs_refs": pcs_refs(), "challenger_refs": challenger_refs(), "proofs": proofs()}
+            "pcs_refs": pcs_refs(), "challenger_refs": challenger_refs(), "proofs": proofs(), "babybear": babybear_refs()}
     with open(os.path.join(HERE, "oracle_refs.json"), "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "oracle_refs.json"))

@@ -150,6 +150,28 @@ def test_duplex_challenger_semantics():
         assert (c.sample_bits(6) == 0) == (cand == w)
 
 
+def test_golden_fixture_babybear():
+    """tests/golden/oracle_refs.json["babybear"]: self-generated regression vectors (tests/golden/make_golden.py)"""
+    import hashlib
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_refs.json")))["babybear"]
+    assert hashlib.sha256(np.ascontiguousarray(K, dtype=np.uint64).tobytes()).hexdigest() == gold["constants_sha256"]
+    assert [int(x) for x in ob.poseidon2_permute(np.arange(16))] == gold["permute_0_to_15"]
+    assert ob.hash_elems(list(range(1, 12))).hex() == gold["leaf_1_to_11"]
+    ch = ob.Challenger(b"multi-stark/v0")
+    ch.observe(7)
+    assert list(ch.sample_ext()) == gold["challenger_sample_ext"] and ch.sample_bits(20) == gold["challenger_sample_bits_20"]
+    with fe.field(fe.BABYBEAR):
+        o = _system(fe.test_params(), fe.mul_air_inputs())
+        packed = fe.pack_claims([])
+        p = o.prove([fe.mul_air_smoke_trace()], packed)
+        assert (len(p), hashlib.sha256(p).hexdigest()) == (gold["mul_air_smoke_test"]["proof_len"], gold["mul_air_smoke_test"]["proof_sha256"])
+        p = o.prove([fe.mul_air_trace(1 << 10)], packed)
+        assert hashlib.sha256(p).hexdigest() == gold["mul_air_1024"]["proof_sha256"]
+
+
 def _system(params, inputs):
     comp = [fe.compile_circuit(c) for c in inputs]
     return ob.System(fe.system_blob(params, comp, K))
