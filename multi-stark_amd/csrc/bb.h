@@ -73,6 +73,8 @@ void bb_stage2(Ctx& ctx, const BProgram& prog, size_t prefix_len, const BLookups
                E4 gamma, BMat& out, E4* total);
 // sum over the claims of 1 / (beta + fingerprint(gamma, claim)) (src/prover.rs:382-387); data in Montgomery form
 E4 bb_claims_accumulator(Ctx& ctx, const u32* d_data_monty, const u64* d_offs, size_t n, E4 beta, E4 gamma);
+// proof-of-work search of the duplex challenger on the device: smallest canonical witness
+u32 bb_grind(Ctx& ctx, const Poseidon2* d_perm, const u32* state16, const u32* pending, unsigned n_pending, unsigned bits);
 // quotient_values (src/prover.rs:756-962) on the quotient domain; q_evals: (n q) x 4 in natural order
 struct BQuotientIn {
   const BProgram* prog;

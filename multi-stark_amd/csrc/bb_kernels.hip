@@ -659,6 +659,47 @@ E4 bb_claims_accumulator(Ctx& ctx, const u32* d_data_monty, const u64* d_offs, s
   return total;
 }
 
+// DuplexChallenger::grind: the smallest w with sample_bits(bits) == 0 after observe(w). With `pending` values queued,
+// the trial is: overwrite state[..pending] with them, state[pending] = w, permute, take the last rate word.
+struct GrindArgs {
+  u32 state[16];  // sponge state with the queued values already written over its first words
+  u32 slot;       // where the witness goes
+  u32 mask;
+  u32 base, count;
+};
+__global__ __launch_bounds__(256) void grind_k(GrindArgs a, const Poseidon2* __restrict__ perm, u32* __restrict__ best) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.count) return;
+  u32 w = a.base + i;
+  u32 st[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) st[k] = a.state[k];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if ((u32)k == a.slot) st[k] = bb_to_monty(w);
+  bb_poseidon2(*perm, st);
+  if ((bb_from_monty(st[7]) & a.mask) == 0) atomicMin(best, w);
+}
+u32 bb_grind(Ctx& ctx, const Poseidon2* d_perm, const u32* state16, const u32* pending, unsigned n_pending, unsigned bits) {
+  GrindArgs a;
+  for (int k = 0; k < 16; k++) a.state[k] = state16[k];
+  for (unsigned k = 0; k < n_pending; k++) a.state[k] = pending[k];
+  a.slot = n_pending;
+  a.mask = (1u << bits) - 1;
+  DBuf<u32> best(ctx, 1);
+  const u32 batch = 1u << 18;
+  for (u64 base = 0; base < BB_P; base += batch) {
+    u32 init = 0xffffffffu, found;
+    ctx.h2d(best.p, &init, 4);
+    a.base = (u32)base;
+    a.count = (u32)std::min<u64>(batch, BB_P - base);
+    grind_k<<<blocks_for(a.count, 256), 256, 0, ctx.stream>>>(a, d_perm, best.p);
+    ctx.d2h(&found, best.p, 4);
+    if (found != 0xffffffffu) return found;
+  }
+  throw std::runtime_error("grind: no witness");
+}
+
 // ------------------------------------------------------------------ quotient (src/prover.rs:756-962)
 struct QuotArgs {
   const u32 *kind, *na, *nb;

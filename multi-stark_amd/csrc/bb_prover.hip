@@ -400,6 +400,17 @@ struct FriOut {
   std::vector<uint8_t> query_bytes;  // the serialised Vec<QueryProof> body (without its length)
 };
 
+// challenger.grind(bits): from 8 bits on the search runs on the device (one permutation per candidate); the host
+// challenger then replays the winning witness and checks it
+u32 grind(BSystem& sys, Challenger& ch, unsigned bits) {
+  if (bits < 8) return ch.grind(bits);
+  if (ch.input.size() >= 8) throw std::runtime_error("grind: challenger queue full");
+  u32 w = bb_grind(*sys.ctx, sys.d_perm.p, ch.state, ch.input.data(), (unsigned)ch.input.size(), bits);
+  ch.observe(bb_to_monty(w));
+  if (ch.sample_bits(bits) != 0) throw std::runtime_error("grind: device witness rejected by the host challenger");
+  return w;
+}
+
 // TwoAdicFriPcs::open + prove_fri (p3-fri 0.5.1: open, prover::prove_fri / commit_phase / answer_query, TwoAdicFriFolding)
 void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, FriOut& fri) {
   Ctx& ctx = *sys.ctx;
@@ -522,7 +533,7 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
     std::vector<Digest8> cap = tree_cap(ctx, fri_trees.back());
     ch.observe_cap(cap);
     fri.commits.push_back(cap);
-    fri.pow_witnesses.push_back(ch.grind((unsigned)prm.commit_pow_bits));
+    fri.pow_witnesses.push_back(grind(sys, ch, (unsigned)prm.commit_pow_bits));
     E4 beta = ch.sample_e4();
     const E4* roll = nullptr;
     if (next_in < inputs.size() && inputs[next_in].second == rows) roll = inputs[next_in++].first;
@@ -558,7 +569,7 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
       ch.observe_e4(fri.final_poly[k]);
     }
   }
-  fri.query_pow_witness = ch.grind((unsigned)prm.query_pow_bits);
+  fri.query_pow_witness = grind(sys, ch, (unsigned)prm.query_pow_bits);
 
   // ---- query phase: one gather of every opened row, sibling value and authentication path
   std::vector<GatherSeg> segs;

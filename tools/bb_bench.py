@@ -1,7 +1,7 @@
 """Timing of BASELINE config 4 (BabyBear / Poseidon2, MulAir at 2^LOG rows, the reference's test-suite parameters):
 ms per proof and trace rows per second with the witness resident in HBM, per-stage host clocks, and - with --oracle -
 the CPU restatement on the same input beside it. Not the bench line (bench.py measures config 2); a parity-test
-configuration measured for the record.   usage: python3 tools/bb_bench.py [LOG_ROWS=20] [STEPS=10] [--oracle]"""
+configuration measured for the record.   usage: python3 tools/bb_bench.py [LOG_ROWS=20] [STEPS=10] [--oracle] [--bench-params]"""
 import json
 import os
 import sys
@@ -22,7 +22,8 @@ def main():
     ctx = pkg.Context(0)
     K = fe.poseidon2_constants()
     with fe.field(fe.BABYBEAR):
-        g = bb.System.new(ctx, fe.test_params(), fe.mul_air_inputs(), K)
+        params = fe.bench_params() if "--bench-params" in sys.argv else fe.test_params()  # blowup 4, 100 queries, 10 + 10 PoW bits
+        g = bb.System.new(ctx, params, fe.mul_air_inputs(), K)
         trace = fe.mul_air_trace(1 << log_rows)
         packed = fe.pack_claims([])
     w = g.witness([trace], packed)
@@ -37,7 +38,8 @@ def main():
             stages[k] = stages.get(k, 0.0) + v / steps
     ms = (time.perf_counter() - t0) * 1e3 / steps
     assert g.verify(packed, proof.to_bytes()) == 0, "the library's own verifier rejects the proof"
-    rec = {"workload": "config 4: MulAir 2^%d rows, BabyBear/Ext4/Poseidon2, blowup 2, 64 queries" % log_rows, "ms_per_proof": round(ms, 3),
+    rec = {"workload": "config 4: MulAir 2^%d rows, BabyBear/Ext4/Poseidon2, %s" % (
+        log_rows, "blowup 4, 100 queries, 10 + 10 proof-of-work bits" if "--bench-params" in sys.argv else "blowup 2, 64 queries"), "ms_per_proof": round(ms, 3),
            "trace_rows_per_s": round((1 << log_rows) / ms * 1e3), "proof_bytes": len(proof.to_bytes()),
            "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
     if "--oracle" in sys.argv:
