@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 #include "../../include/mstark_bb.h"
 #include "bb.h"
@@ -1433,9 +1434,12 @@ struct PermHolder {
   Poseidon2* dev = nullptr;
   bool set = false;
 };
-static PermHolder& perm_holder() {
-  static PermHolder h;
-  return h;
+// one permutation per device (msbb_set_poseidon2 on a context of that device); contexts may live on different threads
+static std::mutex g_perm_mu;
+static PermHolder& perm_holder(int device) {
+  static std::map<int, PermHolder> h;
+  std::lock_guard<std::mutex> lock(g_perm_mu);
+  return h[device];
 }
 
 #define BB_TRY try {
@@ -1530,7 +1534,8 @@ int32_t msbb_verify(msbb_system* sys, size_t n_claims, const uint64_t* claim_off
 int32_t msbb_set_poseidon2(ms_ctx* ctx, const uint32_t* k141) {
   BB_TRY
   Ctx& c = *msamd::ctx_of(ctx);
-  PermHolder& h = perm_holder();
+  HIP_CHECK(hipSetDevice(c.device));
+  PermHolder& h = perm_holder(c.device);
   for (int i = 0; i < 141; i++)
     if (k141[i] >= BB_P) throw std::runtime_error("non-canonical round constant");
   for (int r = 0; r < 8; r++)
@@ -1544,14 +1549,16 @@ int32_t msbb_set_poseidon2(ms_ctx* ctx, const uint32_t* k141) {
   return MS_OK;
   BB_CATCH
 }
-static const Poseidon2* need_perm() {
-  if (!perm_holder().set) throw std::runtime_error("msbb_set_poseidon2 has not been called");
-  return perm_holder().dev;
+static const Poseidon2* need_perm(Ctx& c) {
+  PermHolder& h = perm_holder(c.device);
+  if (!h.set) throw std::runtime_error("msbb_set_poseidon2 has not been called for this device");
+  return h.dev;
 }
 int32_t msbb_poseidon2_permute(ms_ctx* ctx, uint32_t* states, size_t n) {
   BB_TRY
   Ctx& c = *msamd::ctx_of(ctx);
-  const Poseidon2* perm = need_perm();
+  HIP_CHECK(hipSetDevice(c.device));
+  const Poseidon2* perm = need_perm(c);
   if (!n) return MS_OK;
   std::vector<u32> m(16 * n);
   for (size_t i = 0; i < 16 * n; i++) {
@@ -1569,6 +1576,7 @@ int32_t msbb_poseidon2_permute(ms_ctx* ctx, uint32_t* states, size_t n) {
 int32_t msbb_dft_batch(ms_ctx* ctx, const uint32_t* in, size_t h, size_t w, int32_t inverse, uint32_t* out) {
   BB_TRY
   Ctx& c = *msamd::ctx_of(ctx);
+  HIP_CHECK(hipSetDevice(c.device));
   if (h == 0 || (h & (h - 1))) throw std::runtime_error("height must be a power of two");
   if (!w) return MS_OK;
   unsigned log_h = log2_strict(h);
@@ -1591,6 +1599,7 @@ int32_t msbb_dft_batch(ms_ctx* ctx, const uint32_t* in, size_t h, size_t w, int3
 int32_t msbb_coset_lde_batch(ms_ctx* ctx, const uint32_t* in, size_t h, size_t w, uint32_t log_blowup, uint32_t* out) {
   BB_TRY
   Ctx& c = *msamd::ctx_of(ctx);
+  HIP_CHECK(hipSetDevice(c.device));
   if (h == 0 || (h & (h - 1))) throw std::runtime_error("height must be a power of two");
   if (log2_strict(h) + log_blowup > BB_TWO_ADICITY) throw std::runtime_error("LDE taller than the two-adicity of BabyBear");
   if (!w) return MS_OK;
@@ -1605,7 +1614,8 @@ int32_t msbb_mmcs_commit(ms_ctx* ctx, size_t n, const uint32_t* const* mats, con
                          uint32_t cap_height, uint32_t* cap_out, msbb_mmcs** out) {
   BB_TRY
   Ctx& c = *msamd::ctx_of(ctx);
-  const Poseidon2* perm = need_perm();
+  HIP_CHECK(hipSetDevice(c.device));
+  const Poseidon2* perm = need_perm(c);
   std::unique_ptr<msbb_mmcs> h(new msbb_mmcs());
   h->ctx = &c;
   std::vector<BMat> ms(n);
@@ -1623,6 +1633,7 @@ int32_t msbb_mmcs_commit(ms_ctx* ctx, size_t n, const uint32_t* const* mats, con
 int32_t msbb_mmcs_open(msbb_mmcs* m, size_t index, uint32_t* vals_out, uint32_t* proof_out, size_t* n_siblings) {
   BB_TRY
   Ctx& c = *m->ctx;
+  HIP_CHECK(hipSetDevice(c.device));
   const BTree& t = m->data.tree;
   unsigned log_max = log2_strict(t.sizes[0]);
   if (index >= t.sizes[0]) throw std::runtime_error("index out of range");
