@@ -702,6 +702,32 @@ def pythagorean_trace(rows):
     return np.tile(base, (reps, 1))[:rows].copy()
 
 
+def verifier_test_inputs():
+    """[CS::Pythagorean, CS::Complex] of the verifier's own tests, src/verifier.rs:718-782: a (a^2 + b^2) = a c^2 (the extra
+    factor raises the constraint degree to 3) and the complex product (a + ib)(c + id) = e + if; no lookups."""
+    def pyth(b):
+        local, _ = b.main()
+        b.assert_eq(local[0] * (local[0] * local[0] + local[1] * local[1]), local[0] * (local[2] * local[2]))
+
+    def cplx(b):
+        local, _ = b.main()
+        b.assert_eq(local[0] * local[2] - local[1] * local[3], local[4])
+        b.assert_eq(local[0] * local[3] + local[1] * local[2], local[5])
+
+    return [lookup_air(3, pyth, []), lookup_air(6, cplx, [])]
+
+
+def verifier_test_traces(doublings=0):
+    """src/verifier.rs:787-797 (4 + 2 rows); `doublings` = 4 gives the 16-row traces of :806-813 (one row repeated)"""
+    if doublings:
+        py, cx = [3, 4, 5], [4, 2, 3, 1, 10, 10]
+        for _ in range(doublings):
+            py, cx = py + py, cx + cx
+        return [np.array(py, dtype=np.uint64).reshape(-1, 3), np.array(cx, dtype=np.uint64).reshape(-1, 6)]
+    return [np.array([3, 4, 5, 5, 12, 13, 8, 15, 17, 7, 24, 25], dtype=np.uint64).reshape(4, 3),
+            np.array([4, 2, 3, 1, 10, 10, 3, 2, 5, 1, 13, 13], dtype=np.uint64).reshape(2, 6)]
+
+
 def even_odd_inputs(with_dead=False):
     """src/lookup.rs:868-947 (Even / Odd / Dead circuits)."""
     var = Expr.main

@@ -1,0 +1,145 @@
+"""Proof::to_bytes <-> Python structure for GoldilocksBlake3Config (the layout of src/prover.rs:201-248 as restated in
+oracle/oracle_core.cpp proof_to_bytes): lets the tests tamper with a proof FIELD-wise the way the reference's verifier
+tests do (src/verifier.rs:852-912: `proof.stage_1_opened_values[0][0][0] += ONE`, `proof.log_degrees.pop()`, ...).
+Test infrastructure only."""
+import struct
+
+
+class _R:
+    def __init__(self, b):
+        self.b, self.o = b, 0
+
+    def u8(self):
+        v = self.b[self.o]
+        self.o += 1
+        return v
+
+    def u64(self):
+        v = struct.unpack_from("<Q", self.b, self.o)[0]
+        self.o += 8
+        return v
+
+    def raw(self, n):
+        v = bytes(self.b[self.o:self.o + n])
+        self.o += n
+        return v
+
+    def ext(self):
+        return [self.u64(), self.u64()]
+
+    def cap(self):
+        return [self.raw(32) for _ in range(self.u64())]
+
+    def round(self):
+        return [[[self.ext() for _ in range(self.u64())] for _ in range(self.u64())] for _ in range(self.u64())]
+
+
+class _W:
+    def __init__(self):
+        self.p = []
+
+    def u8(self, v):
+        self.p.append(struct.pack("<B", v))
+
+    def u64(self, v):
+        self.p.append(struct.pack("<Q", v))
+
+    def ext(self, e):
+        self.u64(e[0])
+        self.u64(e[1])
+
+    def cap(self, c):
+        self.u64(len(c))
+        self.p.extend(c)
+
+    def round(self, r):
+        self.u64(len(r))
+        for m in r:
+            self.u64(len(m))
+            for pt in m:
+                self.u64(len(pt))
+                for e in pt:
+                    self.ext(e)
+
+
+def parse(b):
+    r = _R(b)
+    p = {"active": [r.u8() for _ in range(r.u64())]}
+    p["stage_1_commit"], p["stage_2_commit"], p["quotient_commit"] = r.cap(), r.cap(), r.cap()
+    p["intermediate_accumulators"] = [r.ext() for _ in range(r.u64())]
+    p["log_degrees"] = [r.u8() for _ in range(r.u64())]
+    fri = {"commit_phase_commits": [r.cap() for _ in range(r.u64())], "commit_pow_witnesses": [r.u64() for _ in range(r.u64())]}
+    qs = []
+    for _ in range(r.u64()):
+        q = {"input_proof": [], "commit_phase_openings": []}
+        for _ in range(r.u64()):
+            rows = [[r.u64() for _ in range(r.u64())] for _ in range(r.u64())]
+            q["input_proof"].append({"opened_values": rows, "proof": [r.raw(32) for _ in range(r.u64())]})
+        for _ in range(r.u64()):
+            la = r.u8()
+            sib = [r.ext() for _ in range(r.u64())]
+            q["commit_phase_openings"].append({"log_arity": la, "sibling_values": sib, "proof": [r.raw(32) for _ in range(r.u64())]})
+        qs.append(q)
+    fri["query_proofs"] = qs
+    fri["final_poly"] = [r.ext() for _ in range(r.u64())]
+    fri["query_pow_witness"] = r.u64()
+    p["opening_proof"] = fri
+    p["quotient_opened_values"] = r.round()
+    p["preprocessed_opened_values"] = r.round() if r.u8() else None
+    p["stage_1_opened_values"] = r.round()
+    p["stage_2_opened_values"] = r.round()
+    assert r.o == len(b), "trailing bytes"
+    return p
+
+
+def serialize(p):
+    w = _W()
+    w.u64(len(p["active"]))
+    for a in p["active"]:
+        w.u8(a)
+    w.cap(p["stage_1_commit"]), w.cap(p["stage_2_commit"]), w.cap(p["quotient_commit"])
+    w.u64(len(p["intermediate_accumulators"]))
+    for e in p["intermediate_accumulators"]:
+        w.ext(e)
+    w.u64(len(p["log_degrees"]))
+    for d in p["log_degrees"]:
+        w.u8(d)
+    f = p["opening_proof"]
+    w.u64(len(f["commit_phase_commits"]))
+    for c in f["commit_phase_commits"]:
+        w.cap(c)
+    w.u64(len(f["commit_pow_witnesses"]))
+    for x in f["commit_pow_witnesses"]:
+        w.u64(x)
+    w.u64(len(f["query_proofs"]))
+    for q in f["query_proofs"]:
+        w.u64(len(q["input_proof"]))
+        for bo in q["input_proof"]:
+            w.u64(len(bo["opened_values"]))
+            for row in bo["opened_values"]:
+                w.u64(len(row))
+                for x in row:
+                    w.u64(x)
+            w.u64(len(bo["proof"]))
+            w.p.extend(bo["proof"])
+        w.u64(len(q["commit_phase_openings"]))
+        for s in q["commit_phase_openings"]:
+            w.u8(s["log_arity"])
+            w.u64(len(s["sibling_values"]))
+            for e in s["sibling_values"]:
+                w.ext(e)
+            w.u64(len(s["proof"]))
+            w.p.extend(s["proof"])
+    w.u64(len(f["final_poly"]))
+    for e in f["final_poly"]:
+        w.ext(e)
+    w.u64(f["query_pow_witness"])
+    w.round(p["quotient_opened_values"])
+    if p["preprocessed_opened_values"] is None:
+        w.u8(0)
+    else:
+        w.u8(1)
+        w.round(p["preprocessed_opened_values"])
+    w.round(p["stage_1_opened_values"])
+    w.round(p["stage_2_opened_values"])
+    return b"".join(w.p)
