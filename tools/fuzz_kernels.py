@@ -3,6 +3,8 @@ random shapes for ms_dft_batch, ms_coset_lde_batch, ms_quotient_lde, ms_mmcs_com
 ms_claims_accumulator and ms_blake3, each compared bit for bit with the oracle.
 
 usage: python3 tools/fuzz_kernels.py [N_CASES_PER_ENTRY_POINT] [SEED]
+       FUZZ_FIELD=babybear python3 tools/fuzz_kernels.py ...   the msbb_* entry points (include/mstark_bb.h) against
+       oracle/libms_oracle_bb.so: transforms, coset LDE, Poseidon2 permutation, Merkle commit / open
 The oracle is used only as the checker."""
 import os
 import sys
@@ -25,9 +27,66 @@ def rand_field(rng, shape):
     return np.where(mask, edge[rng.integers(0, len(edge), shape)], v)
 
 
+def main_babybear(n, seed):
+    pkg = load_package()
+    import oracle_bb as ob
+
+    bb, fe = pkg.babybear, pkg.frontend
+    PB = fe.BABYBEAR["P"]
+    ctx = pkg.Context(0)
+    K = fe.poseidon2_constants(seed)
+    bb.set_poseidon2(ctx, K)
+    ob.set_poseidon2(K)
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+
+    def rf(shape):
+        v = rng.integers(0, PB, shape, dtype=np.uint64)
+        edge = np.array([0, 1, 2, PB - 1, PB - 2, 1 << 27, (1 << 27) + 1, 1 << 30], dtype=np.uint64)
+        return np.where(rng.random(shape) < 0.1, edge[rng.integers(0, len(edge), shape)], v)
+
+    def done(what, k):
+        print("[fuzz %6.1fs] %-28s %d cases identical" % (time.time() - t0, what, k), flush=True)
+
+    for _ in range(n):
+        log_h = int(rng.choice([0, 1, 2, 3, 4, 6, 7, 9, 11, 12, 13, 14, 15, 17, 18, 19, 20, 21]))
+        m = rf((1 << log_h, int(rng.integers(1, 4 if log_h > 16 else 30))))
+        inv = bool(rng.integers(0, 2))
+        assert np.array_equal(bb.dft_batch(ctx, m, inverse=inv), ob.dft_batch(m, inverse=inv)), ("dft", log_h, inv)
+    done("msbb_dft_batch", n)
+    for _ in range(n):
+        log_h, lb = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 12, 13, 14, 16, 17])), int(rng.integers(1, 4))
+        m = rf((1 << log_h, int(rng.integers(1, 4 if log_h > 14 else 30))))
+        assert np.array_equal(bb.coset_lde_batch(ctx, m, lb), ob.coset_lde_bitrev(m, lb)), ("lde", log_h, lb)
+    done("msbb_coset_lde_batch", n)
+    for _ in range(n):
+        st = rf((int(rng.integers(1, 40)), 16))
+        got = bb.poseidon2_permute(ctx, st)
+        assert all(np.array_equal(got[i], ob.poseidon2_permute(st[i])) for i in range(st.shape[0]))
+    done("msbb_poseidon2_permute", n)
+    for _ in range(n):  # 1-6 matrices, mixed heights up to 2^17 (one-lane, 16-lane and one-launch layers; injections), wide rows, caps
+        nm = int(rng.integers(1, 7))
+        top = int(rng.choice([3, 8, 12, 16, 17]))
+        shapes = [(1 << int(rng.integers(0, top + 1)), int(rng.integers(1, 120 if rng.random() < 0.15 else 20))) for _ in range(nm)]
+        shapes = [(h, w if h <= 4096 else min(w, 12)) for h, w in shapes]
+        cap_h = int(rng.integers(0, 4))
+        mats = [rf(sh) for sh in shapes]
+        g, o = bb.Mmcs(ctx, mats, cap_h), ob.Mmcs(mats, cap_h)
+        assert np.array_equal(g.cap, np.frombuffer(o.cap, dtype=np.uint32)), ("mmcs cap", shapes, cap_h)
+        maxh = max(sh[0] for sh in shapes)
+        for index in {0, maxh - 1, int(rng.integers(0, maxh))}:
+            gv, gp = g.open(index)
+            ov, op = o.open(index)
+            assert np.array_equal(gv, ov) and np.array_equal(gp, np.frombuffer(op, dtype=np.uint32)), ("mmcs open", shapes, cap_h, index)
+    done("msbb_mmcs_commit / open", n)
+    print("OK: %d random cases per BabyBear entry point, every result identical to the oracle's" % n)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if os.environ.get("FUZZ_FIELD", "") == "babybear":
+        return main_babybear(n, seed)
     pkg = load_package()
     import oracle
 
