@@ -106,6 +106,57 @@ __global__ __launch_bounds__(256) void ntt_strided_k(u32* __restrict__ data, siz
   }
   for (unsigned e = threadIdx.x; e < (1u << K) * T; e += 256) col[base + ((size_t)(e / T) << sbits) + (e % T)] = s[e];
 }
+// Eight DIF layers [l0, l0 + 8) per pass with the data in registers: a tile is 256 values of the "middle" index bits x 16
+// consecutive low indices; every thread runs two rounds of four layers on 16 values it holds (one LDS exchange between
+// the rounds, padded to stay conflict-free). The twiddle of layer u of a round factors into a per-thread root A^(2^u)
+// (one table load, then squarings) and a 16th root of unity that depends only on the register index (8 constants), so a
+// round costs 46 multiplications per 16 values and no twiddle traffic.
+__device__ __forceinline__ void r16_round(u32 (&x)[16], u32 A, const u32 (&C)[8]) {
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int half = 8 >> u;
+    u32 T[8];
+    T[0] = A;
+#pragma unroll
+    for (int jl = 1; jl < half; jl++) T[jl] = bb_mul(A, C[jl << u]);
+#pragma unroll
+    for (int blk = 0; blk < 16; blk += 2 * half)
+#pragma unroll
+      for (int jl = 0; jl < half; jl++) {
+        u32 a = x[blk + jl], b = x[blk + jl + half];
+        x[blk + jl] = bb_add(a, b);
+        x[blk + jl + half] = bb_mul(bb_sub(a, b), T[jl]);
+      }
+    A = bb_mul(A, A);
+  }
+}
+template <int LO>  // consecutive low indices per tile: 16 (64-byte runs) or 32 (128-byte runs)
+__global__ __launch_bounds__(16 * LO) void ntt_r16_k(u32* __restrict__ data, size_t ld, unsigned n, unsigned l0, const u32* __restrict__ tw) {
+  __shared__ u32 sh[256 * LO + 16 * LO];
+  u32* col = data + (size_t)blockIdx.y * ld;
+  const unsigned sbits = n - l0 - 8;
+  const size_t lo_tiles = (size_t(1) << sbits) / LO;
+  const size_t H = blockIdx.x / lo_tiles, lo0 = (blockIdx.x % lo_tiles) * LO;
+  const size_t base = (H << (n - l0)) + lo0;
+  const unsigned lo = threadIdx.x % LO, q = threadIdx.x / LO;
+  u32 C[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) C[k] = tw[(size_t)k << (n - 4)];  // 16th roots of unity
+  u32 x[16];
+  // round 1: layers l0 .. l0 + 3; my values: middle index (j << 4) | q
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = col[base + ((size_t)((j << 4) | q) << sbits) + lo];
+  r16_round(x, tw[(((size_t)q << sbits) | (lo0 + lo)) << l0], C);
+#pragma unroll
+  for (int j = 0; j < 16; j++) sh[((j << 4) | q) * LO + lo + j * LO] = x[j];  // LO words of padding per 16 middle values
+  __syncthreads();
+  // round 2: layers l0 + 4 .. l0 + 7; my values: middle index (q << 4) | k
+#pragma unroll
+  for (int k = 0; k < 16; k++) x[k] = sh[((q << 4) | k) * LO + lo + q * LO];
+  r16_round(x, tw[(size_t)(lo0 + lo) << (l0 + 4)], C);
+#pragma unroll
+  for (int k = 0; k < 16; k++) col[base + ((size_t)((q << 4) | k) << sbits) + lo] = x[k];
+}
 // last layers [l0, n) on contiguous tiles of `ts` = min(4096, 2^n) elements (whole groups of 2^(n - l0) elements)
 __global__ __launch_bounds__(256) void ntt_contig_k(u32* __restrict__ data, size_t ld, unsigned n, unsigned l0, unsigned log_ts, const u32* __restrict__ tw) {
   __shared__ u32 s[4096];
@@ -133,11 +184,23 @@ void bb_dif(Ctx& ctx, u32* data, size_t ld, unsigned n, size_t ncols) {
   if (n > BB_TWO_ADICITY) throw std::runtime_error("transform larger than the two-adicity of BabyBear");
   const u32* tw = twiddles(ctx, n);
   unsigned l0 = 0;
-  while (n - l0 > 12) {  // 7 layers per strided pass; the rest (6..12 layers) in the contiguous pass
+  static const bool lds_passes = getenv("MSBB_NTT_LDS") != nullptr;  // the plain LDS radix-2 passes (tests)
+  while (!lds_passes && n - l0 >= 12) {  // eight layers per register pass (the low index keeps >= 4 bits: 64-byte runs)
+    if (n - l0 >= 13) {
+      dim3 grid((unsigned)((size_t(1) << n) >> 13), (unsigned)ncols);
+      ntt_r16_k<32><<<grid, 512, 0, ctx.stream>>>(data, ld, n, l0, tw);
+    } else {
+      dim3 grid((unsigned)((size_t(1) << n) >> 12), (unsigned)ncols);
+      ntt_r16_k<16><<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, tw);
+    }
+    l0 += 8;
+  }
+  while (n - l0 > 12) {  // 7 layers per LDS pass
     dim3 grid((unsigned)((size_t(1) << n) >> 12), (unsigned)ncols);
     ntt_strided_k<7, 32><<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, tw);
     l0 += 7;
   }
+  if (l0 == n) return;
   unsigned log_ts = std::min(n, 12u);
   dim3 grid((unsigned)((size_t(1) << n) >> log_ts), (unsigned)ncols);
   ntt_contig_k<<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, log_ts, tw);
