@@ -184,7 +184,7 @@ void bb_dif(Ctx& ctx, u32* data, size_t ld, unsigned n, size_t ncols) {
   if (n > BB_TWO_ADICITY) throw std::runtime_error("transform larger than the two-adicity of BabyBear");
   const u32* tw = twiddles(ctx, n);
   unsigned l0 = 0;
-  static const bool lds_passes = getenv("MSBB_NTT_LDS") != nullptr;  // the plain LDS radix-2 passes (tests)
+  const bool lds_passes = getenv("MSBB_NTT_LDS") != nullptr;  // the plain LDS radix-2 passes (tests)
   while (!lds_passes && n - l0 >= 12) {  // eight layers per register pass (the low index keeps >= 4 bits: 64-byte runs)
     if (n - l0 >= 13) {
       dim3 grid((unsigned)((size_t(1) << n) >> 13), (unsigned)ncols);

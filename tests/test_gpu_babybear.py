@@ -63,13 +63,21 @@ def test_poseidon2_permutation(ctx):
         assert [int(x) for x in got[i]] == [int(x) for x in ob.poseidon2_permute(st[i])]
 
 
-@pytest.mark.parametrize("log_h", [0, 1, 3, 7, 11, 12, 13, 15, 19, 20])
+@pytest.mark.parametrize("log_h", [0, 1, 3, 7, 11, 12, 13, 15, 16, 19, 20, 21, 22])
 def test_dft_batch(ctx, log_h):
     rng = np.random.default_rng(log_h)
     w = 3 if log_h > 14 else 9
     m = rand_field(rng, (1 << log_h, w))
     for inv in (False, True):
         assert np.array_equal(bb.dft_batch(ctx, m, inverse=inv), ob.dft_batch(m, inverse=inv)), (log_h, inv)
+
+
+@pytest.mark.parametrize("log_h", [13, 16, 21])
+def test_dft_batch_lds_passes(ctx, monkeypatch, log_h):
+    """the plain LDS radix-2 passes (MSBB_NTT_LDS=1) that the register passes replaced"""
+    monkeypatch.setenv("MSBB_NTT_LDS", "1")
+    m = rand_field(np.random.default_rng(log_h), (1 << log_h, 2))
+    assert np.array_equal(bb.dft_batch(ctx, m), ob.dft_batch(m))
 
 
 @pytest.mark.parametrize("log_h,lb", [(0, 1), (2, 1), (5, 3), (10, 2), (12, 1), (13, 2), (16, 1), (18, 2)])
