@@ -1,8 +1,11 @@
 """Proof::to_bytes <-> Python structure for GoldilocksBlake3Config (the layout of src/prover.rs:201-248 as restated in
 oracle/oracle_core.cpp proof_to_bytes): lets the tests tamper with a proof FIELD-wise the way the reference's verifier
 tests do (src/verifier.rs:852-912: `proof.stage_1_opened_values[0][0][0] += ONE`, `proof.log_degrees.pop()`, ...).
+`parse(b, elem_bytes=4, ext_degree=4)` reads the BabyBear / Poseidon2 configuration's proofs (elements = Montgomery words).
 Test infrastructure only."""
 import struct
+
+_ELEM, _DEG = 8, 2  # set by parse / serialize
 
 
 class _R:
@@ -19,13 +22,18 @@ class _R:
         self.o += 8
         return v
 
+    def fe(self):
+        v = int.from_bytes(self.b[self.o:self.o + _ELEM], "little")
+        self.o += _ELEM
+        return v
+
     def raw(self, n):
         v = bytes(self.b[self.o:self.o + n])
         self.o += n
         return v
 
     def ext(self):
-        return [self.u64(), self.u64()]
+        return [self.fe() for _ in range(_DEG)]
 
     def cap(self):
         return [self.raw(32) for _ in range(self.u64())]
@@ -44,9 +52,12 @@ class _W:
     def u64(self, v):
         self.p.append(struct.pack("<Q", v))
 
+    def fe(self, v):
+        self.p.append(int(v).to_bytes(_ELEM, "little"))
+
     def ext(self, e):
-        self.u64(e[0])
-        self.u64(e[1])
+        for c in e:
+            self.fe(c)
 
     def cap(self, c):
         self.u64(len(c))
@@ -62,18 +73,20 @@ class _W:
                     self.ext(e)
 
 
-def parse(b):
+def parse(b, elem_bytes=8, ext_degree=2):
+    global _ELEM, _DEG
+    _ELEM, _DEG = elem_bytes, ext_degree
     r = _R(b)
     p = {"active": [r.u8() for _ in range(r.u64())]}
     p["stage_1_commit"], p["stage_2_commit"], p["quotient_commit"] = r.cap(), r.cap(), r.cap()
     p["intermediate_accumulators"] = [r.ext() for _ in range(r.u64())]
     p["log_degrees"] = [r.u8() for _ in range(r.u64())]
-    fri = {"commit_phase_commits": [r.cap() for _ in range(r.u64())], "commit_pow_witnesses": [r.u64() for _ in range(r.u64())]}
+    fri = {"commit_phase_commits": [r.cap() for _ in range(r.u64())], "commit_pow_witnesses": [r.fe() for _ in range(r.u64())]}
     qs = []
     for _ in range(r.u64()):
         q = {"input_proof": [], "commit_phase_openings": []}
         for _ in range(r.u64()):
-            rows = [[r.u64() for _ in range(r.u64())] for _ in range(r.u64())]
+            rows = [[r.fe() for _ in range(r.u64())] for _ in range(r.u64())]
             q["input_proof"].append({"opened_values": rows, "proof": [r.raw(32) for _ in range(r.u64())]})
         for _ in range(r.u64()):
             la = r.u8()
@@ -82,7 +95,7 @@ def parse(b):
         qs.append(q)
     fri["query_proofs"] = qs
     fri["final_poly"] = [r.ext() for _ in range(r.u64())]
-    fri["query_pow_witness"] = r.u64()
+    fri["query_pow_witness"] = r.fe()
     p["opening_proof"] = fri
     p["quotient_opened_values"] = r.round()
     p["preprocessed_opened_values"] = r.round() if r.u8() else None
@@ -92,7 +105,9 @@ def parse(b):
     return p
 
 
-def serialize(p):
+def serialize(p, elem_bytes=8, ext_degree=2):
+    global _ELEM, _DEG
+    _ELEM, _DEG = elem_bytes, ext_degree
     w = _W()
     w.u64(len(p["active"]))
     for a in p["active"]:
@@ -110,7 +125,7 @@ def serialize(p):
         w.cap(c)
     w.u64(len(f["commit_pow_witnesses"]))
     for x in f["commit_pow_witnesses"]:
-        w.u64(x)
+        w.fe(x)
     w.u64(len(f["query_proofs"]))
     for q in f["query_proofs"]:
         w.u64(len(q["input_proof"]))
@@ -119,7 +134,7 @@ def serialize(p):
             for row in bo["opened_values"]:
                 w.u64(len(row))
                 for x in row:
-                    w.u64(x)
+                    w.fe(x)
             w.u64(len(bo["proof"]))
             w.p.extend(bo["proof"])
         w.u64(len(q["commit_phase_openings"]))
@@ -133,7 +148,7 @@ def serialize(p):
     w.u64(len(f["final_poly"]))
     for e in f["final_poly"]:
         w.ext(e)
-    w.u64(f["query_pow_witness"])
+    w.fe(f["query_pow_witness"])
     w.round(p["quotient_opened_values"])
     if p["preprocessed_opened_values"] is None:
         w.u8(0)

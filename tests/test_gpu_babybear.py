@@ -129,6 +129,13 @@ def test_reference_smoke_test(ctx):
     bad = bytearray(proof)
     bad[len(bad) // 2] ^= 4
     assert o.verify(packed, bytes(bad)) != 0
+    # the reference's own tamper: intermediate_accumulators[0] += ONE (baby_bear_config.rs:199-203), field-wise
+    import proof_codec as pc
+
+    t = pc.parse(proof, 4, 4)
+    t["intermediate_accumulators"][0][0] = (t["intermediate_accumulators"][0][0] + (1 << 32) % P) % P
+    tb = pc.serialize(t, 4, 4)
+    assert g.verify(packed, tb) == o.verify(packed, tb) == 6
 
 
 @pytest.mark.parametrize("params", [fe.Params(1, 0, 0, 1, 30, 0, 0), fe.Params(2, 1, 2, 1, 12, 3, 5), fe.Params(3, 2, 1, 1, 8, 6, 0),

@@ -249,3 +249,22 @@ def test_pcs_commit_open_verify_mixed_rounds(ctx, pkg, oracle, params):
     rounds = [[rand_field(rng, (1 << 10, 5)), rand_field(rng, (1 << 7, 2)), rand_field(rng, (1 << 10, 1))], [rand_field(rng, (1 << 9, 9))]]
     _pcs_scenario(ctx, pkg, oracle, params, rounds, -1)
     _pcs_scenario(ctx, pkg, oracle, params, rounds, 1)
+
+
+def test_pcs_open_error_paths(ctx, pkg):
+    params = _fe.Params(1, 0, 0, 1, 10, 0, 0)
+    c = pkg.PcsCommitment(ctx, [np.arange(64, dtype=np.uint64).reshape(32, 2)], 1, 0)
+    ch = pkg.Challenger(params)
+    ch.observe_digests(c.cap)
+    z = ch.sample_ext()
+    with pytest.raises(pkg.MstarkError):  # at most two opening points per matrix
+        pkg.pcs_open(ctx, params, [(c, [[z, z, z]])], ch)
+    with pytest.raises(pkg.MstarkError):  # non-canonical point
+        pkg.pcs_open(ctx, params, [(c, [[(P, 0)]])], pkg.Challenger(params))
+    with pytest.raises(pkg.MstarkError):  # unsupported folding arity
+        pkg.pcs_open(ctx, _fe.Params(1, 0, 0, 2, 10, 0, 0), [(c, [[z]])], pkg.Challenger(params))
+    with pytest.raises(pkg.MstarkError):
+        ch.observe([P])
+    # a matrix that is not taller than blowup * final polynomial length is refused (p3 prove_fri precondition)
+    with pytest.raises(pkg.MstarkError):
+        pkg.pcs_open(ctx, _fe.Params(1, 0, 5, 1, 10, 0, 0), [(c, [[z]])], pkg.Challenger(params))

@@ -192,6 +192,14 @@ def test_reference_smoke_test_mul_air():
             bad = bytearray(proof)
             bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
             assert o.verify(packed, bytes(bad)) != 0
+        # the reference's own tamper: tampered.intermediate_accumulators[0] += Challenge::ONE (baby_bear_config.rs:199-203)
+        import proof_codec as pc
+
+        t = pc.parse(proof, 4, 4)
+        assert pc.serialize(t, 4, 4) == proof
+        one_monty = (1 << 32) % P
+        t["intermediate_accumulators"][0][0] = (t["intermediate_accumulators"][0][0] + one_monty) % P
+        assert o.verify(packed, pc.serialize(t, 4, 4)) == 6  # UnbalancedChannel: the last accumulator is no longer zero
         wrong = fe.mul_air_smoke_trace()
         wrong[1, 2] = 21  # 4 * 5 != 21
         assert o.verify(packed, o.prove([wrong], packed)) == 5  # OodEvaluationMismatch
