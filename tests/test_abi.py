@@ -37,6 +37,16 @@ def test_babybear_header_symbols_are_exported(pkg):
     assert sorted(pkg.babybear.exported_symbols()) == declared
 
 
+def test_rust_binding_lists_every_symbol():
+    """bindings/rust/mstark_sys.rs (uncompiled source for the reference side) declares exactly the headers' entry points"""
+    rs = open(os.path.join(ROOT, "bindings", "rust", "mstark_sys.rs")).read()
+    declared = set(re.findall(r"pub fn ((?:ms|msbb)_[a-z0-9_]+)\(", rs))
+    want = set(_declared_symbols())
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mstark_bb.h")).read(), flags=re.S)
+    want |= set(re.findall(r"\b(msbb_[a-z0-9_]+)\s*\(", txt))
+    assert declared == want, (sorted(want - declared), sorted(declared - want))
+
+
 def test_kernel_names_available_without_gpu(pkg):
     L = pkg.lib()
     n = L.ms_kernel_count()
