@@ -104,6 +104,23 @@ Ctx::Ctx(int dev) : device(dev) {
   twci = tc + 4096;
   twc3 = tc + 8192;
   twc3i = tc + 8192 + 2048;
+  std::vector<u64> ff(8192, 0), fi(8192, 0);
+  for (unsigned r = 1; r <= 12; r++) {
+    u64 w = gl_two_adic_generator(r), wi = gl_inv(w), x = 1, y = 1;
+    size_t off = (size_t(1) << r) - 1;
+    for (size_t i = 0; i < (size_t(1) << r); i++) {
+      ff[off + i] = x;
+      fi[off + i] = y;
+      x = gl_mul(x, w);
+      y = gl_mul(y, wi);
+    }
+  }
+  u64* tf = nullptr;
+  HIP_CHECK(hipMalloc(&tf, 2 * 8192 * sizeof(u64)));
+  HIP_CHECK(hipMemcpy(tf, ff.data(), 8192 * sizeof(u64), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(tf + 8192, fi.data(), 8192 * sizeof(u64), hipMemcpyHostToDevice));
+  twf = tf;
+  twfi = tf + 8192;
 }
 
 Ctx::~Ctx() {
@@ -120,6 +137,7 @@ Ctx::~Ctx() {
   if (pinned) (void)hipHostFree(pinned);
   if (tw0) (void)hipFree(tw0);
   if (twc) (void)hipFree(twc);
+  if (twf) (void)hipFree(twf);
   (void)hipStreamDestroy(stream);
 }
 

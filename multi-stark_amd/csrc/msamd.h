@@ -65,6 +65,9 @@ struct Ctx {
   u64 *twc = nullptr, *twci = nullptr;
   // cubes for the radix-4 butterflies: table r (r = 2..12) holds w^(3i) for i < 2^(r-2) at offset 2^(r-2) - 1
   u64 *twc3 = nullptr, *twc3i = nullptr;
+  // full per-order tables: table r (r = 1..12) holds w^i for ALL i < 2^r at offset 2^r - 1 (the radix-16 rounds in
+  // "16-point network, then one twiddle per value" form need exponents up to 15/16 of the order)
+  u64 *twf = nullptr, *twfi = nullptr;
   // pooled device memory: exact-size buckets, reused across proofs
   std::multimap<size_t, void*> pool_free;
   std::map<void*, size_t> pool_live;

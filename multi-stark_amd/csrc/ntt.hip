@@ -240,6 +240,44 @@ __device__ __forceinline__ void reg_stages16_r4(u64 (&x)[16], u32 lo, unsigned s
   }
 }
 
+// The same four stages once more, as "16-point network with power-of-two twiddles, then one general multiplication per
+// value": the stage twiddle w_{2 half S}^{jl S + lo} factors into the uniform w_{2 half}^{jl} (a shift) and a per-thread
+// rho_s = w_{2 half S}^{lo}; along the network the rho factors of a value collect to rho^{rev4(j)}, rho = w_{16 S}^{lo}
+// (DIF: applied after the network; DIT: before it). 15 general multiplications per 16 values instead of 24.
+// twf = full per-order tables (every exponent below the order).
+#ifndef MSAMD_R16TW
+#define MSAMD_R16TW 1
+#endif
+template <bool DIT, bool INV>
+__device__ __forceinline__ void reg_stages16_tw(u64 (&x)[16], u32 lo, unsigned shift, const u64* __restrict__ twf) {
+  const u64* tab = twf + ((1u << (4 + shift)) - 1);
+  u64 w[16];
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    const int c = ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3);
+    w[j] = tab[(u32)c * lo];
+  }
+  if (DIT) {
+#pragma unroll
+    for (int j = 1; j < 16; j++) x[j] = gl_mul(x[j], w[j]);
+    reg_stages16_uniform<true, INV>(x);
+  } else {
+    reg_stages16_uniform<false, INV>(x);
+#pragma unroll
+    for (int j = 1; j < 16; j++) x[j] = gl_mul(x[j], w[j]);
+  }
+}
+// general round: either form (twx = cube tables for the radix-4 form, full tables for the radix-16 form)
+template <bool DIT, bool INV>
+__device__ __forceinline__ void reg_round16(u64 (&x)[16], u32 lo, unsigned shift, const u64* __restrict__ twc, const u64* __restrict__ twx) {
+#if MSAMD_R16TW
+  (void)twc;
+  reg_stages16_tw<DIT, INV>(x, lo, shift, twx);
+#else
+  reg_stages16_r4<DIT, INV>(x, lo, shift, twc, twx);
+#endif
+}
+
 __device__ __forceinline__ u32 pad_hi(u32 e) { return e + ((e >> 8) << 4); }  // 16 spare slots per 256
 __device__ __forceinline__ u32 pad_lo(u32 e) { return e + (e >> 4); }         // 1 spare slot per 16
 constexpr int NTT12_LDS = 4096 + 256 + 16;
@@ -264,13 +302,13 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
     x[j] = v;
   }
   if (!DIT) {
-    reg_stages16_r4<false, INV>(x, t, 8, twc, twc3);  // bits 11..8
+    reg_round16<false, INV>(x, t, 8, twc, twc3);  // bits 11..8
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi(t + 256 * j)] = x[j];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi(a * 256 + 16 * j + b)];
-    reg_stages16_r4<false, INV>(x, b, 4, twc, twc3);  // bits 7..4
+    reg_round16<false, INV>(x, b, 4, twc, twc3);  // bits 7..4
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_lo(a * 256 + 16 * j + b)] = x[j];
@@ -297,14 +335,14 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_lo(a * 256 + 16 * j + b)];
-    reg_stages16_r4<true, INV>(x, b, 4, twc, twc3);  // bits 4..7
+    reg_round16<true, INV>(x, b, 4, twc, twc3);  // bits 4..7
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi(a * 256 + 16 * j + b)] = x[j];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi(t + 256 * j)];
-    reg_stages16_r4<true, INV>(x, t, 8, twc, twc3);  // bits 8..11
+    reg_round16<true, INV>(x, t, 8, twc, twc3);  // bits 8..11
   }
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -347,7 +385,7 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
 #pragma unroll
       for (int j = 0; j < 16; j++) x[j] = gl_mul(x[j], sc[(size_t(hq + 16 * j) << logS) + lg]);
     }
-    reg_stages16_r4<false, INV>(x, hq, 4, twc, twc3);  // h bits 7..4
+    reg_round16<false, INV>(x, hq, 4, twc, twc3);  // h bits 7..4
 #pragma unroll
     for (int j = 0; j < 16; j++) sm[pad_hi((hq + 16 * j) * 16 + l)] = x[j];
     __syncthreads();
@@ -388,7 +426,7 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq + 16 * j) * 16 + l)];
-    reg_stages16_r4<true, INV>(x, hq, 4, twc, twc3);  // h bits 4..7
+    reg_round16<true, INV>(x, hq, 4, twc, twc3);  // h bits 4..7
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       u64 v = x[j];
@@ -454,10 +492,10 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
     const u64* ttab = ntt8s_table(ctx, logB, inverse);
     if (inverse)
       hipLaunchKernelGGL((ntt8s_k<(DIT != 0), true>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twci, ctx.twc3i, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul);
+                         logn, ctx.twci, MSAMD_R16TW ? ctx.twfi : ctx.twc3i, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul);
     else
       hipLaunchKernelGGL((ntt8s_k<(DIT != 0), false>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twc, ctx.twc3, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul);
+                         logn, ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul);
     ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
@@ -480,9 +518,9 @@ void launch_contig(Ctx& ctx, const u64* src, u64* dst, unsigned K, unsigned logn
     const int id = DIT ? K_NTT12_DIT : K_NTT12_DIF;
     hipEvent_t ev12 = ctx.prof_begin(id);
     if (inverse)
-      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, ctx.twc3i, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, MSAMD_R16TW ? ctx.twfi : ctx.twc3i, src_div, scale, out_mul);
     else
-      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, ctx.twc3, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, src_div, scale, out_mul);
     ctx.prof_end(id, ev12, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
