@@ -91,8 +91,11 @@ void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals);
 // ---- opening
 // 1 / (z - x_i) and x_i / (z - x_i) for the first h storage rows of the bit-reversed coset GENERATOR * H
 void bb_inv_denoms(Ctx& ctx, E4 z, unsigned log_h, size_t count, E4* d_inv, E4* d_wgt);
-// sum_i wgt[i] * m[i][c] over the first h rows, per column -> host (unscaled)
-void bb_bary(Ctx& ctx, const BMat& m, size_t h, const E4* d_wgt, std::vector<E4>& sums);
+// sum_i wgt[i] * m[i][c] over the first h rows, per column (unscaled): partial sums per row block on the device
+// (bb_bary_partials(w, h) values), read back once for all matrices and points, then summed on the host
+size_t bb_bary_partials(size_t w, size_t h);
+void bb_bary_launch(Ctx& ctx, const BMat& m, size_t h, const E4* d_wgt, E4* d_part);
+void bb_bary_finish(const E4* h_part, size_t w, size_t h, std::vector<E4>& sums);
 // ro[i] += sum_p dinv_p[i] * (K_p - off_p * sum_c apow[c] m[i][c])
 void bb_deep(Ctx& ctx, const BMat& m, const E4* d_apow, int npoints, const E4* const* d_inv, const E4* K, const E4* off, E4* d_ro);
 void bb_fri_fold(Ctx& ctx, const E4* cur, size_t rows_out, E4 beta, const E4* roll_in, E4* out);

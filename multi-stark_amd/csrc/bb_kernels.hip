@@ -233,8 +233,7 @@ void bb_coset_lde(Ctx& ctx, const BMat& evals, unsigned lb, BMat& out) {
   u32 n_inv = bb_inv(bb_to_monty((u32)(n % BB_P)));
   dim3 grid(blocks_for(N, 256), (unsigned)w);
   idft_gather_k<<<grid, 256, 0, ctx.stream>>>(tmp.p, n, log_n, out.buf.p, out.ld, N, n_inv, bb_to_monty(BB_GENERATOR));
-  bb_dif(ctx, out.buf.p, out.ld, log_n + lb, w);
-  ctx.sync();  // tmp goes back to the pool
+  bb_dif(ctx, out.buf.p, out.ld, log_n + lb, w);  // (tmp returns to the pool: reuse is ordered by the stream)
 }
 
 // shifted_quotient_slices + zero padding (src/prover.rs:631-679, 709-717): X = DFT(q) bit-reversed; padded column
@@ -886,7 +885,6 @@ void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals) {
     p.row0 = row0, p.rows = std::min(chunk, N - row0);
     quotient_k<<<blocks_for(p.rows, 256), 256, 0, ctx.stream>>>(p);
   }
-  ctx.sync();
 }
 
 // ------------------------------------------------------------------ opening
@@ -918,17 +916,18 @@ __global__ __launch_bounds__(256) void bary_partial_k(const u32* __restrict__ m,
   }
   if (threadIdx.x == 0) part[(size_t)blockIdx.y * nchunks + blockIdx.x] = s[0];
 }
-void bb_bary(Ctx& ctx, const BMat& m, size_t h, const E4* d_wgt, std::vector<E4>& sums) {
-  sums.assign(m.w, e4_zero());
+size_t bb_bary_partials(size_t w, size_t h) { return w * ((h + BARY_ROWS - 1) / BARY_ROWS); }
+void bb_bary_launch(Ctx& ctx, const BMat& m, size_t h, const E4* d_wgt, E4* d_part) {
   if (!m.w) return;
   size_t nch = (h + BARY_ROWS - 1) / BARY_ROWS;
-  DBuf<E4> part(ctx, m.w * nch);
   dim3 grid((unsigned)nch, (unsigned)m.w);
-  bary_partial_k<<<grid, 256, 0, ctx.stream>>>(m.buf.p, m.ld, h, d_wgt, part.p, nch);
-  std::vector<E4> hp(m.w * nch);
-  ctx.d2h(hp.data(), part.p, hp.size() * sizeof(E4));
-  for (size_t c = 0; c < m.w; c++)
-    for (size_t k = 0; k < nch; k++) sums[c] = e4_add(sums[c], hp[c * nch + k]);
+  bary_partial_k<<<grid, 256, 0, ctx.stream>>>(m.buf.p, m.ld, h, d_wgt, d_part, nch);
+}
+void bb_bary_finish(const E4* h_part, size_t w, size_t h, std::vector<E4>& sums) {
+  size_t nch = (h + BARY_ROWS - 1) / BARY_ROWS;
+  sums.assign(w, e4_zero());
+  for (size_t c = 0; c < w; c++)
+    for (size_t k = 0; k < nch; k++) sums[c] = e4_add(sums[c], h_part[c * nch + k]);
 }
 struct DeepArgs {
   const u32* m;

@@ -442,9 +442,28 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
     bb_inv_denoms(ctx, kv.first, log2_strict(kv.second), kv.second, d.inv.p, d.wgt.p);
     denoms.emplace(kv.first, std::move(d));
   }
-  // opened values: barycentric interpolation over the first h = height / blowup storage rows (the coset g H_h)
+  // opened values: barycentric interpolation over the first h = height / blowup storage rows (the coset g H_h); every
+  // matrix and point is launched first, ONE read-back serves them all, then they are observed in round -> matrix -> point order
   u32 g = bb_to_monty(BB_GENERATOR);
   opened.clear();
+  size_t n_part = 0;
+  for (auto& r : rounds)
+    for (size_t mi = 0; mi < r.data->ldes.size(); mi++) n_part += r.points[mi].size() * bb_bary_partials(r.data->ldes[mi].w, r.data->ldes[mi].h >> lb);
+  DBuf<E4> d_part(ctx, std::max<size_t>(n_part, 1));
+  {
+    size_t off = 0;
+    for (auto& r : rounds)
+      for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+        const BMat& mat = r.data->ldes[mi];
+        for (auto& z : r.points[mi]) {
+          bb_bary_launch(ctx, mat, mat.h >> lb, denoms.at(z).wgt.p, d_part.p + off);
+          off += bb_bary_partials(mat.w, mat.h >> lb);
+        }
+      }
+  }
+  std::vector<E4> h_part(std::max<size_t>(n_part, 1));
+  ctx.d2h(h_part.data(), d_part.p, n_part * sizeof(E4));
+  size_t part_off = 0;
   for (auto& r : rounds) {
     OpenedRound orr;
     for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
@@ -454,7 +473,8 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
       std::vector<std::vector<E4>> per_point;
       for (auto& z : r.points[mi]) {
         std::vector<E4> sums;
-        bb_bary(ctx, mat, h, denoms.at(z).wgt.p, sums);
+        bb_bary_finish(h_part.data() + part_off, mat.w, h, sums);
+        part_off += bb_bary_partials(mat.w, h);
         u32 s_pow = bb_exp_pow2(g, log_h);
         E4 vanish = e4_exp_pow2(z, log_h);
         vanish.c[0] = bb_sub(vanish.c[0], s_pow);
@@ -761,7 +781,6 @@ std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
       bb_quotient(ctx, in, q_evals);
       q_ldes.emplace_back();
       bb_quotient_lde(ctx, q_evals, log_degrees[pos], log_q, lb, q_ldes.back());
-      ctx.sync();
       cur_acc = accumulators[pos];
     }
     bb_commit(ctx, sys.d_perm.p, std::move(q_ldes), (unsigned)prm.cap_height, qd);
