@@ -99,6 +99,15 @@ void bb_bary_finish(const E4* h_part, size_t w, size_t h, std::vector<E4>& sums)
 // ro[i] += sum_p dinv_p[i] * (K_p - off_p * sum_c apow[c] m[i][c])
 void bb_deep(Ctx& ctx, const BMat& m, const E4* d_apow, int npoints, const E4* const* d_inv, const E4* K, const E4* off, E4* d_ro);
 void bb_fri_fold(Ctx& ctx, const E4* cur, size_t rows_out, E4 beta, const E4* roll_in, E4* out);
+// the commit-phase transcript on the device (no proof of work): duplex challenger state, one step per round
+struct DevChallenger {
+  u32 state[16], input[8], n_in, n_out;  // the output buffer is state[..n_out], popped from the back
+};
+struct FriBeta {
+  E4 beta, half_beta, beta2;
+};
+void bb_fri_challenge(Ctx& ctx, DevChallenger* d_ch, const Digest8* d_cap, size_t n_cap, const Poseidon2* d_perm, FriBeta* d_out);
+void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows_out, const FriBeta* d_beta, const E4* roll_in, E4* out);
 // gather scattered words into one buffer: out[dst + k] = src[k * stride], k < n
 struct GatherSeg {
   const u32* src;

@@ -983,6 +983,70 @@ void bb_fri_fold(Ctx& ctx, const E4* cur, size_t rows, E4 beta, const E4* roll_i
                                                             e4_square(beta), out);
 }
 
+// ---- the commit-phase transcript on the device (proof-of-work bits = 0): one 16-lane group replays the duplex challenger -
+// observe the round's cap, sample beta - so that the FRI rounds queue up without a host round trip; the host replays
+// the same steps afterwards on its own challenger and rejects any divergence.
+__global__ __launch_bounds__(64) void fri_challenge_k(DevChallenger* ch, const Digest8* __restrict__ cap, u32 n_cap, const Poseidon2* __restrict__ perm,
+                                                      u32 half, FriBeta* __restrict__ out) {
+  const int l = threadIdx.x & 15;
+  if (threadIdx.x >= 16) return;  // one DPP row does the work: lane l holds state word l and queued input l
+  u32 s = ch->state[l];
+  u32 pend = l < 8 ? ch->input[l] : 0;
+  u32 n_in = ch->n_in, n_out = ch->n_out;
+  auto duplex = [&]() {
+    if ((u32)l < n_in) s = pend;
+    n_in = 0;
+    s = coop_poseidon2(*perm, s, l);
+    n_out = 8;
+  };
+  const u32* cw = (const u32*)cap;
+  for (u32 k = 0; k < n_cap * 8; k++) {  // observe: clears the output buffer, queues, absorbs at 8
+    n_out = 0;
+    u32 v = cw[k];
+    if ((u32)l == n_in) pend = v;
+    n_in++;
+    if (n_in == 8) duplex();
+  }
+  E4 beta;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {  // sample_algebra_element: four pops from the back of the output buffer
+    if (n_in > 0 || n_out == 0) duplex();
+    beta.c[c] = (u32)__shfl((int)s, (int)(n_out - 1), 64);
+    n_out--;
+  }
+  ch->state[l] = s;
+  if (l < 8) ch->input[l] = pend;
+  if (l == 0) {
+    ch->n_in = n_in;
+    ch->n_out = n_out;
+    out->beta = beta;
+    out->half_beta = e4_mul_base(beta, half);
+    out->beta2 = e4_square(beta);
+  }
+}
+void bb_fri_challenge(Ctx& ctx, DevChallenger* d_ch, const Digest8* d_cap, size_t n_cap, const Poseidon2* d_perm, FriBeta* d_out) {
+  fri_challenge_k<<<1, 64, 0, ctx.stream>>>(d_ch, d_cap, (u32)n_cap, d_perm, bb_inv(bb_to_monty(2)), d_out);
+}
+__global__ void fri_fold_dev_k(const E4* __restrict__ cur, size_t rows, unsigned log_rows, const FriBeta* __restrict__ fb, u32 half, u32 g_inv,
+                               const E4* __restrict__ roll, E4* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  u32 gp = bb_pow(g_inv, bitrev_dev(i, log_rows));
+  E4 pw = e4_mul_base(fb->half_beta, gp);
+  E4 lo = cur[2 * i], hi = cur[2 * i + 1];
+  E4 a = pw, b = e4_neg(pw);
+  a.c[0] = bb_add(a.c[0], half);
+  b.c[0] = bb_add(b.c[0], half);
+  E4 r = e4_add(e4_mul(a, lo), e4_mul(b, hi));
+  if (roll) r = e4_add(r, e4_mul(fb->beta2, roll[i]));
+  out[i] = r;
+}
+void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows, const FriBeta* d_beta, const E4* roll_in, E4* out) {
+  unsigned lr = log2_host(rows);
+  fri_fold_dev_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(cur, rows, lr, d_beta, bb_inv(bb_to_monty(2)), bb_inv(bb_two_adic_generator(lr + 1)), roll_in,
+                                                                out);
+}
+
 __global__ void gather_k(const GatherSeg* __restrict__ segs, size_t nsegs, u32* __restrict__ out) {
   size_t s = blockIdx.x;
   if (s >= nsegs) return;

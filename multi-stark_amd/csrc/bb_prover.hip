@@ -547,19 +547,45 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
   size_t cur_len = inputs[0].second;
   size_t next_in = 1;
   unsigned log_max_height = log2_strict(cur_len);
+  // Without proof of work the commit phase needs nothing from the host: with MSBB_DEV_FRI=1 the challenger steps run on
+  // the device and the rounds queue up back to back; the host replays them afterwards. Off by default: measured at
+  // 2^20 rows it does not pay (7.2 vs 6.9 ms) - the rounds are ~10 launches of ~5 us each, so the host's launch rate, not
+  // its read-backs, is what spaces them; it needs the launches captured in a graph (or fewer of them) to win.
+  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && getenv("MSBB_DEV_FRI");
+  DBuf<DevChallenger> d_ch;
+  DBuf<FriBeta> d_betas;
+  size_t n_rounds = 0;
+  for (size_t l = cur_len; l > stop; l /= 2) n_rounds++;
+  if (dev_rounds && n_rounds) {
+    DevChallenger hc;
+    for (int k = 0; k < 16; k++) hc.state[k] = ch.state[k];
+    for (int k = 0; k < 8; k++) hc.input[k] = (size_t)k < ch.input.size() ? ch.input[k] : 0;
+    hc.n_in = (u32)ch.input.size();
+    hc.n_out = (u32)ch.output.size();  // host output buffer = state[..n_out] by construction (pops come off the back)
+    d_ch = DBuf<DevChallenger>(ctx, 1);
+    d_betas = DBuf<FriBeta>(ctx, n_rounds);
+    ctx.h2d(d_ch.p, &hc, sizeof(hc));
+  }
+  size_t round = 0;
   while (cur_len > stop) {
     size_t rows = cur_len / 2;
     fri_trees.emplace_back();
     bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back());
-    std::vector<Digest8> cap = tree_cap(ctx, fri_trees.back());
-    ch.observe_cap(cap);
-    fri.commits.push_back(cap);
-    fri.pow_witnesses.push_back(grind(sys, ch, (unsigned)prm.commit_pow_bits));
-    E4 beta = ch.sample_e4();
     const E4* roll = nullptr;
     if (next_in < inputs.size() && inputs[next_in].second == rows) roll = inputs[next_in++].first;
     DBuf<E4> out(ctx, rows);
-    bb_fri_fold(ctx, cur, rows, beta, roll, out.p);
+    if (dev_rounds) {
+      const BTree& t = fri_trees.back();
+      bb_fri_challenge(ctx, d_ch.p, t.layers[t.cap_layer()].p, t.sizes[t.cap_layer()], sys.d_perm.p, d_betas.p + round);
+      bb_fri_fold_dev(ctx, cur, rows, d_betas.p + round, roll, out.p);
+    } else {
+      std::vector<Digest8> cap = tree_cap(ctx, fri_trees.back());
+      ch.observe_cap(cap);
+      fri.commits.push_back(cap);
+      fri.pow_witnesses.push_back(grind(sys, ch, (unsigned)prm.commit_pow_bits));
+      E4 beta = ch.sample_e4();
+      bb_fri_fold(ctx, cur, rows, beta, roll, out.p);
+    }
     // keep the folded-from vector alive for the query openings
     if (layers.empty()) {
       layers.emplace_back();  // layer 0 is inputs[0] (owned by `reduced`)
@@ -569,6 +595,23 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
     layer_len.push_back(rows);
     cur = layers.back().p;
     cur_len = rows;
+    round++;
+  }
+  if (dev_rounds && n_rounds) {  // one read-back: every cap and beta; the host challenger replays and checks
+    std::vector<FriBeta> hb(n_rounds);
+    std::vector<std::vector<Digest8>> caps(n_rounds);
+    for (size_t i = 0; i < n_rounds; i++) {
+      const BTree& t = fri_trees[i];
+      caps[i].resize(t.sizes[t.cap_layer()]);
+      ctx.d2h_queue(caps[i].data(), t.layers[t.cap_layer()].p, caps[i].size() * sizeof(Digest8));
+    }
+    ctx.d2h(hb.data(), d_betas.p, n_rounds * sizeof(FriBeta));
+    for (size_t i = 0; i < n_rounds; i++) {
+      ch.observe_cap(caps[i]);
+      fri.commits.push_back(caps[i]);
+      fri.pow_witnesses.push_back(0);
+      if (!e4_eq(ch.sample_e4(), hb[i].beta)) throw std::runtime_error("FRI: device transcript diverged from the host challenger");
+    }
   }
   if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
   // final polynomial: first final_len entries, undo the bit reversal, inverse DFT (tiny: on the host)
