@@ -53,6 +53,7 @@ extern "C" {
     pub fn ms_ctx_set_profile_mask(ctx: *mut ms_ctx, mask: u32) -> i32;
     pub fn ms_ctx_kernel_stats(ctx: *mut ms_ctx, kernel_id: i32, launches: *mut u64, ms: *mut f64, alg_bytes: *mut f64) -> i32;
     pub fn ms_ctx_reset_stats(ctx: *mut ms_ctx) -> i32;
+    pub fn ms_ctx_debug_fail_alloc(ctx: *mut ms_ctx, nth: i32) -> i32;
     pub fn ms_kernel_count() -> i32;
     pub fn ms_kernel_name(kernel_id: i32) -> *const c_char;
     pub fn ms_system_create(ctx: *mut ms_ctx, blob: *const u8, len: usize, out: *mut *mut ms_system) -> i32;
@@ -62,6 +63,9 @@ extern "C" {
     pub fn ms_witness_create(sys: *mut ms_system, traces: *const *const u64, heights: *const u64, mult: *const *const u64,
                              args: *const *const u64, n_claims: usize, claim_offsets: *const u64, claim_data: *const u64,
                              out: *mut *mut ms_witness) -> i32;
+    pub fn ms_witness_create_host(sys: *mut ms_system, traces: *const *const u64, heights: *const u64, n_claims: usize,
+                                  claim_offsets: *const u64, claim_data: *const u64, pinned: *mut i32,
+                                  out: *mut *mut ms_witness) -> i32;
     pub fn ms_witness_u32_add_bench(sys: *mut ms_system, num_adds: usize, a0: u32, b0: u32, out: *mut *mut ms_witness) -> i32;
     pub fn ms_witness_destroy(w: *mut ms_witness);
     pub fn ms_prove(sys: *mut ms_system, w: *mut ms_witness, proof_out: *mut u8, cap: usize, proof_len: *mut usize, stage_ms: *mut f64) -> i32;

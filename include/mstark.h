@@ -14,7 +14,8 @@
  *
  * What each group replaces in /root/reference:
  *   ms_system_*    System::new + ProverKey                      src/system.rs:115-203 (preprocessed commit :190-195)
- *   ms_witness_*   SystemWitness / from_stage_1                 src/system.rs:225-328
+ *   ms_witness_*   SystemWitness / from_stage_1                 src/system.rs:225-328 (host-resident: the witness argument
+ *                                                               of prove(), src/prover.rs:290-295)
  *   ms_prove       System::prove_multiple_claims                src/prover.rs:290-603
  *   ms_verify      System::verify_multiple_claims               src/verifier.rs:208-532
  *   ms_prove_sharded   the same proof computed by several GPUs  src/prover.rs:290-603 (commit/open calls :350,419,526,580)
@@ -64,6 +65,9 @@ int32_t ms_ctx_trim(ms_ctx* ctx);
 int32_t ms_ctx_set_profile_mask(ms_ctx* ctx, uint32_t mask);
 int32_t ms_ctx_kernel_stats(ms_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* ms, double* alg_bytes);
 int32_t ms_ctx_reset_stats(ms_ctx* ctx);
+/* Diagnostics: the nth device allocation from now fails (0 = off). Lets a test check that an error in the middle of a
+ * proof leaves the library usable (queued read-backs dropped, pool intact). */
+int32_t ms_ctx_debug_fail_alloc(ms_ctx* ctx, int32_t nth);
 int32_t ms_kernel_count(void);
 const char* ms_kernel_name(int32_t kernel_id);
 
@@ -84,6 +88,16 @@ int32_t ms_system_circuit_info(const ms_system* sys, size_t circuit, uint64_t ou
 int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights,
                           const uint64_t* const* mult, const uint64_t* const* args, size_t n_claims,
                           const uint64_t* claim_offsets, const uint64_t* claim_data, ms_witness** out);
+/* A SystemWitness that STAYS in host memory, which is what the reference's prove() is handed (src/prover.rs:290-295;
+ * criterion builds it in the setup closure, benches/multi_stark.rs:292-296). Nothing is uploaded here: the values are
+ * validated and the caller's trace buffers are page-locked (hipHostRegister; *pinned = 1 when every range could be, else
+ * uploads are staged by the runtime). The trace buffers must stay valid and unchanged until ms_witness_destroy. Every
+ * ms_prove on such a witness moves traces and claims to HBM on a copy stream (claims travel while stage 1 is computed),
+ * runs SystemWitness::from_stage_1 (src/system.rs:244-328) on the device and frees the device copies again, so its
+ * wall time is the reference's timed region: witness in host memory at the start, proof bytes in host memory at the end. */
+int32_t ms_witness_create_host(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, size_t n_claims,
+                               const uint64_t* claim_offsets, const uint64_t* claim_data, int32_t* pinned /* nullable */,
+                               ms_witness** out);
 /* The bench workload's witness and claims generated in HBM for the system [ByteTable, U32Add]: build_witness +
  * build_claims of benches/multi_stark.rs:171-238 (two xorshift32 streams from a0, b0; the reference uses 0xdeadbeef,
  * 0xcafebabe) followed by from_stage_1 on the device. Nothing crosses PCIe. */

@@ -42,8 +42,8 @@ def lib():
 def exported_symbols():
     """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
-            "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
-            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create",
+            "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
+            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_pcs_commit", "ms_pcs_open", "ms_pcs_verify", "ms_challenger_create",
             "ms_challenger_destroy", "ms_challenger_observe", "ms_challenger_observe_digests", "ms_challenger_sample_ext",
@@ -93,6 +93,10 @@ class Context:
 
     def trim(self):
         _check(lib().ms_ctx_trim(self.h))
+
+    def debug_fail_alloc(self, nth):
+        """diagnostics: the nth device allocation from now raises (0 = off)"""
+        _check(lib().ms_ctx_debug_fail_alloc(self.h, C.c_int32(nth)))
 
     # ---- profiling
     def kernel_names(self):
@@ -381,6 +385,26 @@ class System:
         h = C.c_void_p()
         _check(lib().ms_witness_create(self.h, tptr, _p(hs), mptr, aptr, C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(h)))
         return SystemWitness(h, int(hs.sum()), self)
+
+    def host_witness(self, traces, claims_packed):
+        """A SystemWitness that stays in HOST memory (ms_witness_create_host): every prove_multiple_claims uploads it,
+        as the reference's prove() would receive it (benches/multi_stark.rs:292-296). The arrays are kept alive (and
+        page-locked) by the returned object."""
+        trs = [_u64(t) if t is not None and len(t) else np.zeros((0, 1), dtype=np.uint64) for t in traces]
+        n = self.n_circuits
+        if len(trs) != n:
+            raise MstarkError("expected one trace per circuit")
+        tptr = (u64p * n)(*[_p(t) for t in trs])
+        hs = _u64([t.shape[0] for t in trs])
+        offs, data = claims_packed
+        data = data if data.size else np.zeros(1, dtype=np.uint64)
+        h = C.c_void_p()
+        pinned = C.c_int32(0)
+        _check(lib().ms_witness_create_host(self.h, tptr, _p(hs), C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(pinned), C.byref(h)))
+        w = SystemWitness(h, int(hs.sum()), self)
+        w.keep = trs
+        w.pinned = bool(pinned.value)
+        return w
 
     def bench_witness_on_device(self, num_adds, a0=0xDEADBEEF, b0=0xCAFEBABE):
         """The bench workload's witness and claims generated in HBM (benches/multi_stark.rs:171-238) for [ByteTable, U32Add]."""

@@ -49,10 +49,12 @@ static thread_local std::string g_err;
   catch (const std::exception& e) { \
     g_err = e.what();               \
     (void)hipGetLastError();        \
+    msamd::abandon_pending();       \
     return MS_ERR;                  \
   }                                 \
   catch (...) {                     \
     g_err = "unknown error";        \
+    msamd::abandon_pending();       \
     return MS_ERR;                  \
   }
 
@@ -82,6 +84,7 @@ namespace msamd {
 void set_last_error(const char* what) {
   g_err = what;
   (void)hipGetLastError();
+  abandon_pending();
 }
 Ctx* ctx_of(ms_ctx* c) {
   if (!c) throw std::runtime_error("null context");
@@ -136,6 +139,10 @@ int32_t ms_ctx_reset_stats(ms_ctx* ctx) {
   return MS_OK;
   MS_CATCH
 }
+int32_t ms_ctx_debug_fail_alloc(ms_ctx* ctx, int32_t nth) {
+  ctx->ctx.fail_alloc_countdown = nth > 0 ? nth : 0;
+  return MS_OK;
+}
 int32_t ms_kernel_count(void) { return K_COUNT; }
 const char* ms_kernel_name(int32_t id) { return kernel_name(id); }
 
@@ -175,6 +182,18 @@ int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const u
   *out = nullptr;
   MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
   w->w = witness_create(*sys->sys, traces, heights, mult, args, n_claims, claim_offsets, claim_data);
+  w->owner = sys;
+  sys->refs++;
+  *out = w.release();
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_witness_create_host(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, size_t n_claims,
+                               const uint64_t* claim_offsets, const uint64_t* claim_data, int32_t* pinned, ms_witness** out) {
+  *out = nullptr;
+  MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
+  w->w = witness_create_host(*sys->sys, traces, heights, n_claims, claim_offsets, claim_data);
+  if (pinned) *pinned = w->w->pinned ? 1 : 0;
   w->owner = sys;
   sys->refs++;
   *out = w.release();

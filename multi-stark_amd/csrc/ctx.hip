@@ -1,7 +1,34 @@
 // Device context: stream, twiddle tables, pooled memory, event-based per-kernel timing.
+#include <mutex>
+#include <set>
+
 #include "msamd.h"
 
 namespace msamd {
+
+// Read-backs queued by d2h_queue point at the caller's locals. When an error unwinds the call before the next
+// synchronisation delivers them, those destinations are gone: the C-ABI catch blocks call abandon_pending() so that the
+// entries are dropped (after a best-effort synchronisation) instead of being written through later.
+namespace {
+thread_local Ctx* tl_pending_ctx = nullptr;
+std::mutex g_live_mu;
+std::set<Ctx*> g_live;
+}  // namespace
+void abandon_pending() {
+  Ctx* c = tl_pending_ctx;
+  tl_pending_ctx = nullptr;
+  if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (!g_live.count(c)) return;
+  }
+  (void)hipStreamSynchronize(c->copy_stream);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipGetLastError();
+  c->down_pending.clear();
+  c->down_used = 0;
+  c->up_used = 0;
+}
 
 static const char* KNAMES[K_COUNT] = {"ntt_lds_strided", "ntt_lds_contig", "ntt12_dif", "ntt12_dit", "ntt8s_dif", "ntt8s_dit", "leaf_hash", "compress_layer", "stage2", "quotient",
                                       "bary_eval",   "deep_reduce", "fri_fold", "transpose",      "other"};
@@ -38,11 +65,17 @@ void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out) 
 }
 
 Ctx::Ctx(int dev) : device(dev) {
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.insert(this);
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) throw std::runtime_error("no HIP device available");
   if (dev < 0 || dev >= count) throw std::runtime_error("HIP device index out of range");
   HIP_CHECK(hipSetDevice(dev));
   HIP_CHECK(hipStreamCreate(&stream));
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  for (auto& e : copy_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   pinned_half = size_t(8) << 20;
   if (hipHostMalloc((void**)&pinned, 2 * pinned_half, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
@@ -121,10 +154,17 @@ Ctx::Ctx(int dev) : device(dev) {
   HIP_CHECK(hipMemcpy(tf + 8192, fi.data(), 8192 * sizeof(u64), hipMemcpyHostToDevice));
   twf = tf;
   twfi = tf + 8192;
+  HIP_CHECK(hipMalloc(&tree_counter, 256));
+  HIP_CHECK(hipMemset(tree_counter, 0, 256));
 }
 
 Ctx::~Ctx() {
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(this);
+  }
   (void)hipSetDevice(device);
+  if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   (void)hipStreamSynchronize(stream);
   for (auto& p : prof_pending) {
     (void)hipEventDestroy(p.a);
@@ -138,10 +178,15 @@ Ctx::~Ctx() {
   if (tw0) (void)hipFree(tw0);
   if (twc) (void)hipFree(twc);
   if (twf) (void)hipFree(twf);
+  if (tree_counter) (void)hipFree(tree_counter);
+  for (auto e : copy_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
   (void)hipStreamDestroy(stream);
 }
 
 void* Ctx::alloc(size_t bytes) {
+  if (fail_alloc_countdown > 0 && --fail_alloc_countdown == 0) throw std::runtime_error("injected allocation failure (ms_ctx_debug_fail_alloc)");
   size_t sz = (bytes + 255) & ~size_t(255);
   if (sz == 0) sz = 256;
   auto it = pool_free.find(sz);
@@ -211,6 +256,7 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
   down_pending.push_back(PendingD2H{dst, down_used, n});
   down_used += need;
+  tl_pending_ctx = this;
 }
 
 void Ctx::d2h(void* dst, const void* src, size_t n) {

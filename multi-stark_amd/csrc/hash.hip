@@ -7,6 +7,7 @@
 // little-endian 32-bit message words. Shorter matrices are injected at the layer whose length equals their
 // height: node = compress(compress(l, r), hash(rows)).
 #include <algorithm>
+#include <cstdlib>
 
 #include "b3_dev.h"
 #include "b3_quad.h"
@@ -325,6 +326,152 @@ __global__ __launch_bounds__(1024) void tree_tail_k(Digest* __restrict__ layer, 
   }
 }
 
+// Every level above a layer of `len` digests in ONE launch (len = 2^k, 2 <= len <= 2^21). A workgroup owns 2048
+// consecutive children, i.e. a whole sub-tree of depth 11: the first level is one compression per thread straight from
+// global memory, the rest runs on quads out of LDS (as tree_tail_k). With several workgroups the sub-tree roots are
+// handed over in-launch: each root is written through (agent-scope relaxed atomic stores = `sc1`), the workgroup drains
+// its stores and draws a ticket (agent-scope atomic add); the workgroup whose ticket is the last one reads all roots
+// with `sc1` loads and computes the remaining levels (MI355X_MICROARCH.md, inter-workgroup visibility: write-through
+// payload + drained counter, consumer = last arriver). Every layer is still written to global memory for the query
+// phase, none is read back. One injected group (shorter matrices) may sit at any level: that level runs one thread per
+// node. With CH the last workgroup continues with the FRI round's challenger step.
+struct SubtreeParams {
+  Digest* child;
+  u32 len;
+  u32 inj_len;   // length of the layer that takes the injected group (0 = none)
+  const MatRef* g;
+  u32 inj_w;
+  u32 inj_multi; // rows longer than one BLAKE3 chunk
+  u32* counter;  // zero at launch; reset by the last workgroup
+  FriChallenge fc;
+};
+
+__device__ __forceinline__ void subtree_levels(u32* sh, u32 n, u32 b, Digest* lvl, u32 glen, const SubtreeParams& p) {
+  const u32 t = threadIdx.x, quad = t >> 2, c = t & 3;
+  for (; n >= 1; n >>= 1) {
+    if (p.inj_len == glen) {  // node = compress(compress(l, r), hash(rows)): one thread per node
+      u32 d[8];
+      const bool act = t < n;
+      if (act) {
+        u32 l[8], r[8], e[8], rh[8];
+        lds_load_digest(sh, 2 * t, l);
+        lds_load_digest(sh, 2 * t + 1, r);
+        b3_compress_pair_root(l, r, e);
+        if (p.inj_multi)
+          hash_row<true>(p.g, glen, size_t(b) * n + t, p.inj_w, rh);
+        else
+          hash_row<false>(p.g, glen, size_t(b) * n + t, p.inj_w, rh);
+        b3_compress_pair_root(e, rh, d);
+      }
+      __syncthreads();
+      if (act) {
+        lds_store_digest(sh, t, d);
+        store_digest(lvl + size_t(b) * n + t, d);
+      }
+      __syncthreads();
+    } else {
+      u32 lo[2], hi[2];
+#pragma unroll
+      for (int ps = 0; ps < 2; ps++) {
+        const u32 q = quad + 256 * ps;
+        if (q < n) b3_quad_parent(sh + 16 * q, lo[ps], hi[ps]);
+      }
+      __syncthreads();
+      u32* out = reinterpret_cast<u32*>(lvl + size_t(b) * n);
+#pragma unroll
+      for (int ps = 0; ps < 2; ps++) {
+        const u32 q = quad + 256 * ps;
+        if (q < n) {
+          sh[8 * q + c] = lo[ps];
+          sh[8 * q + 4 + c] = hi[ps];
+          out[8 * q + c] = lo[ps];
+          out[8 * q + 4 + c] = hi[ps];
+        }
+      }
+      __syncthreads();
+    }
+    lvl += glen;
+    glen >>= 1;
+  }
+}
+
+template <bool CH>
+__global__ __launch_bounds__(1024) void subtree_k(SubtreeParams p) {
+  __shared__ __attribute__((aligned(16))) u32 sh[1024 * 8];
+  __shared__ ChallengeShared cs;
+  __shared__ u32 s_last;
+  const u32 t = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  Digest* lvl = p.child + p.len;  // the first parent layer
+  u32 glen = p.len >> 1;          // its length
+  u32 n;
+  if (p.len >= 2048) {  // 2048 children per workgroup: level 1 from global memory, one node per thread
+    u32 l[8], r[8], d[8];
+    const Digest* mine = p.child + size_t(b) * 2048 + 2 * t;
+    load_digest(mine, l);
+    load_digest(mine + 1, r);
+    b3_compress_pair_root(l, r, d);
+    if (p.inj_len == glen) {
+      u32 rh[8], e[8];
+      if (p.inj_multi)
+        hash_row<true>(p.g, glen, size_t(b) * 1024 + t, p.inj_w, rh);
+      else
+        hash_row<false>(p.g, glen, size_t(b) * 1024 + t, p.inj_w, rh);
+      b3_compress_pair_root(d, rh, e);
+#pragma unroll
+      for (int k = 0; k < 8; k++) d[k] = e[k];
+    }
+    store_digest(lvl + size_t(b) * 1024 + t, d);
+    lds_store_digest(sh, t, d);
+    lvl += glen;
+    glen >>= 1;
+    n = 512;
+  } else {
+    if (t < p.len) {
+      u32 d[8];
+      load_digest(p.child + t, d);
+      lds_store_digest(sh, t, d);
+    }
+    n = p.len >> 1;
+  }
+  if (CH && t < 8) cs.st[t] = p.fc.state[t];
+  __syncthreads();
+  subtree_levels(sh, n, b, lvl, glen, p);
+  if (nb > 1) {
+    // hand the sub-tree root (sh[0..7], already stored plainly for later kernels) to the last workgroup
+    Digest* roots = p.child;
+    {
+      size_t off = 0;
+      for (u32 l = p.len; l > nb; l >>= 1) off += l;
+      roots += off;  // the layer of nb digests
+    }
+    if (t < 8) __hip_atomic_store(reinterpret_cast<u32*>(roots + b) + t, sh[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      const u32 ticket = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = ticket == nb - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const u32* rw = reinterpret_cast<const u32*>(roots);
+    for (u32 i = t; i < nb * 8; i += 1024) sh[i] = __hip_atomic_load(rw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    subtree_levels(sh, nb >> 1, 0, roots + nb, nb >> 1, p);
+  }
+  if (CH) {
+    challenger_round<1024>(cs, sh, p.fc.pow_bits);
+    if (t < 8) {
+      p.fc.state[t] = cs.st[t];
+      p.fc.rec->root[t] = sh[t];
+    }
+    if (t == 0) {
+      p.fc.rec->witness = cs.wit;
+      p.fc.rec->beta = cs.beta;
+    }
+  }
+}
+
 // ---- whole-stream BLAKE3. The stream is `prefix` (prefix_len bytes, any alignment) followed by `nwords`
 // little-endian u64 words (8-byte aligned), which is how the transcript up to the claims is shaped: a short
 // host-built prefix, then the length-prefixed claims as field elements.
@@ -473,9 +620,43 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
   for (size_t li = 1; li < L; li++)
     if (inj[li].count) last_inject = li;
   size_t li = 1;
+  const bool no_subtree = getenv("MSAMD_NO_SUBTREE") != nullptr;  // read at call time (tests flip it)
+  const char* sml = getenv("MSAMD_SUBTREE_MAX_LOG");
+  const unsigned subtree_max_log = sml ? (unsigned)atoi(sml) : 20u;
   while (li < L) {
     const size_t child_len = t.layer_len[li - 1];
     Digest* child = t.base() + t.layer_off[li - 1];
+    // all remaining levels in one launch (sub-trees of 2048 children + in-launch hand-over of their roots)
+    if (!no_subtree && child_len >= 2 && child_len <= (size_t(1) << std::min(subtree_max_log, 21u))) {
+      size_t n_inj = 0, inj_li = 0;
+      for (size_t k = li; k < L; k++)
+        if (inj[k].count) {
+          n_inj++;
+          inj_li = k;
+        }
+      if (n_inj <= 1) {
+        SubtreeParams sp;
+        sp.child = child;
+        sp.len = (u32)child_len;
+        sp.inj_len = n_inj ? (u32)t.layer_len[inj_li] : 0u;
+        sp.g = n_inj ? drefs + inj[inj_li].first : nullptr;
+        sp.inj_w = n_inj ? inj[inj_li].total_w : 0u;
+        sp.inj_multi = n_inj && inj[inj_li].total_w > 128 ? 1u : 0u;
+        sp.counter = ctx.tree_counter;
+        sp.fc = fc ? *fc : FriChallenge{};
+        const unsigned nb = child_len >= 2048 ? (unsigned)(child_len / 2048) : 1u;
+        const KernelId kid = fc ? K_OTHER : K_COMPRESS;
+        hipEvent_t ev = ctx.prof_begin(kid);
+        if (fc)
+          hipLaunchKernelGGL(subtree_k<true>, dim3(nb), dim3(1024), 0, ctx.stream, sp);
+        else
+          hipLaunchKernelGGL(subtree_k<false>, dim3(nb), dim3(1024), 0, ctx.stream, sp);
+        ctx.prof_end(kid, ev, 96.0 * double(child_len) + (n_inj ? 8.0 * sp.inj_w * sp.inj_len : 0.0));
+        fc = nullptr;
+        li = L;
+        break;
+      }
+    }
     if (child_len <= 1024 && li > last_inject) {
       const KernelId kid = fc ? K_OTHER : K_COMPRESS;  // the challenger step's grinding is not tree work
       hipEvent_t ev = ctx.prof_begin(kid);
@@ -516,7 +697,7 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
     ctx.prof_end(K_COMPRESS, ev, double(n) * (96.0 + 8.0 * inj[li].total_w));
     li++;
   }
-  if (fc && L == 1) {  // a single leaf is its own root
+  if (fc && L == 1 && li == 1) {  // a single leaf is its own root
     hipLaunchKernelGGL(tree_tail_k<true>, dim3(1), dim3(1024), 0, ctx.stream, t.base(), 1u, *fc);
     fc = nullptr;
   }

@@ -99,7 +99,21 @@ struct HWitness {
   // claims: host copy (transcript for small inputs) and device copy
   std::vector<u64> claim_offsets, claim_data;
   DBuf<u64> d_claim_offsets, d_claim_data;
+  // host-resident witness (ms_witness_create_host): between proofs nothing of it lives in HBM. prove() uploads the
+  // traces and the claims on the context's copy stream and runs from_stage_1 on the device, every time.
+  bool host_resident = false;
+  std::vector<const u64*> h_traces;                 // the caller's row-major buffers (pinned by hipHostRegister)
+  std::vector<std::vector<u64>> h_mult, h_args;     // only for circuits whose lookup prefix needs the host sweep
+  std::vector<void*> registered;                    // ranges this witness pinned; unpinned by the destructor
+  bool pinned = true;                               // every uploaded range is page-locked
+  void pin(const void* p, size_t bytes);
+  HWitness() {}
+  HWitness(const HWitness&) = delete;
+  HWitness& operator=(const HWitness&) = delete;
+  ~HWitness();
 };
+std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* traces, const u64* heights, size_t n_claims,
+                                              const u64* claim_offsets, const u64* claim_data);
 std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces, const u64* heights, const u64* const* mult,
                                          const u64* const* args, size_t n_claims, const u64* claim_offsets,
                                          const u64* claim_data);

@@ -60,6 +60,8 @@ struct KernelStat {
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // bulk uploads of a host-resident witness, running beside the kernels of `stream`
+  hipEvent_t copy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   u64 *tw0 = nullptr, *tw1 = nullptr, *tw0i = nullptr, *tw1i = nullptr;
   // compact per-order tables: table r (root of order 2^r, r = 1..12) holds w^i for i < 2^(r-1) at offset 2^(r-1) - 1
   u64 *twc = nullptr, *twci = nullptr;
@@ -68,10 +70,12 @@ struct Ctx {
   // full per-order tables: table r (r = 1..12) holds w^i for ALL i < 2^r at offset 2^r - 1 (the radix-16 rounds in
   // "16-point network, then one twiddle per value" form need exponents up to 15/16 of the order)
   u64 *twf = nullptr, *twfi = nullptr;
+  u32* tree_counter = nullptr;  // ticket counter of the in-launch sub-tree hand-over (hash.hip): zero between launches
   // pooled device memory: exact-size buckets, reused across proofs
   std::multimap<size_t, void*> pool_free;
   std::map<void*, size_t> pool_live;
   size_t pool_bytes = 0;
+  int fail_alloc_countdown = 0;  // diagnostics (ms_ctx_debug_fail_alloc): the n-th alloc from now throws
   // pinned staging for small transfers: the first half takes uploads (bump-allocated; every block stays untouched
   // until the stream has been synchronised, then the half is reused), the second half receives read-backs.
   // Pageable buffers would make hipMemcpyAsync stage and block on the host for every call.
@@ -112,6 +116,9 @@ struct Ctx {
   void prof_end(int id, hipEvent_t a, double bytes);
   void prof_collect();
 };
+
+// drop read-backs queued by the calling thread whose destinations an error has unwound (called by the C-ABI catch blocks)
+void abandon_pending();
 
 // RAII device buffer from the pool
 template <class T>

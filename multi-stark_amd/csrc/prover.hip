@@ -340,6 +340,24 @@ void sweep_prefix(const HCircuit& c, const u64* pre_cur, const u64* pre_next, co
     buf[i] = v;
   }
 }
+// SystemWitness::from_stage_1 on the host (src/system.rs:275-328): the flat LookupValues storage of one circuit
+void host_lookup_values(const HCircuit& c, const u64* tr, size_t h, std::vector<u64>& hm, std::vector<u64>& ha) {
+  std::vector<uint32_t> offs(1, 0);
+  for (auto& l : c.lookups) offs.push_back(offs.back() + (uint32_t)l.second.size());
+  hm.assign(h * c.num_lookups, 0);
+  ha.assign(h * c.args_width, 0);
+  std::vector<u64> buf;
+  for (size_t r = 0; r < h; r++) {
+    size_t rn = (r + 1) % h;
+    const u64* pc = c.pre_width ? &c.preprocessed[r * c.pre_width] : nullptr;
+    const u64* pn = c.pre_width ? &c.preprocessed[rn * c.pre_width] : nullptr;
+    sweep_prefix(c, pc, pn, tr + r * c.main_width, tr + rn * c.main_width, r == 0, r == h - 1, buf);
+    for (size_t j = 0; j < c.num_lookups; j++) {
+      hm[r * c.num_lookups + j] = buf[c.lookups[j].first];
+      for (size_t k = 0; k < c.lookups[j].second.size(); k++) ha[r * c.args_width + offs[j] + k] = buf[c.lookups[j].second[k]];
+    }
+  }
+}
 }  // namespace
 
 // A witness whose traces and claims are already in HBM (witness_gen.hip): SystemWitness::from_stage_1 runs on the device.
@@ -434,18 +452,8 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
       ctx.sync();  // SystemWitness::from_stage_1 ran as one kernel
     } else {
       // SystemWitness::from_stage_1, src/system.rs:275-328 (host sweep: huge prefixes or malformed programs)
-      std::vector<u64> hm(h * c.num_lookups), ha(h * c.args_width), buf;
-      const u64* tr = traces[ci];
-      for (size_t r = 0; r < h; r++) {
-        size_t rn = (r + 1) % h;
-        const u64* pc = c.pre_width ? &c.preprocessed[r * c.pre_width] : nullptr;
-        const u64* pn = c.pre_width ? &c.preprocessed[rn * c.pre_width] : nullptr;
-        sweep_prefix(c, pc, pn, tr + r * c.main_width, tr + rn * c.main_width, r == 0, r == h - 1, buf);
-        for (size_t j = 0; j < c.num_lookups; j++) {
-          hm[r * c.num_lookups + j] = buf[c.lookups[j].first];
-          for (size_t k = 0; k < c.lookups[j].second.size(); k++) ha[r * c.args_width + offs[j] + k] = buf[c.lookups[j].second[k]];
-        }
-      }
+      std::vector<u64> hm, ha;
+      host_lookup_values(c, traces[ci], h, hm, ha);
       ctx.h2d(lk.mult.p, hm.data(), hm.size() * 8);
       if (!ha.empty()) ctx.h2d(lk.args.p, ha.data(), ha.size() * 8);
       ctx.sync();
@@ -466,6 +474,175 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
   ctx.sync();
   return w;
 }
+
+// ------------------------------------------------------------------ host-resident SystemWitness
+// The reference's prove() is handed a witness that lives in host memory (benches/multi_stark.rs:292-296,
+// src/prover.rs:290-295). Nothing is uploaded here: the caller's buffers are page-locked so that the per-proof uploads
+// run at the link rate, the values are validated, and prove() moves them to HBM on the copy stream every time.
+void HWitness::pin(const void* p, size_t bytes) {
+  if (!p || !bytes) return;
+  hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault);
+  if (e == hipSuccess) {
+    registered.push_back(const_cast<void*>(p));
+  } else {
+    (void)hipGetLastError();
+    if (e != hipErrorHostMemoryAlreadyRegistered) pinned = false;  // uploads of this range are staged by the runtime
+  }
+}
+HWitness::~HWitness() {
+  if (registered.empty()) return;
+  if (sys && sys->ctx) {
+    (void)hipSetDevice(sys->ctx->device);
+    (void)hipStreamSynchronize(sys->ctx->copy_stream);
+  }
+  for (void* p : registered) (void)hipHostUnregister(p);
+}
+
+std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* traces, const u64* heights, size_t n_claims,
+                                              const u64* claim_offsets, const u64* claim_data) {
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  std::unique_ptr<HWitness> w(new HWitness());
+  w->sys = &sys;
+  w->host_resident = true;
+  const size_t C = sys.circuits.size();
+  w->traces.resize(C);
+  w->lookups.resize(C);
+  w->h_traces.assign(C, nullptr);
+  w->h_mult.resize(C);
+  w->h_args.resize(C);
+  for (size_t ci = 0; ci < C; ci++) {
+    const HCircuit& c = sys.circuits[ci];
+    const size_t h = heights[ci];
+    w->heights.push_back(h);
+    if (h == 0) continue;
+    if (h & (h - 1)) throw std::runtime_error("trace height must be a power of two");
+    if (log2_strict(h) > NTT_MAX_LOG || log2_strict(h) + sys.params.log_blowup > TW_LOG)
+      throw std::runtime_error("trace height exceeds the supported maximum");
+    if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    if (!traces[ci]) throw std::runtime_error("host-resident witness: every active circuit needs its trace");
+    const size_t cnt = h * c.main_width;
+    for (size_t i = 0; i < cnt; i++)
+      if (traces[ci][i] >= GL_P) throw std::runtime_error("non-canonical trace value");
+    w->h_traces[ci] = traces[ci];
+    w->pin(traces[ci], cnt * 8);
+    DLookups& lk = w->lookups[ci];
+    lk.height = h;
+    lk.num_lookups = c.num_lookups;
+    lk.args_width = c.args_width;
+    if (c.num_lookups == 0) continue;
+    std::vector<uint32_t> offs(1, 0);
+    for (auto& l : c.lookups) offs.push_back(offs.back() + (uint32_t)l.second.size());
+    lk.arg_offsets = DBuf<uint32_t>(ctx, offs.size());
+    ctx.h2d(lk.arg_offsets.p, offs.data(), offs.size() * 4);
+    unsigned threads = 64;
+    const bool fits = c.prefix_on_device && c.prefix_prog.n_slots * threads * 8 <= 64 * 1024 && !getenv("MSAMD_HOST_LOOKUP_VALUES");
+    if (!fits) {  // the lookup values of this circuit are part of the host-resident witness (and of every upload)
+      host_lookup_values(c, traces[ci], h, w->h_mult[ci], w->h_args[ci]);
+      w->pin(w->h_mult[ci].data(), w->h_mult[ci].size() * 8);
+      w->pin(w->h_args[ci].data(), w->h_args[ci].size() * 8);
+    }
+  }
+  if (claim_offsets[0] != 0) throw std::runtime_error("claim offsets must start at 0");
+  for (size_t i = 0; i < n_claims; i++)
+    if (claim_offsets[i + 1] < claim_offsets[i]) throw std::runtime_error("claim offsets must be non-decreasing");
+  const size_t tot = n_claims ? (size_t)claim_offsets[n_claims] : 0;
+  w->claim_offsets.assign(claim_offsets, claim_offsets + n_claims + 1);
+  w->claim_data.assign(claim_data, claim_data + tot);
+  for (u64 x : w->claim_data)
+    if (x >= GL_P) throw std::runtime_error("non-canonical claim value");
+  // the uploads read the witness's own copies (the small-claims transcript needs them on the host anyway)
+  w->pin(w->claim_offsets.data(), (n_claims + 1) * 8);
+  w->pin(w->claim_data.data(), tot * 8);
+  ctx.sync();
+  return w;
+}
+
+namespace {
+// Per-proof upload of a host-resident witness. Everything is queued on the copy stream in the order the proof needs it
+// (traces, then claims); the kernels of ctx.stream wait on events, so the claims travel while stage 1 is computed.
+// The device buffers live in the witness for the duration of the proof only.
+struct HostUpload {
+  HWitness& w;
+  Ctx& ctx;
+  bool on = false;
+  HostUpload(HWitness& wit, Ctx& c) : w(wit), ctx(c) {}
+  void start() {
+    if (!w.host_resident) return;
+    on = true;
+    HSystem& sys = *w.sys;
+    const size_t C = sys.circuits.size();
+    // buffers first: pool blocks handed out here may still be in use by kernels queued earlier on ctx.stream
+    HIP_CHECK(hipEventRecord(ctx.copy_ev[3], ctx.stream));
+    HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[3], 0));
+    for (size_t ci = 0; ci < C; ci++) {
+      const HCircuit& c = sys.circuits[ci];
+      const size_t h = w.heights[ci];
+      if (!h) continue;
+      w.traces[ci] = DBuf<u64>(ctx, h * c.main_width);
+      HIP_CHECK(hipMemcpyAsync(w.traces[ci].p, w.h_traces[ci], h * c.main_width * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    }
+    HIP_CHECK(hipEventRecord(ctx.copy_ev[0], ctx.copy_stream));
+    bool host_lookups = false;
+    for (size_t ci = 0; ci < C; ci++) {
+      const HCircuit& c = sys.circuits[ci];
+      const size_t h = w.heights[ci];
+      if (!h || !c.num_lookups) continue;
+      DLookups& lk = w.lookups[ci];
+      lk.mult = DBuf<u64>(ctx, h * c.num_lookups);
+      lk.args = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
+      if (!w.h_mult[ci].empty()) {
+        host_lookups = true;
+        HIP_CHECK(hipMemcpyAsync(lk.mult.p, w.h_mult[ci].data(), w.h_mult[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+        if (!w.h_args[ci].empty())
+          HIP_CHECK(hipMemcpyAsync(lk.args.p, w.h_args[ci].data(), w.h_args[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+      }
+    }
+    if (host_lookups) HIP_CHECK(hipEventRecord(ctx.copy_ev[1], ctx.copy_stream));
+    has_host_lookups = host_lookups;
+    const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
+    w.d_claim_offsets = DBuf<u64>(ctx, n_claims + 1);
+    w.d_claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
+    HIP_CHECK(hipMemcpyAsync(w.d_claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    if (tot) HIP_CHECK(hipMemcpyAsync(w.d_claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    HIP_CHECK(hipEventRecord(ctx.copy_ev[2], ctx.copy_stream));
+  }
+  bool has_host_lookups = false;
+  void wait_traces() {
+    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.copy_ev[0], 0));
+  }
+  // SystemWitness::from_stage_1 (src/system.rs:244-328) as one kernel per circuit, from the traces just uploaded
+  void lookup_values() {
+    if (!on) return;
+    HSystem& sys = *w.sys;
+    if (has_host_lookups) HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.copy_ev[1], 0));
+    for (size_t ci = 0; ci < sys.circuits.size(); ci++) {
+      const HCircuit& c = sys.circuits[ci];
+      const size_t h = w.heights[ci];
+      if (!h || !c.num_lookups || !w.h_mult[ci].empty()) continue;
+      DLookups& lk = w.lookups[ci];
+      if (!lookup_values_device(ctx, c.prefix_prog, w.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h, c.main_width, c.pre_width,
+                                c.args_width, lk.mult.p, lk.args.p))
+        throw std::runtime_error("host-resident witness: lookup prefix does not fit the device sweep");
+    }
+  }
+  void wait_claims() {
+    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.copy_ev[2], 0));
+  }
+  ~HostUpload() {
+    if (!on) return;
+    // the copies may still be in flight when a proof is abandoned: wait before the blocks return to the pool
+    (void)hipStreamSynchronize(ctx.copy_stream);
+    for (auto& t : w.traces) t.reset();
+    for (auto& lk : w.lookups) {
+      lk.mult.reset();
+      lk.args.reset();
+    }
+    w.d_claim_offsets.reset();
+    w.d_claim_data.reset();
+  }
+};
+}  // namespace
 
 // ------------------------------------------------------------------ proof bytes (Proof::to_bytes, src/prover.rs:241-248)
 namespace {
@@ -1058,6 +1235,8 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
   };
 
+  HostUpload up(wit, ctx);  // host-resident witness: uploads start now and run beside the transcript set-up
+  up.start();
   Challenger ch(sys.seed);
   // src/system.rs:211-222
   ch.observe((u64)C);
@@ -1089,6 +1268,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   PcsData s1;
   {
     std::vector<DMat> ldes;
+    up.wait_traces();
     for (size_t ci : aidx) {
       size_t h = wit.heights[ci];
       log_degrees.push_back(log2_strict(h));
@@ -1096,6 +1276,8 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
   }
+  up.lookup_values();
+  up.wait_claims();
   // claims, length-prefixed (src/prover.rs:369-373). Large claim sets are hashed on the device: the transcript
   // since the last sample is `ch.input || words`, and the next operation is a sample, so the digest is all
   // the challenger needs. The stage-1 commitment is part of that prefix; it is patched in on the device, so the

@@ -77,6 +77,17 @@ def test_blake3_stream(ctx, oracle, n):
     [(256, 130)],                          # rows longer than one BLAKE3 chunk
     [(64, 300), (64, 1), (8, 129)],
     [(4096, 26), (1024, 2)],
+    # the one-launch sub-tree kernel (hash.hip::subtree_k): single workgroup, several workgroups with the in-launch
+    # hand-over of their roots, an injected group in the first level, inside a sub-tree, among the roots and at the root;
+    # two injected groups take the layer-by-layer path
+    [(2, 1)],
+    [(2048, 1)],
+    [(8192, 3), (2048, 2)],
+    [(4096, 2), (2048, 1)],
+    [(16384, 2), (4, 130)],
+    [(4096, 1), (1, 3)],
+    [(1 << 15, 1), (1 << 13, 2), (4, 1)],
+    [(1 << 17, 2), (1 << 9, 5)],
 ])
 @pytest.mark.parametrize("cap_height", [0, 2])
 def test_mmcs_commit_open(pkg, ctx, oracle, shapes, cap_height):

@@ -134,6 +134,64 @@ def test_full_size_proof_verifies(pkg, ctx, oracle, fe):
     assert o.verify(fe.pack_claims(bad), proof) != 0
 
 
+# BASELINE config 2 at its real size, byte for byte: the GPU proof of 2^20 additions equals the oracle prover's, from the
+# device-resident witness and from the host-resident one (the bench's timed region: upload inside prove)
+def test_full_size_proof_equals_oracle(pkg, ctx, oracle, fe):
+    traces, claims = fe.u32_add_bench_witness(1 << 20)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    o = oracle.System(g.blob)
+    packed = fe.pack_claims(claims)
+    want = o.prove(traces, packed)
+    assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
+    hw = g.host_witness(traces, packed)
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    assert g.prove_multiple_claims(hw).to_bytes() == want   # the per-proof device copies are rebuilt every time
+
+
+# ms_witness_create_host: the witness stays in host memory and every proof uploads it (traces, claims) and runs
+# from_stage_1 on the device; same bytes as the device-resident witness and as the oracle, on every kind of system
+@pytest.mark.parametrize("case", ["bench6", "bench12", "byte_ops", "even_odd_dead", "squares", "pythagorean", "host_sweep"])
+def test_host_resident_witness(pkg, ctx, oracle, fe, case):
+    import os
+
+    params = fe.test_params()
+    if case.startswith("bench") or case == "host_sweep":
+        traces, claims = fe.u32_add_bench_witness(1 << (12 if case == "bench12" else 6))
+        inputs, params = fe.u32_add_system_inputs(), fe.bench_params()
+    elif case == "byte_ops":
+        traces, claims = fe.byte_operations_witness([(0, 10, 5), (1, 30, 20), (2, 100, 40), (3, 200, 100)])
+        inputs = fe.byte_operations_inputs()
+    elif case == "even_odd_dead":
+        traces, claims = fe.even_odd_traces() + [np.zeros((0, 6), dtype=np.uint64)], [[0, 4, 1]]
+        inputs = fe.even_odd_inputs(with_dead=True)
+    elif case == "squares":
+        traces, claims, inputs = fe.squares_traces(64), [], fe.squares_inputs()
+    else:
+        traces, claims, inputs = [fe.pythagorean_trace(64)], [], fe.pythagorean_inputs()
+    g = pkg.System.new(ctx, params, inputs)
+    packed = fe.pack_claims(claims)
+    want = oracle.System(g.blob).prove(traces, packed)
+    if case == "host_sweep":   # lookup values swept on the host at creation and uploaded with every proof
+        os.environ["MSAMD_HOST_LOOKUP_VALUES"] = "1"
+    try:
+        hw = g.host_witness(traces, packed)
+    finally:
+        os.environ.pop("MSAMD_HOST_LOOKUP_VALUES", None)
+    assert hw.pinned
+    for _ in range(3):
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+    # interleaved with a device-resident witness of the same system (pool blocks move between the two)
+    dw = g.witness(traces, packed)
+    assert g.prove_multiple_claims(dw).to_bytes() == want
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    # validation is that of ms_witness_create
+    if traces[-1].size:
+        bad = [t.copy() for t in traces]
+        bad[-1][0, 0] = np.uint64(0xFFFFFFFF00000001)
+        with pytest.raises(pkg.MstarkError, match="canonical"):
+            g.host_witness(bad, packed)
+
+
 # BASELINE config 5: 2^26 additions (228 GiB of the 288 GiB HBM, about a minute with witness generation and the
 # oracle verifier). Opt-in because of its footprint: MSAMD_STRESS=1 python -m pytest tests -m gpu -k config5;
 # the recorded run is profiles/r01_config5_stress.txt (tools/stress.py is the same flow as a script).
@@ -206,7 +264,7 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
 # every alternative code path selectable by environment variable must give the same proof bytes: host-driven FRI rounds,
 # host-side query step, no single-workgroup FRI tail, host sweep for the lookup values, interpreter kernels instead of
 # the hiprtc-compiled ones (the library reads these variables at call time)
-@pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT"])
+@pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE"])
 def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     import os
 
@@ -292,6 +350,32 @@ def test_error_paths_return_codes_not_crashes(pkg, ctx, fe):
     assert g._proof_cap == len(want)
     # and nothing above left the library in a bad state
     assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
+
+
+# An error in the middle of a proof (here: an injected allocation failure at every allocation in turn) must return an
+# error code, drop the read-backs it had queued into locals that no longer exist, and leave the library usable.
+@pytest.mark.parametrize("host", [False, True])
+def test_mid_proof_failure_leaves_the_library_usable(pkg, ctx, fe, host):
+    traces, claims = fe.u32_add_bench_witness(1 << 11)   # claims hashed on the device: read-backs are queued mid-proof
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    w = g.host_witness(traces, packed) if host else g.witness(traces, packed)
+    want = g.prove_multiple_claims(w).to_bytes()
+    failures = 0
+    for nth in range(1, 400):
+        ctx.debug_fail_alloc(nth)
+        try:
+            got = g.prove_multiple_claims(w).to_bytes()
+        except pkg.MstarkError as e:
+            assert "injected" in str(e)
+            failures += 1
+            ctx.debug_fail_alloc(0)
+            assert g.prove_multiple_claims(w).to_bytes() == want
+            continue
+        ctx.debug_fail_alloc(0)
+        assert got == want     # the proof needed fewer than nth allocations
+        break
+    assert failures > 20
 
 
 # a seeded slice of tools/fuzz_parity.py: random systems (constraint graphs, lookups, preprocessed traces, inactive
