@@ -1,4 +1,5 @@
 // Device context: stream, twiddle tables, pooled memory, event-based per-kernel timing.
+#include <cstdlib>
 #include <mutex>
 #include <set>
 
@@ -77,9 +78,20 @@ Ctx::Ctx(int dev) : device(dev) {
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   for (auto& e : copy_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   pinned_half = size_t(8) << 20;
-  if (hipHostMalloc((void**)&pinned, 2 * pinned_half, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&pinned, 2 * pinned_half + 256, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
     pinned = nullptr;  // transfers fall back to pageable staging by the runtime
+  }
+  if (pinned && !getenv("MSAMD_NO_FLAG_SYNC")) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, pinned, 0) == hipSuccess && dp) {
+      pinned_dev = (uint8_t*)dp;
+      flag_host = reinterpret_cast<uint32_t*>(pinned + 2 * pinned_half);
+      flag_dev = reinterpret_cast<uint32_t*>(pinned_dev + 2 * pinned_half);
+      *flag_host = 0;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   const size_t T = size_t(1) << TW_HALF;
   std::vector<u64> h(4 * T);
@@ -224,10 +236,84 @@ void Ctx::trim() {
   pool_free.clear();
 }
 
+// Small read-backs without the runtime's copy + wake-up path: ONE kernel moves every queued segment into the pinned
+// (host-coherent) staging buffer and then raises a flag there with a system-scope release; the host polls the flag.
+// A proof synchronises half a dozen times on a few hundred bytes (a cap, the logUp totals, the opened values), and the
+// blocking wait's wake-up alone left the GPU idle for 35-50 us each time.
+namespace {
+struct FlagCopySeg {
+  const uint8_t* src;
+  uint32_t dst_off, n;  // byte offset in the staging half, byte count (multiples of 4 take the word path)
+};
+struct FlagCopyArgs {
+  FlagCopySeg seg[12];
+  uint32_t n_seg, seq;
+  uint8_t* host_base;   // device-visible address of the staging half
+  uint32_t* flag;       // device-visible address of the flag word
+};
+__global__ __launch_bounds__(256) void flag_copy_k(FlagCopyArgs a) {
+  for (uint32_t s = 0; s < a.n_seg; s++) {
+    const FlagCopySeg sg = a.seg[s];
+    if (((sg.n | sg.dst_off) & 3u) == 0 && (reinterpret_cast<uintptr_t>(sg.src) & 3u) == 0) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(sg.src);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.host_base + sg.dst_off);
+      for (uint32_t i = threadIdx.x; i < sg.n / 4; i += blockDim.x) dst[i] = src[i];
+    } else {
+      for (uint32_t i = threadIdx.x; i < sg.n; i += blockDim.x) a.host_base[sg.dst_off + i] = sg.src[i];
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
 void Ctx::sync_and_deliver() {
-  HIP_CHECK(hipStreamSynchronize(stream));
+  bool done = false;
+  if (flag_host && !down_pending.empty() && down_pending.size() <= 12 && !down_direct) {
+    FlagCopyArgs a;
+    memset(&a, 0, sizeof(a));
+    size_t total = 0;
+    for (size_t i = 0; i < down_pending.size(); i++) {
+      a.seg[i].src = (const uint8_t*)down_pending[i].src;
+      a.seg[i].dst_off = (uint32_t)down_pending[i].off;
+      a.seg[i].n = (uint32_t)down_pending[i].n;
+      total += down_pending[i].n;
+    }
+    if (total <= (size_t(64) << 10)) {
+      a.n_seg = (uint32_t)down_pending.size();
+      a.seq = ++flag_seq;
+      a.host_base = pinned_dev + pinned_half;
+      a.flag = flag_dev;
+      hipLaunchKernelGGL(flag_copy_k, dim3(1), dim3(256), 0, stream, a);
+      HIP_CHECK(hipGetLastError());
+      volatile uint32_t* f = flag_host;
+      // poll; a stream that has failed never raises the flag: look at it now and then
+      for (uint64_t spins = 0;; spins++) {
+        if (*f == a.seq) {
+          done = true;
+          break;
+        }
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+          hipError_t q = hipStreamQuery(stream);
+          if (q != hipErrorNotReady) {
+            HIP_CHECK(q);
+            done = *f == a.seq;
+            break;
+          }
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+  }
+  if (!done) {
+    for (auto& d : down_pending)
+      if (!d.copied) HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + d.off, d.src, d.n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
   for (auto& d : down_pending) memcpy(d.dst, pinned + pinned_half + d.off, d.n);
   down_pending.clear();
+  down_direct = false;
   down_used = 0;
   up_used = 0;  // every queued upload has executed
 }
@@ -250,11 +336,24 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   size_t need = (n + 63) & ~size_t(63);
   if (!pinned || need > pinned_half) {
     HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));  // pageable: staged by the runtime
+    down_direct = true;  // the next synchronisation has to be a real stream synchronisation
     return;
   }
   if (down_used + need > pinned_half) sync_and_deliver();
-  HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
-  down_pending.push_back(PendingD2H{dst, down_used, n});
+  // the copy itself is issued by the next synchronisation: one flag-copy kernel for all short segments, or one
+  // hipMemcpyAsync each when they are many or long
+  PendingD2H pd;
+  pd.dst = dst;
+  pd.src = src;
+  pd.off = down_used;
+  pd.n = n;
+  pd.copied = false;
+  if (!flag_host || n > (size_t(64) << 10)) {
+    HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
+    pd.copied = true;
+    down_direct = true;
+  }
+  down_pending.push_back(pd);
   down_used += need;
   tl_pending_ctx = this;
 }

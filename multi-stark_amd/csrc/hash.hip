@@ -8,11 +8,14 @@
 // height: node = compress(compress(l, r), hash(rows)).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "b3_dev.h"
 #include "b3_quad.h"
 #include "challenge_dev.h"
+#include "fri_dev.h"
 #include "msamd.h"
+#include "tree_dev.h"
 
 namespace msamd {
 
@@ -131,24 +134,6 @@ __device__ __forceinline__ void hash_row(const MatRef* g, size_t H, size_t row, 
   for (int i = 0; i < 8; i++) out[i] = cv[i];
 }
 
-__device__ __forceinline__ void store_digest(Digest* p, const u32 cv[8]) {
-  uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-  q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-}
-__device__ __forceinline__ void load_digest(const Digest* p, u32 cv[8]) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1];
-  cv[0] = a.x;
-  cv[1] = a.y;
-  cv[2] = a.z;
-  cv[3] = a.w;
-  cv[4] = b.x;
-  cv[5] = b.y;
-  cv[6] = b.z;
-  cv[7] = b.w;
-}
-
 template <bool MULTI>
 __global__ __launch_bounds__(256) void leaf_hash_k(const MatRef* __restrict__ g, size_t H, u32 total_w, Digest* out) {
   size_t row = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
@@ -181,24 +166,6 @@ __global__ __launch_bounds__(256) void compress_layer_k(const Digest* __restrict
 
 // ---- fused upper levels. Layers are stored back to back (leaf layer first), so the parents of a layer of
 // `len` digests start right after it.
-__device__ __forceinline__ void lds_store_digest(u32* sh, u32 idx, const u32 cv[8]) {
-  uint4* q = reinterpret_cast<uint4*>(sh + idx * 8);
-  q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-  q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
-}
-__device__ __forceinline__ void lds_load_digest(const u32* sh, u32 idx, u32 cv[8]) {
-  const uint4* q = reinterpret_cast<const uint4*>(sh + idx * 8);
-  uint4 a = q[0], b = q[1];
-  cv[0] = a.x;
-  cv[1] = a.y;
-  cv[2] = a.z;
-  cv[3] = a.w;
-  cv[4] = b.x;
-  cv[5] = b.y;
-  cv[6] = b.z;
-  cv[7] = b.w;
-}
-
 // three levels per launch: thread i turns children [8i, 8i+8) into 4 + 2 + 1 ancestors in registers (no idle
 // lanes at any level). Its 256 bytes of children are fetched by the whole wave with coalesced 16-byte loads and
 // handed over through LDS (lane stride 272 bytes against bank conflicts): a lane reading its own run directly would
@@ -326,91 +293,107 @@ __global__ __launch_bounds__(1024) void tree_tail_k(Digest* __restrict__ layer, 
   }
 }
 
-// Every level above a layer of `len` digests in ONE launch (len = 2^k, 2 <= len <= 2^21). A workgroup owns 2048
-// consecutive children, i.e. a whole sub-tree of depth 11: the first level is one compression per thread straight from
-// global memory, the rest runs on quads out of LDS (as tree_tail_k). With several workgroups the sub-tree roots are
-// handed over in-launch: each root is written through (agent-scope relaxed atomic stores = `sc1`), the workgroup drains
-// its stores and draws a ticket (agent-scope atomic add); the workgroup whose ticket is the last one reads all roots
-// with `sc1` loads and computes the remaining levels (MI355X_MICROARCH.md, inter-workgroup visibility: write-through
-// payload + drained counter, consumer = last arriver). Every layer is still written to global memory for the query
-// phase, none is read back. One injected group (shorter matrices) may sit at any level: that level runs one thread per
-// node. With CH the last workgroup continues with the FRI round's challenger step.
+// Every level above a layer of `len` digests in ONE launch (len = 2^k, 2 <= len <= 2^21). A workgroup owns `sub`
+// consecutive children, i.e. a whole sub-tree. Dependent compressions are latency-bound, so each level picks its form
+// by its size (tools/micro/quad_chain.hip: 1.17 us for a one-lane compression, 0.6 us on a quad, but a quad pass over
+// all 1024 threads costs 3.2 us): one lane per node while a level has 128 nodes or more, quads (b3_quad.h) below.
+// With several workgroups the sub-tree roots are handed over in-launch: each root is written through (agent-scope
+// relaxed atomic stores = `sc1`), the workgroup drains its stores and draws a ticket (agent-scope atomic add); the
+// workgroup whose ticket is the last one reads all roots with `sc1` loads and computes the remaining levels
+// (MI355X_MICROARCH.md, inter-workgroup visibility: write-through payload + drained counter, consumer = last arriver).
+// Every layer is still written to global memory for the query phase, none is read back.
+// INJ: one injected group (shorter matrices) may sit at any level: that level runs one thread per node.
+// CH: the last workgroup continues with the FRI round's challenger step (challenge_dev.h).
+// FOLD: the children are the leaf digests of a FRI layer that this launch produces itself: it folds the previous
+// layer with the challenge the previous round left on the device, writes the folded layer and hashes its rows - a whole
+// commit-phase round (fold, leaves, tree, observe / grind / sample) per launch.
 struct SubtreeParams {
   Digest* child;
   u32 len;
+  u32 sub;       // children per workgroup: 2^j, 2 <= sub <= 2048; len / sub workgroups (<= 1024)
   u32 inj_len;   // length of the layer that takes the injected group (0 = none)
-  const MatRef* g;
   u32 inj_w;
+  const MatRef* g;
   u32 inj_multi; // rows longer than one BLAKE3 chunk
+  u32 pad;
   u32* counter;  // zero at launch; reset by the last workgroup
   FriChallenge fc;
+  FoldArgs fold;            // FOLD: out has 2 * len elements, cur 4 * len
+  const FriTailRound* prev; // FOLD: the round whose beta folds
 };
 
-__device__ __forceinline__ void subtree_levels(u32* sh, u32 n, u32 b, Digest* lvl, u32 glen, const SubtreeParams& p) {
-  const u32 t = threadIdx.x, quad = t >> 2, c = t & 3;
-  for (; n >= 1; n >>= 1) {
-    if (p.inj_len == glen) {  // node = compress(compress(l, r), hash(rows)): one thread per node
-      u32 d[8];
-      const bool act = t < n;
-      if (act) {
-        u32 l[8], r[8], e[8], rh[8];
-        lds_load_digest(sh, 2 * t, l);
-        lds_load_digest(sh, 2 * t + 1, r);
-        b3_compress_pair_root(l, r, e);
-        if (p.inj_multi)
-          hash_row<true>(p.g, glen, size_t(b) * n + t, p.inj_w, rh);
-        else
-          hash_row<false>(p.g, glen, size_t(b) * n + t, p.inj_w, rh);
-        b3_compress_pair_root(e, rh, d);
-      }
-      __syncthreads();
-      if (act) {
-        lds_store_digest(sh, t, d);
-        store_digest(lvl + size_t(b) * n + t, d);
-      }
-      __syncthreads();
-    } else {
-      u32 lo[2], hi[2];
-#pragma unroll
-      for (int ps = 0; ps < 2; ps++) {
-        const u32 q = quad + 256 * ps;
-        if (q < n) b3_quad_parent(sh + 16 * q, lo[ps], hi[ps]);
-      }
-      __syncthreads();
-      u32* out = reinterpret_cast<u32*>(lvl + size_t(b) * n);
-#pragma unroll
-      for (int ps = 0; ps < 2; ps++) {
-        const u32 q = quad + 256 * ps;
-        if (q < n) {
-          sh[8 * q + c] = lo[ps];
-          sh[8 * q + 4 + c] = hi[ps];
-          out[8 * q + c] = lo[ps];
-          out[8 * q + 4 + c] = hi[ps];
-        }
-      }
-      __syncthreads();
+// one level of a sub-tree held in LDS: n nodes from 2n children at sh (digest i at sh + 8 i), results back to sh[0 .. n)
+// and to gout[0 .. n). Called by all 1024 threads.
+template <bool INJ>
+__device__ __forceinline__ void tree_level(u32* sh, u32 n, Digest* gout, const SubtreeParams& p, u32 glen, size_t gfirst) {
+  const u32 t = threadIdx.x;
+  if (INJ && p.inj_len == glen) {  // node = compress(compress(l, r), hash(rows)): one thread per node
+    u32 d[8];
+    const bool act = t < n;
+    if (act) {
+      u32 l[8], r[8], e[8], rh[8];
+      lds_load_digest(sh, 2 * t, l);
+      lds_load_digest(sh, 2 * t + 1, r);
+      b3_compress_pair_root(l, r, e);
+      if (p.inj_multi)
+        hash_row<true>(p.g, glen, gfirst + t, p.inj_w, rh);
+      else
+        hash_row<false>(p.g, glen, gfirst + t, p.inj_w, rh);
+      b3_compress_pair_root(e, rh, d);
     }
-    lvl += glen;
-    glen >>= 1;
+    __syncthreads();
+    if (act) {
+      lds_store_digest(sh, t, d);
+      store_digest(gout + t, d);
+    }
+    __syncthreads();
+  } else {
+    tree_level_plain(sh, n, gout);
   }
 }
 
-template <bool CH>
+template <bool CH, bool INJ, bool FOLD>
 __global__ __launch_bounds__(1024) void subtree_k(SubtreeParams p) {
   __shared__ __attribute__((aligned(16))) u32 sh[1024 * 8];
   __shared__ ChallengeShared cs;
   __shared__ u32 s_last;
-  const u32 t = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  const u32 t = threadIdx.x, nb = gridDim.x;
+  u32 b = blockIdx.x;
   Digest* lvl = p.child + p.len;  // the first parent layer
   u32 glen = p.len >> 1;          // its length
   u32 n;
-  if (p.len >= 2048) {  // 2048 children per workgroup: level 1 from global memory, one node per thread
+  E2 hb = e2(0), rf = e2(0);
+  if (FOLD) {
+    const E2 beta = p.prev->beta;
+    hb = e2_mul_base(beta, 0x7FFFFFFF80000001ULL);
+    rf = e2_sqr(beta);
+  }
+  if (p.sub == 2048) {  // level 1 in registers: one node per thread from its two children
     u32 l[8], r[8], d[8];
-    const Digest* mine = p.child + size_t(b) * 2048 + 2 * t;
-    load_digest(mine, l);
-    load_digest(mine + 1, r);
+    const size_t c0 = size_t(b) * 2048 + 2 * t;
+    if (FOLD) {
+      u32 m[16];
+      E2 o0 = fri_fold_one(p.fold, 2 * c0, hb, rf), o1 = fri_fold_one(p.fold, 2 * c0 + 1, hb, rf);
+      p.fold.out[2 * c0] = o0;
+      p.fold.out[2 * c0 + 1] = o1;
+      fri_row_block(o0, o1, m);
+      b3_iv(l);
+      b3_compress(l, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      o0 = fri_fold_one(p.fold, 2 * c0 + 2, hb, rf);
+      o1 = fri_fold_one(p.fold, 2 * c0 + 3, hb, rf);
+      p.fold.out[2 * c0 + 2] = o0;
+      p.fold.out[2 * c0 + 3] = o1;
+      fri_row_block(o0, o1, m);
+      b3_iv(r);
+      b3_compress(r, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+      store_digest(p.child + c0, l);
+      store_digest(p.child + c0 + 1, r);
+    } else {
+      load_digest(p.child + c0, l);
+      load_digest(p.child + c0 + 1, r);
+    }
     b3_compress_pair_root(l, r, d);
-    if (p.inj_len == glen) {
+    if (INJ && p.inj_len == glen) {
       u32 rh[8], e[8];
       if (p.inj_multi)
         hash_row<true>(p.g, glen, size_t(b) * 1024 + t, p.inj_w, rh);
@@ -425,39 +408,56 @@ __global__ __launch_bounds__(1024) void subtree_k(SubtreeParams p) {
     lvl += glen;
     glen >>= 1;
     n = 512;
-  } else {
-    if (t < p.len) {
+  } else {  // sub <= 1024 children straight into LDS
+    if (t < p.sub) {
       u32 d[8];
-      load_digest(p.child + t, d);
+      const size_t c0 = size_t(b) * p.sub + t;
+      if (FOLD) {
+        u32 m[16];
+        const E2 o0 = fri_fold_one(p.fold, 2 * c0, hb, rf), o1 = fri_fold_one(p.fold, 2 * c0 + 1, hb, rf);
+        p.fold.out[2 * c0] = o0;
+        p.fold.out[2 * c0 + 1] = o1;
+        fri_row_block(o0, o1, m);
+        b3_iv(d);
+        b3_compress(d, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+        store_digest(p.child + c0, d);
+      } else {
+        load_digest(p.child + c0, d);
+      }
       lds_store_digest(sh, t, d);
     }
-    n = p.len >> 1;
+    n = p.sub >> 1;
   }
   if (CH && t < 8) cs.st[t] = p.fc.state[t];
   __syncthreads();
-  subtree_levels(sh, n, b, lvl, glen, p);
-  if (nb > 1) {
-    // hand the sub-tree root (sh[0..7], already stored plainly for later kernels) to the last workgroup
-    Digest* roots = p.child;
-    {
-      size_t off = 0;
-      for (u32 l = p.len; l > nb; l >>= 1) off += l;
-      roots += off;  // the layer of nb digests
+#pragma unroll 1
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) {
+      if (nb == 1) break;
+      // hand the sub-tree root (sh[0..7], already stored plainly for later kernels) to the last workgroup
+      Digest* roots = lvl - nb;  // the layer of nb digests this phase just completed
+      if (t < 8) __hip_atomic_store(reinterpret_cast<u32*>(roots + b) + t, sh[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const u32 ticket = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == nb - 1 ? 1u : 0u;
+      }
+      __syncthreads();
+      if (!s_last) return;
+      const u32* rw = reinterpret_cast<const u32*>(roots);
+      for (u32 i = t; i < nb * 8; i += 1024) sh[i] = __hip_atomic_load(rw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      b = 0;
+      n = nb >> 1;
     }
-    if (t < 8) __hip_atomic_store(reinterpret_cast<u32*>(roots + b) + t, sh[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-      const u32 ticket = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = ticket == nb - 1 ? 1u : 0u;
+#pragma unroll 1
+    for (; n >= 1; n >>= 1) {
+      tree_level<INJ>(sh, n, lvl + size_t(b) * n, p, glen, size_t(b) * n);
+      lvl += glen;
+      glen >>= 1;
     }
-    __syncthreads();
-    if (!s_last) return;
-    const u32* rw = reinterpret_cast<const u32*>(roots);
-    for (u32 i = t; i < nb * 8; i += 1024) sh[i] = __hip_atomic_load(rw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    subtree_levels(sh, nb >> 1, 0, roots + nb, nb >> 1, p);
   }
   if (CH) {
     challenger_round<1024>(cs, sh, p.fc.pow_bits);
@@ -614,6 +614,16 @@ struct InjectAt {
   u32 total_w = 0;
   size_t count = 0;
 };
+// children per workgroup of subtree_k: one workgroup up to 1024 children; above that about 256 workgroups (one per CU),
+// each owning between 8 and 2048 children, so that the leaf work spreads over the chip while the hand-over stays one hop
+static u32 subtree_children_per_group(size_t len) {
+  if (len <= 1024) return (u32)len;
+  size_t sub = len / 256;
+  if (sub < 8) sub = 8;
+  if (sub > 2048) sub = 2048;
+  return (u32)sub;
+}
+
 static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, const MatRef* drefs, const FriChallenge* fc = nullptr) {
   const size_t L = t.layer_len.size();
   size_t last_inject = 0;
@@ -626,7 +636,7 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
   while (li < L) {
     const size_t child_len = t.layer_len[li - 1];
     Digest* child = t.base() + t.layer_off[li - 1];
-    // all remaining levels in one launch (sub-trees of 2048 children + in-launch hand-over of their roots)
+    // all remaining levels in one launch (sub-trees per workgroup + in-launch hand-over of their roots)
     if (!no_subtree && child_len >= 2 && child_len <= (size_t(1) << std::min(subtree_max_log, 21u))) {
       size_t n_inj = 0, inj_li = 0;
       for (size_t k = li; k < L; k++)
@@ -634,23 +644,27 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
           n_inj++;
           inj_li = k;
         }
-      if (n_inj <= 1) {
+      if (n_inj == 0 || (n_inj == 1 && !fc)) {
         SubtreeParams sp;
+        memset(&sp, 0, sizeof(sp));
         sp.child = child;
         sp.len = (u32)child_len;
+        sp.sub = subtree_children_per_group(child_len);
         sp.inj_len = n_inj ? (u32)t.layer_len[inj_li] : 0u;
         sp.g = n_inj ? drefs + inj[inj_li].first : nullptr;
         sp.inj_w = n_inj ? inj[inj_li].total_w : 0u;
         sp.inj_multi = n_inj && inj[inj_li].total_w > 128 ? 1u : 0u;
         sp.counter = ctx.tree_counter;
         sp.fc = fc ? *fc : FriChallenge{};
-        const unsigned nb = child_len >= 2048 ? (unsigned)(child_len / 2048) : 1u;
+        const unsigned nb = (unsigned)(child_len / sp.sub);
         const KernelId kid = fc ? K_OTHER : K_COMPRESS;
         hipEvent_t ev = ctx.prof_begin(kid);
         if (fc)
-          hipLaunchKernelGGL(subtree_k<true>, dim3(nb), dim3(1024), 0, ctx.stream, sp);
+          hipLaunchKernelGGL((subtree_k<true, false, false>), dim3(nb), dim3(1024), 0, ctx.stream, sp);
+        else if (n_inj)
+          hipLaunchKernelGGL((subtree_k<false, true, false>), dim3(nb), dim3(1024), 0, ctx.stream, sp);
         else
-          hipLaunchKernelGGL(subtree_k<false>, dim3(nb), dim3(1024), 0, ctx.stream, sp);
+          hipLaunchKernelGGL((subtree_k<false, false, false>), dim3(nb), dim3(1024), 0, ctx.stream, sp);
         ctx.prof_end(kid, ev, 96.0 * double(child_len) + (n_inj ? 8.0 * sp.inj_w * sp.inj_len : 0.0));
         fc = nullptr;
         li = L;
@@ -708,6 +722,39 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
 void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc) {
   std::vector<InjectAt> inj(t.layer_len.size());
   build_levels(ctx, t, inj, nullptr, fc);
+}
+
+bool fri_round_fusable(size_t rows) {
+  const char* off = getenv("MSAMD_NO_FRI_FUSED");
+  return !off && !getenv("MSAMD_NO_SUBTREE") && rows >= 4 && rows / 2 <= (size_t(1) << 21);
+}
+
+// One commit-phase round in one launch: fold `cur` (2 * rows elements) with the beta of `prev` into `out` (rows elements),
+// hash the rows / 2 leaves of the folded layer into t's leaf layer, build t and run the challenger step `fc` on its root.
+void fri_round_fused(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriTailRound* prev, const E2* roll_in, E2* out,
+                     const FriChallenge& fc) {
+  const size_t leaves = rows / 2;
+  const unsigned lr = log2_strict(rows);
+  if (lr + 1 > TW_LOG) throw std::runtime_error("FRI layer above 2^28 is not supported");
+  if (!t.digests.p) merkle_alloc(ctx, t, leaves);
+  SubtreeParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.child = t.base();
+  sp.len = (u32)leaves;
+  sp.sub = subtree_children_per_group(leaves);
+  sp.counter = ctx.tree_counter;
+  sp.fc = fc;
+  sp.fold.cur = cur;
+  sp.fold.roll = roll_in;
+  sp.fold.out = out;
+  sp.fold.t0i = ctx.tw0i;
+  sp.fold.t1i = ctx.tw1i;
+  sp.fold.log_rows = lr;
+  sp.prev = prev;
+  hipEvent_t ev = ctx.prof_begin(K_FRI_FOLD);
+  hipLaunchKernelGGL((subtree_k<true, false, true>), dim3((unsigned)(leaves / sp.sub)), dim3(1024), 0, ctx.stream, sp);
+  ctx.prof_end(K_FRI_FOLD, ev, 48.0 * rows + 64.0 * leaves);
+  HIP_CHECK(hipGetLastError());
 }
 
 void merkle_build(Ctx& ctx, DTree& t) {

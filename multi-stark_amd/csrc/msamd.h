@@ -83,9 +83,15 @@ struct Ctx {
   size_t pinned_half = 0, up_used = 0, down_used = 0;
   struct PendingD2H {
     void* dst;
+    const void* src;
     size_t off, n;
+    bool copied;  // a hipMemcpyAsync into the staging buffer has already been issued
   };
   std::vector<PendingD2H> down_pending;
+  bool down_direct = false;        // some queued read-back bypasses the flag-copy kernel
+  uint8_t* pinned_dev = nullptr;   // device-visible address of `pinned`
+  uint32_t *flag_host = nullptr, *flag_dev = nullptr;  // completion flag of the flag-copy kernel (in the pinned block)
+  uint32_t flag_seq = 0;
   // LDE scale vectors (g w^k0)^j / n, per log_n and log_blowup
   std::map<std::pair<unsigned, unsigned>, u64*> lde_scales;
   // profiling
@@ -364,6 +370,11 @@ struct FriChallenge {
   FriTailRound* rec;
   uint32_t pow_bits;
 };
+// One commit-phase round in ONE launch (hash.hip::subtree_k): fold with the challenge `prev` left on the device, leaf
+// digests of the folded layer, its whole tree and the challenger step `fc`. fusable: rows / 2 leaves fit the kernel.
+bool fri_round_fusable(size_t rows);
+void fri_round_fused(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriTailRound* prev, const E2* roll_in, E2* out,
+                     const FriChallenge& fc);
 // fold with beta read from rec (device); next_leaves != nullptr also writes the next layer's leaf digests
 void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in /*nullable*/, E2* out,
                   Digest* next_leaves /*nullable*/);

@@ -6,6 +6,8 @@
 #include "b3_dev.h"
 #include "b3_quad.h"
 #include "challenge_dev.h"
+#include "fri_dev.h"
+#include "tree_dev.h"
 #include "msamd.h"
 
 namespace msamd {
@@ -226,8 +228,8 @@ __global__ __launch_bounds__(256) void fri_fold_k(const E2* __restrict__ cur, si
   u32 e = bitrev32((u32)i, log_rows) << (TW_LOG - log_rows - 1);
   u64 gp = gl_mul(t1i[e >> TW_HALF], t0i[e & ((1u << TW_HALF) - 1)]);
   E2 pw = e2_mul_base(half_beta, gp);
-  E2 lo = cur[2 * i], hi = cur[2 * i + 1];
-  E2 r = e2_add(e2_mul(e2(gl_add(half, pw.c0), pw.c1), lo), e2_mul(e2(gl_sub(half, pw.c0), gl_neg(pw.c1)), hi));
+  (void)half;
+  E2 r = fri_fold_value(cur[2 * i], cur[2 * i + 1], pw);
   if (roll) r = e2_add(r, e2_mul(roll_f, roll[i]));
   out[i] = r;
 }
@@ -280,8 +282,7 @@ __global__ __launch_bounds__(256) void fri_fold_dev_k(const E2* __restrict__ cur
       u32 e = bitrev32((u32)i, log_rows) << (TW_LOG - log_rows - 1);
       u64 gp = gl_mul(t1i[e >> TW_HALF], t0i[e & ((1u << TW_HALF) - 1)]);
       E2 pw = e2_mul_base(hb, gp);
-      E2 lo = cur[2 * i], hi = cur[2 * i + 1];
-      E2 r = e2_add(e2_mul(e2(gl_add(half, pw.c0), pw.c1), lo), e2_mul(e2(gl_sub(half, pw.c0), gl_neg(pw.c1)), hi));
+      E2 r = fri_fold_value(cur[2 * i], cur[2 * i + 1], pw);
       if (roll) r = e2_add(r, e2_mul(rf, roll[i]));
       out[i] = r;
       o[k] = r;
@@ -406,49 +407,34 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
   for (u32 r = 0; r < p.n_rounds; r++) {
     const u32 rows = len >> 1;
     const unsigned log_rows = 31 - __clz(rows);
-    // ---- leaf digests (ExtensionMmcs rows of two Ext2 values = 32 bytes) and tree levels, one node per quad
-    // (b3_quad.h): the whole round is a chain of dependent compressions over at most 1024 nodes
+    // ---- leaf digests (ExtensionMmcs rows of two Ext2 values = 32 bytes) and tree levels. The whole round is a chain
+    // of dependent compressions: one lane per node while a level has 128 nodes or more, one quad per node below
+    // (tree_dev.h)
     const u32 quad = t >> 2, qc = t & 3;
     u32* gout = reinterpret_cast<u32*>(tout);
-    {
-      u32 lo[4], hi[4];
-#pragma unroll
-      for (int ps = 0; ps < 4; ps++) {
-        const u32 q = quad + 256 * ps;
-        if (q < rows) b3_quad_row32(reinterpret_cast<const u32*>(&cur[2 * q]), lo[ps], hi[ps]);
+    if (rows >= 128) {
+      if (t < rows) {
+        u32 m[16], cv[8];
+        fri_row_block(cur[2 * t], cur[2 * t + 1], m);
+        b3_iv(cv);
+        b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+        lds_store_digest(tree, t, cv);
+        store_digest(tout + t, cv);
       }
-#pragma unroll
-      for (int ps = 0; ps < 4; ps++) {
-        const u32 q = quad + 256 * ps;
-        if (q < rows) {
-          tree[8 * q + qc] = lo[ps];
-          tree[8 * q + 4 + qc] = hi[ps];
-          gout[8 * q + qc] = lo[ps];
-          gout[8 * q + 4 + qc] = hi[ps];
-        }
+    } else {
+      u32 lo = 0, hi = 0;
+      if (quad < rows) {
+        b3_quad_row32(reinterpret_cast<const u32*>(&cur[2 * quad]), lo, hi);
+        tree[8 * quad + qc] = lo;
+        tree[8 * quad + 4 + qc] = hi;
+        gout[8 * quad + qc] = lo;
+        gout[8 * quad + 4 + qc] = hi;
       }
     }
     __syncthreads();
     gout += 8 * rows;
     for (u32 n = rows >> 1; n >= 1; n >>= 1) {
-      u32 lo[2], hi[2];
-#pragma unroll
-      for (int ps = 0; ps < 2; ps++) {
-        const u32 q = quad + 256 * ps;
-        if (q < n) b3_quad_parent(tree + 16 * q, lo[ps], hi[ps]);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ps = 0; ps < 2; ps++) {
-        const u32 q = quad + 256 * ps;
-        if (q < n) {
-          tree[8 * q + qc] = lo[ps];
-          tree[8 * q + 4 + qc] = hi[ps];
-          gout[8 * q + qc] = lo[ps];
-          gout[8 * q + 4 + qc] = hi[ps];
-        }
-      }
-      __syncthreads();
+      tree_level_plain(tree, n, reinterpret_cast<Digest*>(gout));
       gout += 8 * n;
     }
     tout = reinterpret_cast<Digest*>(gout);
@@ -469,8 +455,7 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
       u32 e = bitrev32(t, log_rows) << (TW_LOG - log_rows - 1);
       u64 gp = gl_mul(p.t1i[e >> TW_HALF], p.t0i[e & ((1u << TW_HALF) - 1)]);
       E2 pw = e2_mul_base(hb, gp);
-      E2 lo = cur[2 * t], hi = cur[2 * t + 1];
-      nv = e2_add(e2_mul(e2(gl_add(half, pw.c0), pw.c1), lo), e2_mul(e2(gl_sub(half, pw.c0), gl_neg(pw.c1)), hi));
+      nv = fri_fold_value(cur[2 * t], cur[2 * t + 1], pw);
       if (do_roll) nv = e2_add(nv, e2_mul(e2_sqr(beta), p.roll[roll_i].p[t]));
     }
     __syncthreads();
@@ -533,32 +518,37 @@ __global__ __launch_bounds__(1024) void fri_query_challenge_k(const u32* __restr
     }
     __syncthreads();
   }
-  if (t == 0) {
-    int pos;
-    if (pow_bits) {
-      pos = 24;  // check_witness' sample_bits consumed digest bytes 24..31
-    } else {
+  int pos;
+  if (pow_bits) {
+    pos = 24;  // check_witness' sample_bits consumed digest bytes 24..31
+  } else {
+    if (t == 0) {
       u32 cv[8];
       b3_iv(cv);
       b3_compress(cv, blk, 0, 48, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
       for (int k = 0; k < 8; k++) dg[k] = cv[k];
+    }
+    __syncthreads();
+    pos = 32;
+  }
+  if (t == 0) out[0] = wit;
+  // every query index is 8 bytes popped from the back of the output buffer; an exhausted buffer is refilled by
+  // digest <- BLAKE3(digest): a chain of dependent compressions, each run by one quad (half the latency of one lane)
+  const u64 imask = (u64(1) << log_max_height) - 1;
+  for (u32 q = 0; q < n_queries; q++) {
+    if (pos == 0) {
+      u32 lo = 0, hi = 0;
+      if (t < 4) b3_quad_row32(dg, lo, hi);
+      __syncthreads();
+      if (t < 4) {
+        dg[t] = lo;
+        dg[4 + t] = hi;
+      }
+      __syncthreads();
       pos = 32;
     }
-    out[0] = wit;
-    const u64 imask = (u64(1) << log_max_height) - 1;
-    for (u32 q = 0; q < n_queries; q++) {
-      if (pos == 0) {  // output buffer exhausted: digest <- BLAKE3(digest)
-        u32 m[16], nv[8];
-        for (int k = 0; k < 8; k++) m[k] = dg[k];
-        for (int k = 8; k < 16; k++) m[k] = 0;
-        b3_iv(nv);
-        b3_compress(nv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-        for (int k = 0; k < 8; k++) dg[k] = nv[k];
-        pos = 32;
-      }
-      pos -= 8;
-      out[1 + q] = be64_at(dg, pos) & imask;
-    }
+    pos -= 8;
+    if (t == 0) out[1 + q] = be64_at(dg, pos) & imask;
   }
 }
 

@@ -967,7 +967,8 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     d_recs = DBuf<FriTailRound>(ctx, n_total);
     d_final = DBuf<E2>(ctx, stop);
     size_t r = 0;
-    bool leaves_done = false;
+    bool leaves_done = false;  // the fold of the previous round already hashed this round's leaves
+    bool tree_done = false;    // the previous round's fused launch already built this round's tree and ran its challenger step
     while (folded.n > stop) {
       if (use_tail && folded.n <= 2048) {
         const uint32_t len0 = (uint32_t)folded.n;
@@ -1009,26 +1010,40 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
         break;
       }
       const size_t rows = folded.n / 2;
-      if (!leaves_done) {
-        trees.emplace_back();
-        trees.back().cap_height = 0;
+      if (!tree_done) {
+        if (!leaves_done) {
+          trees.emplace_back();
+          trees.back().cap_height = 0;
+        }
+        FriChallenge fc{d_state.p, d_recs.p + r, (uint32_t)prm.commit_pow_bits};
+        fri_tree_build(ctx, trees.back(), leaves_done ? nullptr : folded.p, rows, &fc);
       }
-      DTree& t = trees.back();
-      FriChallenge fc{d_state.p, d_recs.p + r, (uint32_t)prm.commit_pow_bits};
-      fri_tree_build(ctx, t, leaves_done ? nullptr : folded.p, rows, &fc);
       DBuf<E2> nxt(ctx, rows);
       const E2* roll = nullptr;
       if (next_in < inputs.size() && inputs[next_in].n == rows) roll = inputs[next_in++].p;
-      // the next round's leaf layer is hashed by the fold itself unless that round belongs to the tail kernel
-      leaves_done = rows > stop && rows >= 2 && !(use_tail && rows <= 2048);
-      Digest* next_leaves = nullptr;
-      if (leaves_done) {
+      // does the folded vector get a commit round of its own outside the tail kernel?
+      const bool next_is_round = rows > stop && rows >= 2 && !(use_tail && rows <= 2048);
+      if (next_is_round && fri_round_fusable(rows)) {
+        // that whole round - this fold, its leaf digests, its tree, its challenger step - is ONE launch
         trees.emplace_back();
         trees.back().cap_height = 0;
-        merkle_alloc(ctx, trees.back(), rows / 2);
-        next_leaves = trees.back().base();
+        FriChallenge fc_next{d_state.p, d_recs.p + r + 1, (uint32_t)prm.commit_pow_bits};
+        fri_round_fused(ctx, trees.back(), folded.p, rows, d_recs.p + r, roll, nxt.p, fc_next);
+        tree_done = true;
+        leaves_done = false;
+      } else {
+        tree_done = false;
+        // the next round's leaf layer is hashed by the fold itself unless that round belongs to the tail kernel
+        leaves_done = next_is_round;
+        Digest* next_leaves = nullptr;
+        if (leaves_done) {
+          trees.emplace_back();
+          trees.back().cap_height = 0;
+          merkle_alloc(ctx, trees.back(), rows / 2);
+          next_leaves = trees.back().base();
+        }
+        fri_fold_dev(ctx, folded.p, rows, d_recs.p + r, roll, nxt.p, next_leaves);
       }
-      fri_fold_dev(ctx, folded.p, rows, d_recs.p + r, roll, nxt.p, next_leaves);
       layers.push_back(folded.p);
       layer_bufs.push_back(std::move(folded));
       folded = std::move(nxt);
