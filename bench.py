@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — prove() throughput of the U32-add + byte-table workload (benches/multi_stark.rs, bench_config())
-on MI355X. One step = one System::prove_multiple_claims over the reference's timed region (SURVEY §8d,
-benches/multi_stark.rs:292-296): the witness (traces + claims) is in pinned HOST memory when the step starts, the
-proof bytes are in host memory when it ends; upload, from_stage_1 on the device and read-back are inside. The
-HBM-resident figure (witness uploaded once, outside) is reported beside it as config.hbm_resident_ms.
+on MI355X.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: weak scaling, one independent [ByteTable, U32Add @ 2^20] system per GPU (per-rank xorshift seeds as in
-SURVEY §8d config 3); the only data-path collective is an all_gather of each rank's three 32-byte commitments
-(RCCL) which rank 0 folds into a joint digest. Rank 0 prints ONE JSON line.
+N = 1 (BASELINE config 2): one step = one System::prove_multiple_claims over the reference's timed region (SURVEY §8d,
+benches/multi_stark.rs:292-296): the witness (traces + claims) is in pinned HOST memory when the step starts, the proof
+bytes are in host memory when it ends; upload, from_stage_1 on the device and read-back are inside. The HBM-resident
+figure (witness uploaded once, outside) is reported beside it as config.hbm_resident_ms.
+
+N > 1 (BASELINE config 3, weak scaling): one step = ONE proof of the system [ByteTable, U32Add x N] computed by all
+ranks together (ms_prove_sharded): rank k computes adder k (2^20 rows, its own xorshift seeds), every commitment is
+one Merkle tree over all matrices, so the LDE row ranges are exchanged before leaf hashing (all-to-all), sub-tree
+roots / logUp totals / opened values / reduced openings are all-gathered, and every rank returns the same proof bytes.
+The exchanges run on the library's own RCCL transport (csrc/comm_rccl.hip: grouped ncclSend / ncclRecv and ncclAllGather
+called from C); torch.distributed only bootstraps (the 128-byte RCCL id, the barrier, the max over ranks). In this mode
+each rank's witness is resident in HBM (ms_prove_sharded takes device-resident witnesses). The independent-proof mode
+(one [ByteTable, U32Add] proof per GPU, host-resident witnesses, commitments all-gathered) is measured in the same run
+and reported as the secondary object `replicas`. Rank 0 prints ONE JSON line.
 """
 import argparse
 import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,6 +38,10 @@ from __graft_entry__ import load_package, load_oracle  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ALG_BYTES_PER_ROW = 5512
 TRAFFIC_FILE = "r02_traffic.json"
+WORKLOAD = ("U32-add + byte-table lookup (benches/multi_stark.rs), 2^%d additions per %s, bench_config(): log_blowup 2, "
+            "100 queries, 10+10 PoW bits, GoldilocksBlake3Config; %s, proof bytes returned to host")
+HOST_RESIDENT = ("witness (traces + claims) in pinned host memory at step start: upload, from_stage_1 on the device and "
+                 "read-back inside the timed region")
 
 
 def parse_args():
@@ -36,25 +49,353 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--log-adds", type=int, default=20, help="log2 of U32 additions per proof (BASELINE: 20)")
+    ap.add_argument("--log-adds", type=int, default=20, help="log2 of U32 additions per proof / per rank (BASELINE: 20)")
     ap.add_argument("--cpu-log-adds", type=int, default=20, help="size of the CPU baseline leg (same workload as the GPU by default)")
-    ap.add_argument("--hbm-resident", action="store_true", help="primary figure from a witness already resident in HBM "
-                    "(round-1 definition) instead of the host-resident one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
-                    "rehearse the multi-rank path with several ranks sharing one GPU)")
-    ap.add_argument("--joint", action="store_true", help="N > 1: ONE proof of the system [ByteTable, U32Add x N] computed by all "
-                    "ranks together (ms_prove_sharded, BASELINE config 3) instead of one independent proof per rank")
-    ap.add_argument("--no-joint-leg", action="store_true", help="N > 1: skip the secondary measurement of the joint proof")
-    ap.add_argument("--primary-timeout", type=float, default=600.0, help="N > 1: seconds after which a primary leg that cannot "
-                    "finish (a failed rank leaves the others in a collective) ends the job with a non-zero status")
-    ap.add_argument("--joint-timeout", type=float, default=240.0, help="seconds after which the secondary joint-proof "
-                    "measurement is abandoned (the primary result is still printed)")
+    ap.add_argument("--hbm-resident", action="store_true", help="N = 1: primary figure from a witness already resident in HBM "
+                    "(round-1 definition) instead of the host-resident one")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL on ROCm; gloo only to "
+                    "rehearse the multi-rank path with several ranks sharing one GPU: the exchanges then go through TorchComm)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="N > 1: who runs the joint proof's exchanges: "
+                    "the library's own RCCL transport (default) or torch.distributed callbacks")
+    ap.add_argument("--joint", action="store_true", help="(default for N > 1) the joint proof is the primary figure")
+    ap.add_argument("--replicas-primary", action="store_true", help="N > 1: one independent proof per rank as the primary figure")
+    ap.add_argument("--no-replicas-leg", action="store_true", help="N > 1: skip the secondary independent-proof measurement")
+    ap.add_argument("--no-joint-leg", action="store_true", help="N > 1 with --replicas-primary: skip the joint proof")
+    ap.add_argument("--primary-timeout", type=float, default=600.0, help="N > 1: seconds after which a leg that cannot finish (a "
+                    "failed rank leaves the others in a collective) ends the job with a non-zero status")
     return ap.parse_args()
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+class Watchdog:
+    """Ends the whole job with a NON-ZERO status when a leg cannot finish: one rank failing inside a collective would leave
+    the others blocked forever, and a hang must not be recorded as a success. Whatever rank 0 has measured so far is
+    printed first, with the error recorded."""
+
+    def __init__(self, rank, what, seconds, partial):
+        self.done = threading.Event()
+        self.rank, self.what, self.seconds, self.partial = rank, what, seconds, partial
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def _run(self):
+        if self.done.wait(self.seconds):
+            return
+        log("[rank %d] %s did not finish within %.0f s: exiting with status 3" % (self.rank, self.what, self.seconds))
+        if self.rank == 0:
+            line = self.partial()
+            if line is not None:
+                line["error"] = "%s timed out after %.0f s (collective hang or a failed rank)" % (self.what, self.seconds)
+                print(json.dumps(line), flush=True)
+        os._exit(3)
+
+    def finish(self):
+        self.done.set()
+
+
+def profile_first_step(ctx, step, rank):
+    """one untimed step with HIP events around every kernel class: picks the dominant class"""
+    names = ctx.kernel_names()
+    ctx.set_profile(names)
+    ctx.reset_stats()
+    proof = step()
+    table = ctx.kernel_stats()
+    ctx.set_profile([])
+    ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+    dominant = ranked[0][0] if ranked and ranked[0][1]["ms"] > 0 else "ntt12_dif"
+    if rank == 0:
+        log("per-kernel-class device time of one proof (HIP events, profiled warmup step):")
+        for n, s in ranked:
+            if s["launches"]:
+                log("  %-16s launches %4d  total %8.3f ms  alg %.1f GB/s" % (n, s["launches"], s["ms"], s["alg_bytes"] / max(s["ms"], 1e-9) / 1e6))
+    return proof, dominant
+
+
+def roofline_of(dominant, dom):
+    avg_ms = dom["ms"] / max(dom["launches"], 1)
+    bytes_per_launch = dom["alg_bytes"] / max(dom["launches"], 1)
+    achieved = bytes_per_launch / max(avg_ms, 1e-12) / 1e6  # GB/s
+    return {
+        "kernel": dominant,
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": measured_traffic(dominant),
+        "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % TRAFFIC_FILE,
+        "avg_launch_ms": avg_ms,
+        "alg_bytes_per_launch": bytes_per_launch,
+        "launches": dom["launches"],
+    }
+
+
+def base_line(args, n_gpus, value, ms_per_step):
+    return {
+        "metric": "prove_trace_rows_per_sec",
+        "value": value,
+        "unit": "rows/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+    }
+
+
+# ------------------------------------------------------------------------------------------------ N = 1
+def single_gpu(args, pkg, fe, ctx, torch):
+    num_adds = 1 << args.log_adds
+    t = time.time()
+    traces, claims = fe.u32_add_bench_witness(num_adds)
+    system = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    # setup, untimed (criterion's setup closure builds the witness): validate + page-lock the host buffers. Every timed step
+    # uploads them and runs SystemWitness::from_stage_1 on the device.
+    witness = system.witness(traces, packed) if args.hbm_resident else system.host_witness(traces, packed)
+    if not args.hbm_resident and not witness.pinned:
+        log("warning: host buffers could not be page-locked; uploads are staged by the runtime")
+    rows = witness.rows
+    log("witness ready in %.1fs: %d rows/proof" % (time.time() - t, rows))
+
+    def step():
+        return system.prove_multiple_claims(witness)
+
+    def sync():
+        ctx.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    proof, dominant = profile_first_step(ctx, step, 0)
+    for _ in range(max(args.warmup, 1) - 1):
+        proof = step()
+    log("warm-up done (%d steps); timing %d steps" % (max(args.warmup, 1), args.steps))
+    # ---- timed region: exactly K steps, HIP events only around the dominant kernel class
+    ctx.set_profile([dominant])
+    ctx.reset_stats()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    log("timed region done: %.3f ms per step" % (1e3 * elapsed / args.steps))
+    dom = ctx.kernel_stats()[dominant]
+    ctx.set_profile([])
+    stage = system.prove_multiple_claims(witness, want_times=True).stage_ms
+    # the same proof from a witness that already sits in HBM (round-1 definition of the step): context, never `value`
+    hbm_ms = None
+    if not args.hbm_resident:
+        dw = system.witness(traces, packed)
+        assert system.prove_multiple_claims(dw).to_bytes() == proof.to_bytes()
+        k = max(3, min(args.steps, 10))
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            system.prove_multiple_claims(dw)
+        ctx.sync()
+        hbm_ms = 1e3 * (time.perf_counter() - t1) / k
+        del dw
+        log("HBM-resident witness: %.3f ms per proof" % hbm_ms)
+    result = base_line(args, 1, rows * args.steps / elapsed, 1e3 * elapsed / args.steps)
+    result["config"] = {
+        "workload": WORKLOAD % (args.log_adds, "proof", "witness resident in HBM" if args.hbm_resident else HOST_RESIDENT),
+        "rows_per_proof": rows,
+        "proof_bytes": len(proof.to_bytes()),
+        "parallelism": "single GPU",
+        "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+        "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows / (elapsed / args.steps) / 1e9,
+        "hbm_resident_ms": hbm_ms,
+        "host_bytes_uploaded_per_proof": None if args.hbm_resident else int(sum(t.nbytes for t in traces) + packed[0].nbytes + packed[1].nbytes),
+    }
+    result["roofline"] = roofline_of(dominant, dom)
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(fe, system.blob, args.cpu_log_adds)
+    return result
+
+
+# ------------------------------------------------------------------------------------------------ N > 1
+def timed_steps(args, ctx, torch, dist, step, sync_extra, dev):
+    """W warm-up steps (the first one profiled), then exactly K steps between barrier + synchronize; max over ranks"""
+    rank = dist.get_rank()
+
+    def sync_all():
+        ctx.sync()
+        sync_extra()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    proof, dominant = profile_first_step(ctx, step, rank)
+    for _ in range(max(args.warmup, 1) - 1):
+        proof = step()
+    ctx.set_profile([dominant])
+    ctx.reset_stats()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dom = ctx.kernel_stats()[dominant]
+    ctx.set_profile([])
+    return proof, float(tmax.item()), dominant, dom
+
+
+def replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces, claims):
+    """one independent [ByteTable, U32Add] proof per rank per step (host-resident witnesses, as at N = 1); the only exchange
+    is an all_gather of each rank's three commitments, folded into a joint digest on rank 0"""
+    world = dist.get_world_size()
+    system = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    witness = system.host_witness(traces, packed)
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    digests = []
+    state = {"g": None}
+
+    def step():
+        # the commitments of proof k are gathered by a worker thread while proof k + 1 runs (CommitmentGatherer);
+        # sync waits for all of them, so the timed region contains every collective it started
+        proof = system.prove_multiple_claims(witness)
+        blob = mgpu.commitments_of(proof.to_bytes(), 2)
+        if state["g"] is None:
+            state["g"] = mgpu.CommitmentGatherer(len(blob), dev if args.backend == "nccl" else None,
+                                                 on_gathered=lambda allc: digests.append(mgpu.joint_digest(allc)))
+        state["g"].submit(blob)
+        return proof
+
+    def sync_extra():
+        if state["g"] is not None:
+            state["g"].finish()
+
+    proof, elapsed, dominant, dom = timed_steps(args, ctx, torch, dist, step, sync_extra, dev)
+    if state["g"] is not None:
+        state["g"].close()
+    rows = witness.rows
+    if rank == 0:
+        log("replicas: %.3f ms per step (%d proofs per step); last joint digest %s" % (
+            1e3 * elapsed / args.steps, world, digests[-1].hex() if digests else "-"))
+    return {
+        "what": "one independent [ByteTable, U32Add @ 2^%d] proof per GPU per step, host-resident witnesses, the three commitments of "
+                "every proof all-gathered (RCCL) and digested on rank 0" % args.log_adds,
+        "value": rows * world * args.steps / elapsed, "unit": "rows/s", "ms_per_step": 1e3 * elapsed / args.steps,
+        "rows_per_proof": rows, "proofs_per_step": world, "proof_bytes": len(proof.to_bytes()),
+    }, dominant, dom, rows
+
+
+def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims):
+    """ONE proof of [ByteTable, U32Add x N] by all ranks per step (ms_prove_sharded); setup (untimed, like criterion's setup
+    closure): the byte table's multiplicities are the sum over ranks (plain integer counts) and every rank holds all
+    claims, which the transcript absorbs in order"""
+    import importlib
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    world = dist.get_world_size()
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+    byte = torch.from_numpy(traces[0].astype(np.int64)).to(dev)
+    dist.all_reduce(byte, op=dist.ReduceOp.SUM)
+    mine_claims = torch.from_numpy(np.ascontiguousarray(claims).view(np.int64)).to(dev)
+    parts = [torch.empty_like(mine_claims) for _ in range(world)]
+    dist.all_gather(parts, mine_claims)
+    packed = fe.pack_claims(np.concatenate([p.cpu().numpy().view(np.uint64) for p in parts], axis=0))
+    del parts
+    owners = sharded.u32_add_owners(world)
+    tr = [byte.cpu().numpy().astype(np.uint64)] + [traces[1] if k == rank else None for k in range(world)]
+    remote = {1 + k: traces[1].shape[0] for k in range(world) if k != rank}
+    witness = system.witness(tr, packed, remote_heights=remote)
+    transport = args.transport if args.backend == "nccl" else "torch"
+    if transport == "rccl":
+        # bootstrap only: rank 0 draws the RCCL id, torch.distributed hands it round; the exchanges themselves are C
+        box = [sharded.RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = sharded.RcclComm(ctx, box[0], rank, world)
+    else:
+        comm = sharded.TorchComm(local_rank)
+    rows = 256 + world * traces[1].shape[0]
+
+    def step():
+        return system.prove_sharded(witness, comm, owners)
+
+    proof = step()  # fills the pool, opens the RCCL channels
+    comm.bytes_moved = 0
+    proof, elapsed, dominant, dom = timed_steps(args, ctx, torch, dist, step, lambda: None, dev)
+    moved = comm.bytes_moved // (args.steps + max(args.warmup, 1))
+    stage = system.prove_sharded(witness, comm, owners, want_times=True).stage_ms
+    sha = hashlib.sha256(proof.to_bytes()).hexdigest()
+    if rank == 0:
+        log("joint proof: %.3f ms per proof, %d rows, transport %s, sha256 %s" % (1e3 * elapsed / args.steps, rows, transport, sha[:16]))
+    info = {
+        "what": "ONE proof of [ByteTable, U32Add x %d] by %d ranks (ms_prove_sharded): row-range all-to-all per commitment, roots / "
+                "totals / opened values / reduced openings all-gathered" % (world, world),
+        "value": rows * args.steps / elapsed, "unit": "rows/s", "ms_per_step": 1e3 * elapsed / args.steps,
+        "rows_per_proof": rows, "proof_bytes": len(proof.to_bytes()), "proof_sha256": sha, "transport": transport,
+        "bytes_exchanged_per_rank_per_proof": moved, "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+    }
+    return info, dominant, dom, rows
+
+
+def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
+    import importlib
+
+    mgpu = importlib.import_module("multi_stark_amd.distributed")
+    a0, b0 = mgpu.rank_seeds(rank)  # per-rank seeds (SURVEY §8d config 3); rank 0 is exactly the reference's bench witness
+    t = time.time()
+    traces, claims = fe.u32_add_bench_witness(1 << args.log_adds, a0, b0)
+    log("[rank %d] witness generated in %.1fs" % (rank, time.time() - t))
+    done = {}
+
+    def partial():
+        # what rank 0 can still report when a later leg hangs
+        if "replicas" in done:
+            info = done["replicas"][0]
+            line = base_line(args, n_gpus, info["value"], info["ms_per_step"])
+            line["config"] = {"workload": WORKLOAD % (args.log_adds, "proof", HOST_RESIDENT), "parallelism": "1 proof per GPU (replicas)"}
+            line["replicas"] = info
+            return line
+        return base_line(args, n_gpus, None, None)
+
+    wd = Watchdog(rank, "the multi-GPU bench", args.primary_timeout, partial)
+    joint_primary = not args.replicas_primary
+    if not args.no_replicas_leg or not joint_primary:
+        done["replicas"] = replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces, claims)
+    if joint_primary or not args.no_joint_leg:
+        done["joint"] = joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
+    wd.finish()
+    prim = done["joint"] if joint_primary else done["replicas"]
+    info, dominant, dom, rows = prim
+    result = base_line(args, n_gpus, info["value"], info["ms_per_step"])
+    result["config"] = {
+        "workload": WORKLOAD % (args.log_adds, "rank" if joint_primary else "proof",
+                                "each rank's witness resident in HBM (ms_prove_sharded takes device-resident witnesses)" if joint_primary
+                                else HOST_RESIDENT),
+        "rows_per_proof": rows,
+        "proof_bytes": info["proof_bytes"],
+        "parallelism": ("one joint proof over %d GPUs (ms_prove_sharded, transport %s)" % (n_gpus, info.get("transport"))) if joint_primary
+                       else "1 proof per GPU (replicas)",
+        "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows * (1 if joint_primary else n_gpus) / (info["ms_per_step"] / 1e3) / 1e9,
+    }
+    if joint_primary:
+        result["config"]["stage_ms"] = info["stage_ms"]
+        result["config"]["bytes_exchanged_per_rank_per_proof"] = info["bytes_exchanged_per_rank_per_proof"]
+        result["config"]["proof_sha256"] = info["proof_sha256"]
+    result["roofline"] = roofline_of(dominant, dom)
+    if joint_primary and "replicas" in done:
+        result["replicas"] = done["replicas"][0]
+    if not joint_primary and "joint" in done:
+        result["joint_proof"] = done["joint"][0]
+    return result
 
 
 def main():
@@ -69,15 +410,15 @@ def main():
     force_dist = world == 1 and bool(os.environ.get("MSAMD_BENCH_FORCE_DIST")) and "RANK" in os.environ
 
     torch = None
-    dist = None
     try:
         import torch as _torch
 
         torch = _torch
-    except Exception as e:  # torch is plumbing only (barrier/synchronize); never needed for the proof itself
+    except Exception as e:  # torch is plumbing only (barrier / synchronize / bootstrap); never needed for the proof itself
         if n_gpus > 1 or force_dist:
             raise
         log("torch unavailable (%s): using the library's own stream synchronisation" % e)
+    dist = None
     if n_gpus > 1 or force_dist:
         import torch.distributed as _dist
 
@@ -94,287 +435,14 @@ def main():
     pkg = load_package()
     fe = pkg.frontend
     ctx = pkg.Context(local_rank)
-    params = fe.bench_params()
-    joint = args.joint and (n_gpus > 1 or force_dist)
-    num_adds = 1 << args.log_adds
-    # per-rank seeds; rank 0 is exactly the reference's bench witness
-    a0, b0 = (0xDEADBEEF, 0xCAFEBABE)
-    mgpu = None
-    if n_gpus > 1 or force_dist:
-        import importlib
-
-        mgpu = importlib.import_module("multi_stark_amd.distributed")
-        a0, b0 = mgpu.rank_seeds(rank)
-    t = time.time()
-    traces, claims = fe.u32_add_bench_witness(num_adds, a0, b0)
-    comm = owners = None
-    if joint:
-        # one system for everyone; rank k computes adder k. Setup (untimed, like the reference's criterion setup
-        # closure): the byte table's multiplicities are the sum over ranks (plain integer counts, far below 2^63) and
-        # every rank holds all claims, which the transcript absorbs in order
-        sharded = importlib.import_module("multi_stark_amd.sharded")
-        world_n = dist.get_world_size()
-        inputs = fe.multi_u32_add_system_inputs(world_n)
-        system = pkg.System.new(ctx, params, inputs)
-        dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
-        byte = torch.from_numpy(traces[0].astype(np.int64)).to(dev)
-        dist.all_reduce(byte, op=dist.ReduceOp.SUM)
-        mine_claims = torch.from_numpy(np.ascontiguousarray(claims).view(np.int64)).to(dev)
-        parts = [torch.empty_like(mine_claims) for _ in range(world_n)]
-        dist.all_gather(parts, mine_claims)
-        all_claims = np.concatenate([p.cpu().numpy().view(np.uint64) for p in parts], axis=0)
-        packed = fe.pack_claims(all_claims)
-        owners = sharded.u32_add_owners(world_n)
-        tr = [byte.cpu().numpy().astype(np.uint64)] + [traces[1] if k == rank else None for k in range(world_n)]
-        remote = {1 + k: traces[1].shape[0] for k in range(world_n) if k != rank}
-        witness = system.witness(tr, packed, remote_heights=remote)
-        comm = sharded.TorchComm(local_rank)
-        rows_per_proof = 256 + world_n * traces[1].shape[0]
+    if dist is None:
+        result = single_gpu(args, pkg, fe, ctx, torch)
     else:
-        inputs = fe.u32_add_system_inputs()
-        system = pkg.System.new(ctx, params, inputs)
-        packed = fe.pack_claims(claims)
-        # setup, untimed (criterion's setup closure builds the witness): validate + page-lock the host buffers. Every
-        # timed step uploads them and runs SystemWitness::from_stage_1 on the device.
-        witness = system.witness(traces, packed) if args.hbm_resident else system.host_witness(traces, packed)
-        if not args.hbm_resident and not witness.pinned:
-            log("warning: host buffers could not be page-locked; uploads are staged by the runtime")
-        rows_per_proof = witness.rows
-    log("[rank %d] witness ready in %.1fs: %d rows/proof%s" % (rank, time.time() - t, rows_per_proof, " (joint proof)" if joint else ""))
-
-    gatherer = None
-    digests = []
-
-    def sync_all():
-        ctx.sync()
-        if gatherer is not None:
-            gatherer.finish()  # every submitted commitment set has been gathered and digested
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def step():
-        # the commitments of proof k are gathered by a worker thread while proof k + 1 runs (CommitmentGatherer);
-        # sync_all() waits for all of them, so the timed region contains every collective it started
-        nonlocal gatherer
-        if joint:
-            return system.prove_sharded(witness, comm, owners)
-        proof = system.prove_multiple_claims(witness)
-        if dist is not None:
-            blob = mgpu.commitments_of(proof.to_bytes(), 2)
-            if gatherer is None:
-                gatherer = mgpu.CommitmentGatherer(len(blob), torch.device("cuda", local_rank) if args.backend == "nccl" else None,
-                                                   on_gathered=lambda allc: digests.append(mgpu.joint_digest(allc)))
-            gatherer.submit(blob)
-        return proof
-
-    # ---- warmup (untimed); the first warmup step is profiled per kernel class to pick the dominant kernel
-    names = ctx.kernel_names()
-    proof = None
-    dominant = "ntt8s_dif"
-    table = {}
-    for i in range(max(args.warmup, 1)):
-        if i == 0:
-            ctx.set_profile(names)
-            ctx.reset_stats()
-        proof = step()
-        if i == 0:
-            table = ctx.kernel_stats()
-            ctx.set_profile([])
-            ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
-            if ranked and ranked[0][1]["ms"] > 0:
-                dominant = ranked[0][0]
-            if rank == 0:
-                log("per-kernel-class device time of one proof (HIP events, profiled warmup step):")
-                for n, s in ranked:
-                    if s["launches"]:
-                        log("  %-16s launches %4d  total %8.3f ms  alg %.1f GB/s" % (
-                            n, s["launches"], s["ms"], s["alg_bytes"] / max(s["ms"], 1e-9) / 1e6))
-    proof_len = len(proof.to_bytes())
-    log("[rank %d] warm-up done (%d steps); timing %d steps" % (rank, max(args.warmup, 1), args.steps))
-
-    # ---- timed region: exactly K steps, HIP events only around the dominant kernel class
-    primary_done = None
-    if dist is not None:
-        import threading
-
-        primary_done = threading.Event()
-
-        def primary_watchdog():
-            # one rank failing (or its gather worker dying) would leave the others blocked in a collective forever
-            if not primary_done.wait(args.primary_timeout):
-                log("[rank %d] primary leg did not finish within %.0f s: exiting with status 4" % (rank, args.primary_timeout))
-                os._exit(4)
-
-        threading.Thread(target=primary_watchdog, daemon=True).start()
-    ctx.set_profile([dominant])
-    ctx.reset_stats()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    if primary_done is not None:
-        primary_done.set()
-    log("[rank %d] timed region done: %.3f ms per step" % (rank, 1e3 * elapsed / args.steps))
-    dom = ctx.kernel_stats()[dominant]
-    ctx.set_profile([])
-    stage = (system.prove_sharded(witness, comm, owners, want_times=True) if joint else
-             system.prove_multiple_claims(witness, want_times=True)).stage_ms
-    # the same proof from a witness that already sits in HBM (round-1 definition of the step): context, never `value`
-    hbm_ms = None
-    if not joint and not args.hbm_resident:
-        dw = system.witness(traces, packed)
-        assert system.prove_multiple_claims(dw).to_bytes() == proof.to_bytes()
-        k = max(3, min(args.steps, 10))
-        ctx.sync()
-        t1 = time.perf_counter()
-        for _ in range(k):
-            system.prove_multiple_claims(dw)
-        ctx.sync()
-        hbm_ms = 1e3 * (time.perf_counter() - t1) / k
-        del dw
-        log("[rank %d] HBM-resident witness: %.3f ms per proof" % (rank, hbm_ms))
-
-    result = None
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = rows_per_proof * (1 if joint else n_gpus) * args.steps / elapsed
-        avg_ms = dom["ms"] / max(dom["launches"], 1)
-        bytes_per_launch = dom["alg_bytes"] / max(dom["launches"], 1)
-        achieved = bytes_per_launch / max(avg_ms, 1e-12) / 1e6  # GB/s
-        result = {
-            "metric": "prove_trace_rows_per_sec",
-            "value": value,
-            "unit": "rows/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "config": {
-                "workload": "U32-add + byte-table lookup (benches/multi_stark.rs), 2^%d additions per proof, "
-                            "bench_config(): log_blowup 2, 100 queries, 10+10 PoW bits, GoldilocksBlake3Config; "
-                            "%s, proof bytes returned to host" % (args.log_adds, "witness resident in HBM" if (joint or args.hbm_resident) else
-                                "witness (traces + claims) in pinned host memory at step start: upload, from_stage_1 on the device "
-                                "and read-back inside the timed region"),
-                "rows_per_proof": rows_per_proof,
-                "proof_bytes": proof_len,
-                "parallelism": ("one joint proof over %d GPUs (ms_prove_sharded)" % n_gpus) if joint else
-                               "1 proof per GPU" if n_gpus > 1 else "single GPU",
-                "stage_ms": {k: round(v, 3) for k, v in stage.items()},
-                "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows_per_proof / (elapsed / args.steps) / 1e9,
-                "hbm_resident_ms": hbm_ms,
-                "host_bytes_uploaded_per_proof": None if (joint or args.hbm_resident) else int(sum(t.nbytes for t in traces) + packed[0].nbytes + packed[1].nbytes),
-            },
-            "roofline": {
-                "kernel": dominant,
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(dominant),
-                "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % TRAFFIC_FILE,
-                "avg_launch_ms": avg_ms,
-                "alg_bytes_per_launch": bytes_per_launch,
-                "launches": dom["launches"],
-            },
-        }
-        if not args.no_cpu_baseline and n_gpus == 1:
-            result["cpu_baseline"] = cpu_baseline(fe, system.blob, args.cpu_log_adds)
-    if gatherer is not None:
-        gatherer.close()
-        if rank == 0:
-            log("gathered and digested %d commitment sets; last joint digest %s" % (len(digests), digests[-1].hex() if digests else "-"))
-    # ---- secondary leg, N > 1: BASELINE config 3 taken literally - ONE proof of [ByteTable, U32Add x N] computed by all
-    # ranks together (ms_prove_sharded). Reported next to the primary figure, never instead of it; a watchdog prints
-    # the primary result and ends the job if this leg cannot finish (a rank failing inside a collective would
-    # otherwise hang the others).
-    if dist is not None and not joint and not args.no_joint_leg:
-        import threading
-
-        finished = threading.Event()
-
-        def watchdog():
-            # a hang here is a failure of the job, reported as one: the primary line is printed with the error
-            # recorded, then every rank exits NON-ZERO so that the launcher and the driver see it
-            if not finished.wait(args.joint_timeout):
-                if rank == 0:
-                    result["joint_proof"] = {"error": "timed out after %.0f s (collective hang or a failed rank)" % args.joint_timeout}
-                    print(json.dumps(result), flush=True)
-                log("[rank %d] joint-proof leg timed out: exiting with status 3" % rank)
-                os._exit(3)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        info = joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
-        finished.set()
-        if rank == 0:
-            result["joint_proof"] = info
-    if dist is not None:
+        result = multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
-
-
-def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims):
-    """One proof of [ByteTable, U32Add x N] by all ranks (ms_prove_sharded): setup untimed, 1 warm-up, K timed proofs."""
-    import importlib
-
-    try:
-        sharded = importlib.import_module("multi_stark_amd.sharded")
-        world = dist.get_world_size()
-        system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
-        dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
-        byte = torch.from_numpy(traces[0].astype(np.int64)).to(dev)
-        dist.all_reduce(byte, op=dist.ReduceOp.SUM)  # multiplicities of the shared byte table: plain integer counts
-        mine_claims = torch.from_numpy(np.ascontiguousarray(claims).view(np.int64)).to(dev)
-        parts = [torch.empty_like(mine_claims) for _ in range(world)]
-        dist.all_gather(parts, mine_claims)
-        packed = fe.pack_claims(np.concatenate([p.cpu().numpy().view(np.uint64) for p in parts], axis=0))
-        del parts
-        owners = sharded.u32_add_owners(world)
-        tr = [byte.cpu().numpy().astype(np.uint64)] + [traces[1] if k == rank else None for k in range(world)]
-        remote = {1 + k: traces[1].shape[0] for k in range(world) if k != rank}
-        witness = system.witness(tr, packed, remote_heights=remote)
-        comm = sharded.TorchComm(local_rank)
-        rows = 256 + world * traces[1].shape[0]
-        proof = system.prove_sharded(witness, comm, owners)  # warm-up (fills the pool)
-        steps = max(1, min(args.steps, 5))
-        comm.bytes_moved = 0
-        ctx.sync()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            proof = system.prove_sharded(witness, comm, owners)
-        ctx.sync()
-        dist.barrier()
-        elapsed = time.perf_counter() - t0
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        stage = system.prove_sharded(witness, comm, owners, want_times=True).stage_ms
-        sha = __import__("hashlib").sha256(proof.to_bytes()).hexdigest()
-        return {"what": "ONE proof of [ByteTable, U32Add x %d] by %d ranks (ms_prove_sharded): row-range all-to-all per "
-                        "commitment, roots / totals / openings all-gathered" % (world, world),
-                "value": rows * steps / elapsed, "unit": "rows/s", "ms_per_proof": 1e3 * elapsed / steps, "steps": steps,
-                "rows_per_proof": rows, "proof_bytes": len(proof.to_bytes()), "proof_sha256": sha,
-                "bytes_exchanged_per_rank_per_proof": comm.bytes_moved // steps,
-                "stage_ms": {k: round(v, 3) for k, v in stage.items()}}
-    except BaseException as e:  # the primary result must survive
-        return {"error": repr(e)}
 
 
 def measured_traffic(kernel):

@@ -14,6 +14,7 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct ms_witness { _p: [u8; 0] }
 #[repr(C)] pub struct ms_mmcs { _p: [u8; 0] }
 #[repr(C)] pub struct ms_challenger { _p: [u8; 0] }
+#[repr(C)] pub struct ms_comm_rccl { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_system { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_witness { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_mmcs { _p: [u8; 0] }
@@ -73,6 +74,11 @@ extern "C" {
                      proof_len: usize, verdict: *mut i32) -> i32;
     pub fn ms_prove_sharded(sys: *mut ms_system, w: *mut ms_witness, comm: *const ms_comm, owners: *const i32, proof_out: *mut u8,
                             cap: usize, proof_len: *mut usize, stage_ms: *mut f64) -> i32;
+    pub fn ms_comm_rccl_unique_id(out: *mut u8) -> i32;
+    pub fn ms_comm_rccl_create(ctx: *mut ms_ctx, unique_id: *const u8, rank: i32, world: i32, out: *mut *mut ms_comm_rccl) -> i32;
+    pub fn ms_comm_rccl_table(c: *mut ms_comm_rccl) -> *const ms_comm;
+    pub fn ms_comm_rccl_bytes_moved(c: *mut ms_comm_rccl) -> u64;
+    pub fn ms_comm_rccl_destroy(c: *mut ms_comm_rccl);
     pub fn ms_dft_batch(ctx: *mut ms_ctx, input: *const u64, h: usize, w: usize, inverse: i32, out: *mut u64) -> i32;
     pub fn ms_coset_lde_batch(ctx: *mut ms_ctx, input: *const u64, h: usize, w: usize, log_blowup: u32, out: *mut u64) -> i32;
     pub fn ms_quotient_lde(ctx: *mut ms_ctx, input: *const u64, log_n: u32, log_q: u32, log_blowup: u32, d: usize, out: *mut u64) -> i32;

@@ -19,6 +19,7 @@
  *   ms_prove       System::prove_multiple_claims                src/prover.rs:290-603
  *   ms_verify      System::verify_multiple_claims               src/verifier.rs:208-532
  *   ms_prove_sharded   the same proof computed by several GPUs  src/prover.rs:290-603 (commit/open calls :350,419,526,580)
+ *   ms_comm_rccl_*     its transport on RCCL (the reference has no collectives: Cargo.toml has no MPI / NCCL crate)
  *   ms_dft_batch   Radix2DitParallel::dft_batch                 src/prover.rs:650,716 (type fixed at :440)
  *   ms_coset_lde_batch  the LDE inside Pcs::commit              src/prover.rs:350,419; layout pinned by :975-999
  *   ms_quotient_lde     shifted_quotient_slices + lde_from_shifted_coefficients   src/prover.rs:631-717
@@ -154,6 +155,20 @@ typedef struct ms_comm {
 } ms_comm;
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms);
+
+/* ---- Native transport for ms_prove_sharded: RCCL over xGMI (csrc/comm_rccl.hip; librccl is loaded at run time). The host
+ * needs no Python: rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever channel the
+ * host already has (a file, MPI, a TCP store); every rank then creates its transport on its own context (collective:
+ * ncclCommInitRank) and passes ms_comm_rccl_table() to ms_prove_sharded. all_to_all = one grouped ncclSend / ncclRecv
+ * pair per peer, all_gather = ncclAllGather, both on the transport's own stream; world = 1 needs no id and no librccl. */
+#define MS_RCCL_UNIQUE_ID_BYTES 128
+typedef struct ms_comm_rccl ms_comm_rccl;
+int32_t ms_comm_rccl_unique_id(uint8_t out[MS_RCCL_UNIQUE_ID_BYTES]);
+int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_ID_BYTES], int32_t rank, int32_t world,
+                            ms_comm_rccl** out);
+const ms_comm* ms_comm_rccl_table(ms_comm_rccl* c);
+uint64_t ms_comm_rccl_bytes_moved(ms_comm_rccl* c); /* bytes this rank has put through the two exchanges so far */
+void ms_comm_rccl_destroy(ms_comm_rccl* c);
 
 /* ---- PCS-level entry points (host buffers in, host buffers out) */
 /* out[k] = sum_j in[j] w_h^{jk} per column (inverse != 0: the inverse transform incl. 1/h); natural order both sides */

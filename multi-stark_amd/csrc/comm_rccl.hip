@@ -1,0 +1,214 @@
+// Native transport for ms_prove_sharded: the two exchanges of the ms_comm table (include/mstark.h) on RCCL over xGMI,
+// with no Python and no torch in the data path, so that the reference-side (Rust) host of INTEGRATION.md can run the
+// joint proof of BASELINE config 3 by itself. librccl is loaded at run time (dlopen), like hiprtc: the prover library
+// has no link-time dependency on it and single-GPU users never load it.
+//   all_to_all  = grouped ncclSend / ncclRecv, one pair per peer (xGMI is point-to-point: one link per pair)
+//   all_gather  = ncclAllGather
+// Both run on the transport's own stream; the blocking forms return when the data has arrived (the ms_comm contract),
+// the start / wait pair lets the prover overlap the exchange of one column group with the transforms of the next.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <string>
+
+#include "../../include/mstark.h"
+#include "msamd.h"
+
+namespace msamd {
+void set_last_error(const char* what);
+Ctx* ctx_of(ms_ctx* c);
+void ctx_retain(ms_ctx* c);
+void ctx_release(ms_ctx* c);
+}  // namespace msamd
+using namespace msamd;
+
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_api;
+
+// one copy of RCCL per process: if the host has already loaded one (torch ships its own), use that one
+const RcclApi& rccl() {
+  if (g_api.lib) return g_api;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (const char* env = getenv("MSAMD_RCCL_LIB"))
+    if (!h) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  for (const char* n : names)
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) throw std::runtime_error(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"));
+  RcclApi a;
+  a.lib = h;
+#define MS_SYM(field, name)                                                       \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                  \
+  if (!a.field) throw std::runtime_error(std::string("librccl lacks ") + name)
+  MS_SYM(GetUniqueId, "ncclGetUniqueId");
+  MS_SYM(CommInitRank, "ncclCommInitRank");
+  MS_SYM(CommDestroy, "ncclCommDestroy");
+  MS_SYM(GroupStart, "ncclGroupStart");
+  MS_SYM(GroupEnd, "ncclGroupEnd");
+  MS_SYM(Send, "ncclSend");
+  MS_SYM(Recv, "ncclRecv");
+  MS_SYM(AllGather, "ncclAllGather");
+  MS_SYM(GetErrorString, "ncclGetErrorString");
+#undef MS_SYM
+  g_api = a;
+  return g_api;
+}
+
+void nccl_check(ncclResult_t r, const char* what) {
+  if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL ") + what + ": " + rccl().GetErrorString(r));
+}
+}  // namespace
+
+struct ms_comm_rccl {
+  ms_ctx* owner = nullptr;
+  Ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  int rank = 0, world = 1;
+  uint64_t bytes_moved = 0;
+  ms_comm table;
+
+  void exchange(const uint8_t* send, size_t send_stride, uint8_t* recv, size_t recv_stride, size_t n) {
+    bytes_moved += n * (size_t)world;
+    if (n == 0) return;
+    if (world > 1) {
+      nccl_check(rccl().GroupStart(), "ncclGroupStart");
+      for (int k = 0; k < world; k++) {
+        if (k == rank) continue;
+        nccl_check(rccl().Send(send + (size_t)k * send_stride, n, ncclUint8, k, comm, stream), "ncclSend");
+        nccl_check(rccl().Recv(recv + (size_t)k * recv_stride, n, ncclUint8, k, comm, stream), "ncclRecv");
+      }
+      nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    }
+    // this rank's own block never leaves the device
+    HIP_CHECK(hipMemcpyAsync(recv + (size_t)rank * recv_stride, send + (size_t)rank * send_stride, n, hipMemcpyDeviceToDevice, stream));
+  }
+  void gather(const void* send, void* recv, size_t n) {
+    bytes_moved += n * (size_t)world;
+    if (n == 0) return;
+    if (world > 1)
+      nccl_check(rccl().AllGather(send, recv, n, ncclUint8, comm, stream), "ncclAllGather");
+    else
+      HIP_CHECK(hipMemcpyAsync(recv, send, n, hipMemcpyDeviceToDevice, stream));
+  }
+};
+
+namespace {
+template <class F>
+int32_t guarded(ms_comm_rccl* c, F f) {
+  try {
+    HIP_CHECK(hipSetDevice(c->ctx->device));
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+int32_t cb_all_to_all(void* user, const void* send, void* recv, size_t per_peer) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] {
+    c->exchange((const uint8_t*)send, per_peer, (uint8_t*)recv, per_peer, per_peer);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+  });
+}
+int32_t cb_all_gather(void* user, const void* send, void* recv, size_t bytes) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] {
+    c->gather(send, recv, bytes);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+  });
+}
+int32_t cb_start(void* user, const void* send, size_t send_stride, void* recv, size_t recv_stride, size_t per_peer) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] { c->exchange((const uint8_t*)send, send_stride, (uint8_t*)recv, recv_stride, per_peer); });
+}
+int32_t cb_wait(void* user) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] { HIP_CHECK(hipStreamSynchronize(c->stream)); });
+}
+}  // namespace
+
+extern "C" {
+
+int32_t ms_comm_rccl_unique_id(uint8_t out[MS_RCCL_UNIQUE_ID_BYTES]) {
+  try {
+    static_assert(sizeof(ncclUniqueId) == MS_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out, &id, sizeof(id));
+    return MS_OK;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return MS_ERR;
+  }
+}
+
+int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_ID_BYTES], int32_t rank, int32_t world,
+                            ms_comm_rccl** out) {
+  *out = nullptr;
+  ms_comm_rccl* c = nullptr;
+  try {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ms_comm_rccl_create: rank out of range");
+    c = new ms_comm_rccl();
+    c->ctx = ctx_of(ctx);
+    c->rank = rank;
+    c->world = world;
+    HIP_CHECK(hipSetDevice(c->ctx->device));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (world > 1) {
+      ncclUniqueId id;
+      memcpy(&id, unique_id, sizeof(id));
+      nccl_check(rccl().CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+    }
+    memset(&c->table, 0, sizeof(c->table));
+    c->table.rank = rank;
+    c->table.world = world;
+    c->table.user = c;
+    c->table.all_to_all = cb_all_to_all;
+    c->table.all_gather = cb_all_gather;
+    c->table.all_to_all_start = cb_start;
+    c->table.all_to_all_wait = cb_wait;
+    c->owner = ctx;
+    ctx_retain(ctx);
+    *out = c;
+    return MS_OK;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    if (c) {
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+      delete c;
+    }
+    return MS_ERR;
+  }
+}
+
+const ms_comm* ms_comm_rccl_table(ms_comm_rccl* c) { return c ? &c->table : nullptr; }
+uint64_t ms_comm_rccl_bytes_moved(ms_comm_rccl* c) { return c ? c->bytes_moved : 0; }
+
+void ms_comm_rccl_destroy(ms_comm_rccl* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  (void)hipStreamDestroy(c->stream);
+  ms_ctx* o = c->owner;
+  delete c;
+  ctx_release(o);
+}
+
+}  // extern "C"

@@ -1,4 +1,5 @@
-"""Transport for `System.prove_sharded` (ms_prove_sharded): the two exchanges the library asks for, on torch.distributed.
+"""Transports for `System.prove_sharded` (ms_prove_sharded): the two exchanges the library asks for, on torch.distributed
+(`TorchComm`) or on the library's own RCCL transport (`RcclComm`, csrc/comm_rccl.hip - no torch involved).
 
 `TorchComm` builds the `ms_comm` callback table of include/mstark.h. With backend "nccl" (= RCCL on ROCm) the device
 buffers the library hands over are wrapped as torch tensors in place (`__cuda_array_interface__`) and exchanged by
@@ -6,9 +7,6 @@ buffers the library hands over are wrapped as torch tensors in place (`__cuda_ar
 rehearsals, where several ranks share one device) the buffers are staged through host memory. Torch is plumbing here:
 every byte that is exchanged was produced, and is consumed, by the library's own kernels."""
 import ctypes as C
-
-import torch
-import torch.distributed as dist
 
 _CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 _START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t)
@@ -29,6 +27,10 @@ class _DevBytes:
 
 class TorchComm:
     def __init__(self, device_index=0, group=None):
+        global torch, dist
+        import torch  # plumbing of this transport only: RcclComm below needs neither
+        import torch.distributed as dist
+
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -119,6 +121,56 @@ class TorchComm:
                 torch.cuda.synchronize(self.device)
 
         return self._guard(run)
+
+
+class RcclComm:
+    """The library's own transport (ms_comm_rccl_*, csrc/comm_rccl.hip): grouped ncclSend / ncclRecv and ncclAllGather called
+    from C, nothing of the exchange passes through Python. `unique_id`: the 128 bytes of `RcclComm.unique_id()` drawn on
+    rank 0 and handed to every rank by the host's own channel (bench.py broadcasts them with torch.distributed)."""
+
+    def __init__(self, ctx, unique_id: bytes, rank: int, world: int):
+        from . import lib, _check
+
+        self._lib = lib()
+        self.ctx = ctx
+        self.rank, self.world = rank, world
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id if unique_id else bytes(128))
+        _check(self._lib.ms_comm_rccl_create(ctx.h, buf, C.c_int32(rank), C.c_int32(world), C.byref(self.h)))
+        self._lib.ms_comm_rccl_table.restype = C.c_void_p
+        self._lib.ms_comm_rccl_bytes_moved.restype = C.c_uint64
+        self.struct = MsComm.from_address(self._lib.ms_comm_rccl_table(self.h))
+        self._base = 0
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import lib, _check
+
+        buf = (C.c_uint8 * 128)()
+        _check(lib().ms_comm_rccl_unique_id(buf))
+        return bytes(buf)
+
+    @property
+    def bytes_moved(self):
+        return int(self._lib.ms_comm_rccl_bytes_moved(self.h)) - self._base
+
+    @bytes_moved.setter
+    def bytes_moved(self, v):
+        self._base = int(self._lib.ms_comm_rccl_bytes_moved(self.h)) - int(v)
+
+    def reraise(self):
+        pass  # errors of this transport come back as the library's error codes
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.ms_comm_rccl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def u32_add_owners(k):
