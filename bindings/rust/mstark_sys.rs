@@ -15,6 +15,7 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct ms_mmcs { _p: [u8; 0] }
 #[repr(C)] pub struct ms_challenger { _p: [u8; 0] }
 #[repr(C)] pub struct ms_comm_rccl { _p: [u8; 0] }
+#[repr(C)] pub struct ms_trace { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_system { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_witness { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_mmcs { _p: [u8; 0] }
@@ -101,6 +102,20 @@ extern "C" {
     pub fn ms_pcs_verify(params7: *const u64, n_rounds: usize, caps: *const *const u8, cap_sizes: *const u64, n_mats: *const u64,
                          log_n: *const u64, widths: *const u64, n_points: *const u64, points: *const u64, opened: *const u64,
                          fri: *const u8, fri_len: usize, ch: *mut ms_challenger, accepted: *mut i32) -> i32;
+    pub fn ms_trace_destroy(t: *mut ms_trace);
+    pub fn ms_trace_info(t: *const ms_trace, out3: *mut u64) -> i32;
+    pub fn ms_system_preprocessed_mmcs(sys: *mut ms_system, out: *mut *mut ms_mmcs) -> i32;
+    pub fn ms_witness_commit_stage1(w: *mut ms_witness, cap_out: *mut u8, out: *mut *mut ms_mmcs) -> i32;
+    pub fn ms_challenger_observe_claims(ch: *mut ms_challenger, w: *mut ms_witness) -> i32;
+    pub fn ms_witness_claims_accumulator(w: *mut ms_witness, beta: *const u64, gamma: *const u64, acc_out: *mut u64) -> i32;
+    pub fn ms_stage2_build(w: *mut ms_witness, beta: *const u64, gamma: *const u64, acc_in: *const u64, accs_out: *mut u64,
+                           traces_out: *mut *mut ms_trace) -> i32;
+    pub fn ms_pcs_commit_traces(ctx: *mut ms_ctx, log_blowup: u32, cap_height: u32, n: usize, evals: *const *mut ms_trace,
+                                cap_out: *mut u8, out: *mut *mut ms_mmcs) -> i32;
+    pub fn ms_quotient(sys: *mut ms_system, circuit: usize, log_n: u32, s1: *mut ms_mmcs, s1_idx: usize, s2: *mut ms_mmcs,
+                       s2_idx: usize, publics8: *const u64, alpha: *const u64, q_lde_out: *mut *mut ms_trace) -> i32;
+    pub fn ms_pcs_commit_ldes(ctx: *mut ms_ctx, cap_height: u32, n: usize, ldes: *const *mut ms_trace, cap_out: *mut u8,
+                              out: *mut *mut ms_mmcs) -> i32;
     pub fn ms_stage2_trace(ctx: *mut ms_ctx, height: usize, num_lookups: usize, mult: *const u64, arg_offsets: *const u64,
                            args: *const u64, beta: *const u64, gamma: *const u64, acc_in: *const u64, trace_out: *mut u64,
                            acc_out: *mut u64) -> i32;

@@ -214,7 +214,44 @@ int32_t ms_pcs_verify(const uint64_t params7[7], size_t n_rounds, const uint8_t*
                       const uint64_t* points, const uint64_t* opened, const uint8_t* fri, size_t fri_len, ms_challenger* ch,
                       int32_t* accepted);
 
-/* ---- in-tree kernels of the reference */
+/* ---- Level 2: the prover's steps on DEVICE HANDLES, for a host that keeps the reference's own prover loop
+ * (src/prover.rs:290-603: "Rust host keeps the multi-circuit / lookup bookkeeping and calls kernels through FFI") and
+ * calls the device once per step. Between the calls only commitments, accumulators and challenges cross the boundary;
+ * traces, LDEs and trees stay in HBM behind ms_witness / ms_trace / ms_mmcs. Together with ms_challenger_* and ms_pcs_open
+ * these are all the device calls of prove_multiple_claims (tests/test_gpu_level2.py drives exactly that loop from Python
+ * and obtains the bytes ms_prove writes):
+ *   ms_witness_commit_stage1      pcs.commit(stage-1 traces)                             src/prover.rs:338-350
+ *   ms_challenger_observe_claims  the claims absorbed by the transcript                  src/prover.rs:369-373
+ *   ms_witness_claims_accumulator the initial accumulator                                src/prover.rs:382-387
+ *   ms_stage2_build               LookupValues::stage_2_traces -> evaluation handles     src/prover.rs:400, src/lookup.rs:472-555
+ *   ms_pcs_commit_traces          pcs.commit(stage-2 traces) on those handles            src/prover.rs:414-419
+ *   ms_quotient                   quotient_values + shifted_quotient_slices +            src/prover.rs:459-468,483,511-517
+ *                                 lde_from_shifted_coefficients -> LDE handle
+ *   ms_pcs_commit_ldes            pcs.commit_ldes                                        src/prover.rs:526
+ *   ms_system_preprocessed_mmcs   the ProverKey's preprocessed prover data (a view)      src/system.rs:190-195
+ * Matrices of a commitment are indexed by ACTIVE position (circuits with an empty trace are skipped), as the reference's
+ * per-stage matrix lists are (src/prover.rs:216-225). A handle consumed by a commit call keeps existing but is empty;
+ * destroy it like any other. Host-resident witnesses (ms_witness_create_host) are not accepted here. */
+typedef struct ms_trace ms_trace;
+void ms_trace_destroy(ms_trace* t);
+int32_t ms_trace_info(const ms_trace* t, uint64_t out3[3]); /* height, width, kind (0 evaluations, 1 LDE) */
+int32_t ms_system_preprocessed_mmcs(ms_system* sys, ms_mmcs** out); /* *out = NULL when the system has no preprocessed trace */
+int32_t ms_witness_commit_stage1(ms_witness* w, uint8_t* cap_out, ms_mmcs** out);
+int32_t ms_challenger_observe_claims(ms_challenger* ch, ms_witness* w);
+int32_t ms_witness_claims_accumulator(ms_witness* w, const uint64_t beta[2], const uint64_t gamma[2], uint64_t acc_out[2]);
+/* accs_out: 2 words per active circuit (the accumulator after each circuit, src/lookup.rs:544-550); traces_out: one handle
+ * per active circuit */
+int32_t ms_stage2_build(ms_witness* w, const uint64_t beta[2], const uint64_t gamma[2], const uint64_t acc_in[2], uint64_t* accs_out,
+                        ms_trace** traces_out);
+int32_t ms_pcs_commit_traces(ms_ctx* ctx, uint32_t log_blowup, uint32_t cap_height, size_t n, ms_trace* const* evals, uint8_t* cap_out,
+                             ms_mmcs** out);
+/* publics8 = [beta, gamma, acc_in, acc_out] as (c0, c1) pairs (src/lookup.rs:78-84); s1 / s2: the stage commitments and
+ * the circuit's matrix index inside each */
+int32_t ms_quotient(ms_system* sys, size_t circuit, uint32_t log_n, ms_mmcs* s1, size_t s1_idx, ms_mmcs* s2, size_t s2_idx,
+                    const uint64_t publics8[8], const uint64_t alpha[2], ms_trace** q_lde_out);
+int32_t ms_pcs_commit_ldes(ms_ctx* ctx, uint32_t cap_height, size_t n, ms_trace* const* ldes, uint8_t* cap_out, ms_mmcs** out);
+
+/* ---- in-tree kernels of the reference, host buffers in and out (kernel-level parity tests) */
 int32_t ms_stage2_trace(ms_ctx* ctx, size_t height, size_t num_lookups, const uint64_t* mult,
                         const uint64_t* arg_offsets, const uint64_t* args, const uint64_t beta[2],
                         const uint64_t gamma[2], const uint64_t acc_in[2], uint64_t* trace_out, uint64_t acc_out[2]);

@@ -49,7 +49,9 @@ def exported_symbols():
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_pcs_commit", "ms_pcs_open", "ms_pcs_verify", "ms_challenger_create",
             "ms_challenger_destroy", "ms_challenger_observe", "ms_challenger_observe_digests", "ms_challenger_sample_ext",
             "ms_challenger_sample_bits", "ms_stage2_trace", "ms_claims_accumulator",
-            "ms_quotient_values", "ms_field_op"]
+            "ms_quotient_values", "ms_field_op", "ms_trace_destroy", "ms_trace_info", "ms_system_preprocessed_mmcs",
+            "ms_witness_commit_stage1", "ms_challenger_observe_claims", "ms_witness_claims_accumulator", "ms_stage2_build",
+            "ms_pcs_commit_traces", "ms_quotient", "ms_pcs_commit_ldes"]
 
 
 def _check(rc):
@@ -203,6 +205,60 @@ class Mmcs:
             self.h = None
 
 
+class DeviceCommitment(Mmcs):
+    """ProverData produced by a Level-2 call (ms_witness_commit_stage1, ms_pcs_commit_traces, ms_pcs_commit_ldes,
+    ms_system_preprocessed_mmcs): the matrices never left the device."""
+
+    def __init__(self, ctx, handle, cap: bytes, widths, log_max):
+        self.ctx, self.h, self.cap = ctx, handle, cap
+        self.widths = _u64(widths)
+        self.log_max = log_max
+        self.mats = []
+
+
+class Trace:
+    """A device-resident matrix handed between Level-2 calls (ms_trace): stage-2 evaluations or a quotient LDE."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def info(self):
+        o = np.zeros(3, dtype=np.uint64)
+        _check(lib().ms_trace_info(self.h, _p(o)))
+        return int(o[0]), int(o[1]), int(o[2])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ms_trace_destroy(self.h)
+            self.h = None
+
+
+def _cap_buffer(cap_height, max_height):
+    return np.zeros(32 * min(1 << cap_height, max_height), dtype=np.uint8)
+
+
+def pcs_commit_traces(ctx, traces, log_blowup, cap_height=0):
+    """Pcs::commit (src/prover.rs:414-419) on evaluation handles; the handles are consumed"""
+    infos = [t.info() for t in traces]
+    maxh = max(h for h, _, _ in infos) << log_blowup
+    cap = _cap_buffer(cap_height, maxh)
+    hs = (C.c_void_p * len(traces))(*[t.h for t in traces])
+    out = C.c_void_p()
+    _check(lib().ms_pcs_commit_traces(ctx.h, C.c_uint32(log_blowup), C.c_uint32(cap_height), C.c_size_t(len(traces)), hs, _b(cap), C.byref(out)))
+    return DeviceCommitment(ctx, out, cap.tobytes(), [w for _, w, _ in infos], maxh.bit_length() - 1)
+
+
+def pcs_commit_ldes(ctx, ldes, cap_height=0):
+    """Pcs::commit_ldes (src/prover.rs:526) on LDE handles; the commitment takes the matrices over"""
+    infos = [t.info() for t in ldes]
+    maxh = max(h for h, _, _ in infos)
+    cap = _cap_buffer(cap_height, maxh)
+    hs = (C.c_void_p * len(ldes))(*[t.h for t in ldes])
+    out = C.c_void_p()
+    _check(lib().ms_pcs_commit_ldes(ctx.h, C.c_uint32(cap_height), C.c_size_t(len(ldes)), hs, _b(cap), C.byref(out)))
+    return DeviceCommitment(ctx, out, cap.tobytes(), [w for _, w, _ in infos], maxh.bit_length() - 1)
+
+
 class PcsCommitment(Mmcs):
     """Pcs::commit (examples/pcs_example.rs:64-69): evaluations over the natural domains -> coset LDE + Merkle tree on the device."""
 
@@ -232,12 +288,16 @@ class Challenger:
         _check(lib().ms_challenger_create(_p(_u64(params.words())), C.byref(self.h)))
 
     def observe(self, elems):
-        e = _u64(np.atleast_1d(elems))
+        e = np.atleast_1d(np.asarray(elems, dtype=np.uint64))  # dtype first: a tuple of words above 2^63 would pass through float64
         _check(lib().ms_challenger_observe(self.h, _p(e), C.c_size_t(e.size)))
 
     def observe_digests(self, cap: bytes):
         a = np.frombuffer(cap, dtype=np.uint8)
         _check(lib().ms_challenger_observe_digests(self.h, _b(a), C.c_size_t(len(cap) // 32)))
+
+    def observe_claims(self, witness):
+        """the claims of a device-resident witness, absorbed as src/prover.rs:369-373 does (hashed on the device when long)"""
+        _check(lib().ms_challenger_observe_claims(self.h, witness.h))
 
     def sample_ext(self):
         o = np.zeros(2, dtype=np.uint64)
@@ -325,6 +385,29 @@ class SystemWitness:
             lib().ms_witness_destroy(self.h)
             self.h = None
 
+    # ---- Level 2 (include/mstark.h): the prover's steps one by one, everything staying on the device
+    def commit_stage1(self, heights, widths):
+        """pcs.commit of the stage-1 traces (src/prover.rs:338-350); heights / widths of the ACTIVE circuits"""
+        sysm = self.system
+        lb, ch = sysm.params.log_blowup, sysm.params.cap_height
+        maxh = max(heights) << lb
+        cap = _cap_buffer(ch, maxh)
+        out = C.c_void_p()
+        _check(lib().ms_witness_commit_stage1(self.h, _b(cap), C.byref(out)))
+        return DeviceCommitment(sysm.ctx, out, cap.tobytes(), widths, maxh.bit_length() - 1)
+
+    def claims_accumulator(self, beta, gamma):
+        acc = np.zeros(2, dtype=np.uint64)
+        _check(lib().ms_witness_claims_accumulator(self.h, _p(_u64(beta)), _p(_u64(gamma)), _p(acc)))
+        return int(acc[0]), int(acc[1])
+
+    def stage2_build(self, n_active, beta, gamma, acc_in):
+        """LookupValues::stage_2_traces (src/prover.rs:400): ([accumulator after each active circuit], [Trace handles])"""
+        accs = np.zeros(2 * n_active, dtype=np.uint64)
+        hs = (C.c_void_p * n_active)()
+        _check(lib().ms_stage2_build(self.h, _p(_u64(beta)), _p(_u64(gamma)), _p(_u64(acc_in)), _p(accs), hs))
+        return [(int(accs[2 * i]), int(accs[2 * i + 1])) for i in range(n_active)], [Trace(C.c_void_p(h)) for h in hs]
+
 
 class System:
     """System<GoldilocksBlake3Config> + ProverKey on one device."""
@@ -341,7 +424,9 @@ class System:
     def new(ctx, params, circuit_inputs):
         """`System::new(config, inputs)`: compiles each circuit with the front-end and commits the preprocessed traces."""
         compiled = [compile_circuit(ci) for ci in circuit_inputs]
-        return System(ctx, system_blob(params, compiled), len(compiled))
+        s = System(ctx, system_blob(params, compiled), len(compiled))
+        s.params = params
+        return s
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -466,6 +551,23 @@ class System:
             _check(rc)
             keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]
             return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
+
+    def preprocessed_mmcs(self, heights_widths):
+        """the ProverKey's preprocessed prover data as a commitment handle (None without preprocessed traces);
+        heights_widths: [(lde_height, width)] of the preprocessed matrices"""
+        out = C.c_void_p()
+        _check(lib().ms_system_preprocessed_mmcs(self.h, C.byref(out)))
+        if not out:
+            return None
+        maxh = max(h for h, _ in heights_widths)
+        return DeviceCommitment(self.ctx, out, self.preprocessed_commit(), [w for _, w in heights_widths], maxh.bit_length() - 1)
+
+    def quotient(self, ci, log_n, s1, s1_idx, s2, s2_idx, publics8, alpha):
+        """quotient_values + shifted_quotient_slices + lde_from_shifted_coefficients (src/prover.rs:483,511-517) -> LDE handle"""
+        out = C.c_void_p()
+        _check(lib().ms_quotient(self.h, C.c_size_t(ci), C.c_uint32(log_n), s1.h, C.c_size_t(s1_idx), s2.h, C.c_size_t(s2_idx),
+                                 _p(_u64(publics8)), _p(_u64(alpha)), C.byref(out)))
+        return Trace(out)
 
     def quotient_values(self, ci, publics8, log_n, log_q, pre_q, s1_q, s2_q, alpha):
         N = 1 << (log_n + log_q)

@@ -39,6 +39,20 @@ struct ms_mmcs {
   ms_ctx* owner = nullptr;
   Ctx* ctx = nullptr;
   PcsData data;
+  // a view of prover data owned by a system (the preprocessed commitment, ms_system_preprocessed_mmcs): `borrowed` points at
+  // it and `lender` keeps the system alive
+  PcsData* borrowed = nullptr;
+  ms_system* lender = nullptr;
+  PcsData& pd() { return borrowed ? *borrowed : data; }
+};
+// a device-resident matrix handed between Level-2 calls: stage-2 evaluations (kind 0: n x w, rows in the order the
+// inverse transform wants) or a committed-to-be LDE (kind 1: (n << log_blowup) x w)
+struct ms_trace {
+  ms_ctx* owner = nullptr;
+  Ctx* ctx = nullptr;
+  DMat m;
+  unsigned log_n = 0;
+  int kind = 0;
 };
 
 static thread_local std::string g_err;
@@ -408,8 +422,8 @@ int32_t ms_pcs_open(ms_ctx* c, const uint64_t params7[7], size_t n_rounds, ms_mm
   size_t mk = 0, pk = 0;
   for (size_t r = 0; r < n_rounds; r++) {
     if (rounds[r]->ctx != &ctx) throw std::runtime_error("commitment belongs to another context");
-    data.push_back(&rounds[r]->data);
-    for (size_t m = 0; m < rounds[r]->data.ldes.size(); m++) {
+    data.push_back(&rounds[r]->pd());
+    for (size_t m = 0; m < rounds[r]->pd().ldes.size(); m++) {
       std::vector<E2> pl;
       for (uint64_t k = 0; k < n_points[mk]; k++) {
         if (points[2 * pk] >= GL_P || points[2 * pk + 1] >= GL_P) throw std::runtime_error("non-canonical opening point");
@@ -443,7 +457,7 @@ int32_t ms_pcs_verify(const uint64_t params7[7], size_t n_rounds, const uint8_t*
     commits[r].resize(cap_sizes[r]);
     for (size_t i = 0; i < cap_sizes[r]; i++) memcpy(commits[r][i].b, caps[r] + 32 * i, 32);
     for (uint64_t m = 0; m < n_mats[r]; m++) {
-      if (log_n[mk] > 40) return MS_OK;
+      if (log_n[mk] + params7[0] > GL_TWO_ADICITY) return MS_OK;  // rejected: the LDE domain would exceed the field's 2-adicity
       ln[r].push_back((unsigned)log_n[mk]);
       ws[r].push_back((size_t)widths[mk]);
       std::vector<E2> pl;
@@ -469,12 +483,12 @@ int32_t ms_pcs_verify(const uint64_t params7[7], size_t n_rounds, const uint8_t*
 
 int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proof_out, size_t* n_siblings) {
   MS_TRY Ctx& ctx = *m->ctx;
-  const DTree& t = m->data.tree;
+  const DTree& t = m->pd().tree;
   unsigned lmh = log2_strict(t.max_height());
   if (index >= t.max_height()) throw std::runtime_error("index out of range");
   std::vector<GatherReq> reqs;
   size_t off = 0;
-  for (auto& dm : m->data.ldes) {
+  for (auto& dm : m->pd().ldes) {
     GatherReq q{dm.d(), dm.h, index >> (lmh - log2_strict(dm.h)), (uint32_t)dm.w, 0, off};
     reqs.push_back(q);
     off += dm.w * 8;
@@ -497,9 +511,249 @@ int32_t ms_mmcs_open(ms_mmcs* m, size_t index, uint64_t* vals_out, uint8_t* proo
 void ms_mmcs_destroy(ms_mmcs* m) {
   if (!m) return;
   ms_ctx* c = m->owner;
+  ms_system* lender = m->lender;
   m->data = PcsData();
   delete m;
+  if (lender) system_unref(lender);
   ctx_unref(c);
+}
+
+// ---------------------------------------------------------------- Level 2: the prover's steps on device handles
+// For a host that keeps the reference's own prover loop (src/prover.rs:290-603) and calls the device per step: nothing
+// but commitments, accumulators, challenges and the final opening crosses the boundary between the calls.
+static ms_trace* new_trace(ms_ctx* c, DMat&& m, unsigned log_n, int kind) {
+  ms_trace* t = new ms_trace();
+  t->owner = c;
+  t->ctx = &c->ctx;
+  t->m = std::move(m);
+  t->log_n = log_n;
+  t->kind = kind;
+  c->refs++;
+  return t;
+}
+void ms_trace_destroy(ms_trace* t) {
+  if (!t) return;
+  ms_ctx* c = t->owner;
+  t->m = DMat();
+  delete t;
+  ctx_unref(c);
+}
+int32_t ms_trace_info(const ms_trace* t, uint64_t out3[3]) {
+  MS_TRY if (!t) throw std::runtime_error("null trace handle");
+  out3[0] = t->m.h;
+  out3[1] = t->m.w;
+  out3[2] = (uint64_t)t->kind;
+  return MS_OK;
+  MS_CATCH
+}
+
+static void need_device_witness(const HWitness& w) {
+  if (w.host_resident) throw std::runtime_error("the Level-2 entry points take a device-resident witness (ms_witness_create)");
+  if (w.has_remote) throw std::runtime_error("this witness lacks traces that another rank computes");
+}
+
+int32_t ms_system_preprocessed_mmcs(ms_system* sys, ms_mmcs** out) {
+  *out = nullptr;
+  MS_TRY HSystem& s = *sys->sys;
+  if (!s.has_pre) return MS_OK;  // no preprocessed traces: *out stays null
+  std::unique_ptr<ms_mmcs> m(new ms_mmcs());
+  m->ctx = s.ctx;
+  m->borrowed = &s.pre_data;
+  m->lender = sys;
+  sys->refs++;
+  m->owner = sys->owner;
+  sys->owner->refs++;
+  *out = m.release();
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_witness_commit_stage1(ms_witness* w, uint8_t* cap_out, ms_mmcs** out) {
+  *out = nullptr;
+  MS_TRY HWitness& wit = *w->w;
+  HSystem& sys = *wit.sys;
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  need_device_witness(wit);
+  std::unique_ptr<ms_mmcs> m(new ms_mmcs());
+  m->ctx = &ctx;
+  std::vector<DMat> ldes;
+  for (size_t ci = 0; ci < sys.circuits.size(); ci++) {
+    const size_t h = wit.heights[ci];
+    if (!h) continue;
+    const size_t wd = sys.circuits[ci].main_width;
+    const unsigned logn = log2_strict(h), lb = (unsigned)sys.params.log_blowup;
+    DBuf<u64> ev(ctx, h * wd);
+    transpose_in(ctx, wit.traces[ci].p, ev.p, h, wd, true);
+    DMat lde;
+    lde.h = h << lb;
+    lde.w = wd;
+    lde.buf = DBuf<u64>(ctx, lde.h * wd);
+    coset_lde(ctx, ev.p, lde.d(), logn, lb, wd);
+    ldes.push_back(std::move(lde));
+  }
+  if (ldes.empty()) throw std::runtime_error("cannot prove with every circuit deactivated (all traces empty)");
+  commit_matrices(ctx, std::move(ldes), (unsigned)sys.params.cap_height, m->data);
+  std::vector<Digest> cap = merkle_cap(ctx, m->data.tree);
+  for (size_t i = 0; i < cap.size(); i++) memcpy(cap_out + 32 * i, cap[i].b, 32);
+  m->owner = w->owner->owner;
+  m->owner->refs++;
+  *out = m.release();
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_challenger_observe_claims(ms_challenger* ch, ms_witness* w) {
+  MS_TRY HWitness& wit = *w->w;
+  Ctx& ctx = *wit.sys->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  need_device_witness(wit);
+  observe_claims(ctx, ch->ch, wit);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_witness_claims_accumulator(ms_witness* w, const uint64_t beta[2], const uint64_t gamma[2], uint64_t acc_out[2]) {
+  MS_TRY HWitness& wit = *w->w;
+  Ctx& ctx = *wit.sys->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  need_device_witness(wit);
+  const size_t n_claims = wit.claim_offsets.size() - 1;
+  E2 a = n_claims ? claims_accumulator(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, e2(beta[0], beta[1]), e2(gamma[0], gamma[1])) : e2(0);
+  acc_out[0] = a.c0;
+  acc_out[1] = a.c1;
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_stage2_build(ms_witness* w, const uint64_t beta[2], const uint64_t gamma[2], const uint64_t acc_in[2], uint64_t* accs_out,
+                        ms_trace** traces_out) {
+  MS_TRY HWitness& wit = *w->w;
+  HSystem& sys = *wit.sys;
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  need_device_witness(wit);
+  E2 acc = e2(acc_in[0], acc_in[1]);
+  size_t pos = 0;
+  std::vector<std::unique_ptr<ms_trace, void (*)(ms_trace*)>> made;
+  for (size_t ci = 0; ci < sys.circuits.size(); ci++) {
+    const size_t n = wit.heights[ci];
+    if (!n) continue;
+    const HCircuit& c = sys.circuits[ci];
+    DMat ev;
+    ev.h = n;
+    ev.w = c.stage2_width;
+    ev.buf = DBuf<u64>(ctx, n * c.stage2_width);
+    const E2 tot = stage2_build(ctx, wit.lookups[ci], e2(beta[0], beta[1]), e2(gamma[0], gamma[1]), ev.d(), &c.stage2_jit);
+    acc = e2_add(acc, tot);
+    accs_out[2 * pos] = acc.c0;
+    accs_out[2 * pos + 1] = acc.c1;
+    made.emplace_back(new_trace(w->owner->owner, std::move(ev), log2_strict(n), 0), ms_trace_destroy);
+    pos++;
+  }
+  for (size_t i = 0; i < made.size(); i++) traces_out[i] = made[i].release();
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_pcs_commit_traces(ms_ctx* c, uint32_t log_blowup, uint32_t cap_height, size_t n, ms_trace* const* evals, uint8_t* cap_out,
+                             ms_mmcs** out) {
+  *out = nullptr;
+  MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  if (log_blowup < 1 || log_blowup > 8) throw std::runtime_error("log_blowup out of range");
+  std::unique_ptr<ms_mmcs> m(new ms_mmcs());
+  m->ctx = &ctx;
+  std::vector<DMat> ldes;
+  for (size_t i = 0; i < n; i++) {
+    ms_trace* t = evals[i];
+    if (!t || t->ctx != &ctx || t->kind != 0 || !t->m.d()) throw std::runtime_error("ms_pcs_commit_traces: not an evaluation handle of this context");
+    if (t->log_n > NTT_MAX_LOG || t->log_n + log_blowup > TW_LOG) throw std::runtime_error("matrix too tall");
+    DMat lde;
+    lde.h = t->m.h << log_blowup;
+    lde.w = t->m.w;
+    lde.buf = DBuf<u64>(ctx, lde.h * lde.w);
+    coset_lde(ctx, t->m.d(), lde.d(), t->log_n, log_blowup, lde.w);  // consumes the evaluations
+    t->m = DMat();
+    ldes.push_back(std::move(lde));
+  }
+  commit_matrices(ctx, std::move(ldes), cap_height, m->data);
+  std::vector<Digest> cap = merkle_cap(ctx, m->data.tree);
+  for (size_t i = 0; i < cap.size(); i++) memcpy(cap_out + 32 * i, cap[i].b, 32);
+  m->owner = c;
+  c->refs++;
+  *out = m.release();
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_quotient(ms_system* sys, size_t ci, uint32_t log_n, ms_mmcs* s1, size_t s1_idx, ms_mmcs* s2, size_t s2_idx,
+                    const uint64_t publics8[8], const uint64_t alpha[2], ms_trace** q_lde_out) {
+  *q_lde_out = nullptr;
+  MS_TRY HSystem& s = *sys->sys;
+  Ctx& ctx = *s.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  if (ci >= s.circuits.size()) throw std::runtime_error("circuit index out of range");
+  const HCircuit& c = s.circuits[ci];
+  const unsigned lb = (unsigned)s.params.log_blowup, log_q = log2_strict(c.quotient_degree());
+  if (s1->ctx != &ctx || s2->ctx != &ctx) throw std::runtime_error("commitment belongs to another context");
+  if (s1_idx >= s1->pd().ldes.size() || s2_idx >= s2->pd().ldes.size()) throw std::runtime_error("matrix index out of range");
+  const DMat& m1 = s1->pd().ldes[s1_idx];
+  const DMat& m2 = s2->pd().ldes[s2_idx];
+  const size_t n = size_t(1) << log_n, nq = n << log_q;
+  if (m1.h != (n << lb) || m2.h != (n << lb) || m1.w != c.main_width || m2.w != c.stage2_width)
+    throw std::runtime_error("ms_quotient: the committed matrices do not have this circuit's shape");
+  QuotientArgs qa;
+  if (s.has_pre && s.pre_indices[ci] >= 0) {
+    const DMat& pm = s.pre_data.ldes[s.pre_indices[ci]];
+    if (pm.h != (n << lb)) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    qa.pre = pm.d();
+    qa.pre_h = pm.h;
+  }
+  qa.s1 = m1.d();
+  qa.s1_h = m1.h;
+  qa.s2 = m2.d();
+  qa.s2_h = m2.h;
+  qa.log_n = log_n;
+  qa.log_q = log_q;
+  for (int k = 0; k < 8; k++) {
+    if (publics8[k] >= GL_P) throw std::runtime_error("non-canonical public value");
+    qa.publics[k] = publics8[k];
+  }
+  qa.alpha = e2(alpha[0], alpha[1]);
+  DBuf<u64> qv(ctx, nq * 2);
+  quotient_eval(ctx, c.prog, qa, qv.p);
+  DMat lde;
+  lde.h = n << lb;
+  lde.w = 2 << log_q;
+  lde.buf = DBuf<u64>(ctx, lde.h * lde.w);
+  quotient_lde(ctx, qv.p, lde.d(), log_n, log_q, lb, 2);
+  *q_lde_out = new_trace(sys->owner, std::move(lde), log_n, 1);
+  return MS_OK;
+  MS_CATCH
+}
+
+int32_t ms_pcs_commit_ldes(ms_ctx* c, uint32_t cap_height, size_t n, ms_trace* const* ldes, uint8_t* cap_out, ms_mmcs** out) {
+  *out = nullptr;
+  MS_TRY Ctx& ctx = c->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  std::unique_ptr<ms_mmcs> m(new ms_mmcs());
+  m->ctx = &ctx;
+  std::vector<DMat> ms;
+  for (size_t i = 0; i < n; i++) {
+    ms_trace* t = ldes[i];
+    if (!t || t->ctx != &ctx || t->kind != 1 || !t->m.d()) throw std::runtime_error("ms_pcs_commit_ldes: not an LDE handle of this context");
+    ms.push_back(std::move(t->m));  // the commitment takes the matrix over
+    t->m = DMat();
+  }
+  commit_matrices(ctx, std::move(ms), cap_height, m->data);
+  std::vector<Digest> cap = merkle_cap(ctx, m->data.tree);
+  for (size_t i = 0; i < cap.size(); i++) memcpy(cap_out + 32 * i, cap[i].b, 32);
+  m->owner = c;
+  c->refs++;
+  *out = m.release();
+  return MS_OK;
+  MS_CATCH
 }
 
 int32_t ms_blake3(ms_ctx* c, const uint8_t* bytes, size_t len, uint8_t out32[32]) {

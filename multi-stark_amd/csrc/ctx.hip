@@ -1,4 +1,6 @@
 // Device context: stream, twiddle tables, pooled memory, event-based per-kernel timing.
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -15,6 +17,44 @@ thread_local Ctx* tl_pending_ctx = nullptr;
 std::mutex g_live_mu;
 std::set<Ctx*> g_live;
 }  // namespace
+namespace {
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    if (getenv("MSAMD_NO_ROCTX")) return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr;
+      pop = nullptr;
+    }
+  }
+};
+const RoctxApi& roctx() {
+  static RoctxApi api;
+  return api;
+}
+}  // namespace
+RoctxRange::RoctxRange(const char* name) {
+  if (roctx().push) {
+    roctx().push(name);
+    on = true;
+  }
+}
+RoctxRange::~RoctxRange() {
+  if (on) roctx().pop();
+}
+void RoctxRange::next(const char* name) {
+  if (on) {
+    roctx().pop();
+    roctx().push(name);
+  }
+}
+
 void abandon_pending() {
   Ctx* c = tl_pending_ctx;
   tl_pending_ctx = nullptr;

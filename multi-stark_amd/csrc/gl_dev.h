@@ -336,7 +336,11 @@ GL_HD u64 gl_inv(u64 a) {
   u64 r = gl_exp_pow2(t31, 33);
   return gl_mul(r, t32);
 }
-GL_HD u64 gl_two_adic_generator(unsigned bits) { return gl_exp_pow2(GL_W32, 32 - bits); }
+static constexpr unsigned GL_TWO_ADICITY = 32;
+// generator of the subgroup of order 2^bits, bits <= 32 (callers bound bits; beyond the 2-adicity there is no such root
+// and the unsigned difference below would wrap into billions of squarings: answer with 0, which no caller can mistake
+// for a root of unity)
+GL_HD u64 gl_two_adic_generator(unsigned bits) { return bits > GL_TWO_ADICITY ? 0 : gl_exp_pow2(GL_W32, GL_TWO_ADICITY - bits); }
 
 struct E2 {
   u64 c0, c1;

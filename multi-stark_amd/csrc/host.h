@@ -142,6 +142,8 @@ bool pcs_verify_standalone(const Params& prm, const std::vector<std::vector<Dige
                            const std::vector<E2>& opened_flat, const uint8_t* fri, size_t fri_len, Challenger& ch);
 
 void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out);
+// the claims part of the transcript (src/prover.rs:369-373) for a device-resident witness: long lists are hashed on the device
+void observe_claims(Ctx& ctx, Challenger& ch, HWitness& wit);
 void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out);
 
 }  // namespace msamd

@@ -123,6 +123,16 @@ struct Ctx {
   void prof_collect();
 };
 
+// roctx range with one of the reference's tracing span names (src/prover.rs:289,336,391,413,437,538: "stark/prove",
+// "stark/stage1_commit", ...), so that rocprofv3 --marker-trace shows the same phases the reference's tracing subscriber
+// does. The roctx library is looked up at run time; without it the ranges cost nothing.
+struct RoctxRange {
+  bool on = false;
+  explicit RoctxRange(const char* name);
+  ~RoctxRange();
+  void next(const char* name);  // close the current range and open another one
+};
+
 // drop read-backs queued by the calling thread whose destinations an error has unwound (called by the C-ABI catch blocks)
 void abandon_pending();
 

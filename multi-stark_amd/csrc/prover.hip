@@ -1233,6 +1233,30 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
 }
 }  // namespace
 
+// claims, length-prefixed (src/prover.rs:369-373), absorbed into `ch`. Large claim sets are hashed on the device: the
+// transcript since the last sample is `ch.input || words` and the next operation is a sample, so the digest is all the
+// challenger needs (prove() below does the same with the stage-1 commitment patched in on the device).
+void observe_claims(Ctx& ctx, Challenger& ch, HWitness& wit) {
+  const size_t n_claims = wit.claim_offsets.size() - 1;
+  const size_t claim_elems = wit.claim_data.size();
+  const size_t claim_words = 1 + n_claims + claim_elems;
+  if (claim_words <= 8192) {
+    ch.observe((u64)n_claims);
+    for (size_t i = 0; i < n_claims; i++) {
+      size_t a = wit.claim_offsets[i], b = wit.claim_offsets[i + 1];
+      ch.observe((u64)(b - a));
+      for (size_t k = a; k < b; k++) ch.observe(wit.claim_data[k]);
+    }
+    return;
+  }
+  DBuf<uint8_t> d_prefix(ctx, ch.input.size());
+  ctx.h2d(d_prefix.p, ch.input.data(), ch.input.size());
+  DBuf<u64> d_words(ctx, claim_words);
+  claims_transcript_words(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, claim_elems, d_words.p);
+  Digest d = blake3_device(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words);
+  ch.flush_with(d);
+}
+
 // ------------------------------------------------------------------ prove
 std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   Ctx& ctx = *sys.ctx;
@@ -1250,6 +1274,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
   };
 
+  RoctxRange whole("stark/prove");
   HostUpload up(wit, ctx);  // host-resident witness: uploads start now and run beside the transcript set-up
   up.start();
   Challenger ch(sys.seed);
@@ -1279,6 +1304,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
   // ---- stage 1 commit (src/prover.rs:336-351)
   t0 = now_ms();
+  RoctxRange phase("stark/stage1_commit");
   std::vector<unsigned> log_degrees;
   PcsData s1;
   {
@@ -1355,6 +1381,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
   // ---- lookup construction (src/prover.rs:391-409) + stage 2 commit (:413-421)
   t0 = now_ms();
+  phase.next("stark/lookup_construction");
   std::vector<DBuf<u64>> s2_evals(NA);
   for (size_t pos = 0; pos < NA; pos++) {
     size_t ci = aidx[pos];
@@ -1365,6 +1392,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   }
   lap(1);
   t0 = now_ms();
+  phase.next("stark/stage2_commit");
   PcsData s2;
   {
     std::vector<DMat> ldes;
@@ -1399,6 +1427,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
   // ---- quotient (src/prover.rs:437-528)
   t0 = now_ms();
+  phase.next("stark/quotient");
   PcsData qd;
   {
     std::vector<DMat> qldes;
@@ -1444,6 +1473,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
   // ---- opening (src/prover.rs:538-581)
   t0 = now_ms();
+  phase.next("stark/fri_open");
   const E2 zeta = ch.sample_ext();
   std::vector<OpenRound> rounds(3);
   rounds[0].data = &s1;

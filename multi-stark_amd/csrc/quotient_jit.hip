@@ -149,14 +149,6 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
   return o.str();
 }
 
-u64 fnv1a(const std::string& s, u64 h) {
-  for (unsigned char c : s) {
-    h ^= c;
-    h *= 1099511628211ULL;
-  }
-  return h;
-}
-
 // ---- hiprtc through dlopen (no link-time dependency: a box without it still runs the interpreter)
 struct Rtc {
   void* lib = nullptr;
@@ -167,6 +159,7 @@ struct Rtc {
   int (*code_size)(void*, size_t*) = nullptr;
   int (*get_code)(void*, char*) = nullptr;
   int (*destroy)(void**) = nullptr;
+  int version = 0;  // major * 1000 + minor: part of the cache key
   bool ok = false;
   Rtc() {
     for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
@@ -182,12 +175,16 @@ struct Rtc {
     get_code = (decltype(get_code))dlsym(lib, "hiprtcGetCode");
     destroy = (decltype(destroy))dlsym(lib, "hiprtcDestroyProgram");
     ok = create && compile && log_size && get_log && code_size && get_code && destroy;
+    if (auto ver = (int (*)(int*, int*))dlsym(lib, "hiprtcVersion")) {
+      int major = 0, minor = 0;
+      if (ver(&major, &minor) == 0) version = major * 1000 + minor;
+    }
   }
 };
 
 std::string library_dir() {
   Dl_info info;
-  if (dladdr((void*)&fnv1a, &info) && info.dli_fname) {
+  if (dladdr((void*)&library_dir, &info) && info.dli_fname) {
     std::string p = info.dli_fname;
     size_t k = p.rfind('/');
     return k == std::string::npos ? "." : p.substr(0, k);
@@ -196,7 +193,7 @@ std::string library_dir() {
 }
 
 std::mutex g_mu;
-std::map<u64, std::vector<char>> g_code;  // source hash -> code object (empty = compilation failed, do not retry)
+std::map<std::string, std::vector<char>> g_code;  // key digest -> code object (empty = compilation failed, do not retry)
 
 bool read_file(const std::string& path, std::vector<char>& out) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -210,31 +207,63 @@ bool read_file(const std::string& path, std::vector<char>& out) {
   return ok;
 }
 
+// the architecture the code objects are built for: that of the current device (gfx950 on MI355X)
+std::string device_arch() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return "gfx950";
+  }
+  std::string a = prop.gcnArchName;  // "gfx950:sramecc+:xnack-"
+  const size_t k = a.find(':');
+  return k == std::string::npos ? a : a.substr(0, k);
+}
+
+// A cached code object is only ever loaded when it was built from exactly this program: the key is the BLAKE3 digest of the
+// source, the headers it includes, the target architecture, the hiprtc version and the compiler options, and the file
+// carries that digest in its header (a stale, foreign or truncated file is ignored and rebuilt). The cache directory
+// is private to the user.
+const char CACHE_MAGIC[8] = {'M', 'S', 'J', 'C', '0', '0', '0', '2'};
+
 const std::vector<char>* code_object(const std::string& src) {
   static Rtc rtc;
   const std::string dir = library_dir();
+  const std::string arch = device_arch();
+  const std::string inc = "-I" + dir + "/csrc";
+  const std::string arch_opt = "--offload-arch=" + arch;
+  const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", inc.c_str()};
+  std::string key = arch + '\0' + std::to_string(rtc.version) + '\0' + "-O3 -std=c++17" + '\0';
   // the headers are part of the program: a change to the field arithmetic must not reuse old code objects
-  u64 h = fnv1a(src, 1469598103934665603ULL);
   for (const char* hdr : {"/csrc/gl_dev.h", "/csrc/quotient_params.h", "/csrc/lookup_params.h"}) {
     std::vector<char> t;
-    if (read_file(dir + hdr, t)) h = fnv1a(std::string(t.begin(), t.end()), h);
+    if (read_file(dir + hdr, t)) key.append(t.begin(), t.end());
+    key += '\0';
   }
+  key += src;
+  uint8_t dg[32];
+  blake3_host(reinterpret_cast<const uint8_t*>(key.data()), key.size(), dg);
+  char hex[65];
+  for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", dg[i]);
+  const std::string id(hex, 64);
   std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_code.find(h);
+  auto it = g_code.find(id);
   if (it != g_code.end()) return it->second.empty() ? nullptr : &it->second;
-  std::vector<char>& slot = g_code[h];
+  std::vector<char>& slot = g_code[id];
   const char* env = getenv("MSAMD_JIT_CACHE");
   const std::string cache_dir = env ? env : dir + "/.jit_cache";
-  char name[64];
-  snprintf(name, sizeof(name), "/q_%016llx.co", (unsigned long long)h);
-  const std::string path = cache_dir + name;
-  if (read_file(path, slot)) return &slot;
+  const std::string path = cache_dir + "/q_" + id.substr(0, 32) + ".co";
+  {
+    std::vector<char> file;
+    if (read_file(path, file) && file.size() > 40 && memcmp(file.data(), CACHE_MAGIC, 8) == 0 && memcmp(file.data() + 8, dg, 32) == 0) {
+      slot.assign(file.begin() + 40, file.end());
+      return &slot;
+    }
+  }
   slot.clear();
   if (!rtc.ok) return nullptr;
   void* prog = nullptr;
   if (rtc.create(&prog, src.c_str(), "quotient_jit.hip", 0, nullptr, nullptr) != 0) return nullptr;
-  const std::string inc = "-I" + dir + "/csrc";
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
   const int rc = rtc.compile(prog, 4, opts);
   if (rc != 0) {
     size_t ls = 0;
@@ -251,10 +280,10 @@ const std::vector<char>* code_object(const std::string& src) {
   rtc.get_code(prog, slot.data());
   rtc.destroy(&prog);
   // best-effort disk cache: write to a private name, then rename (several ranks may compile the same program)
-  mkdir(cache_dir.c_str(), 0755);
+  mkdir(cache_dir.c_str(), 0700);
   const std::string tmp = path + "." + std::to_string((long)getpid());
   if (FILE* f = fopen(tmp.c_str(), "wb")) {
-    const bool ok = fwrite(slot.data(), 1, slot.size(), f) == slot.size();
+    const bool ok = fwrite(CACHE_MAGIC, 1, 8, f) == 8 && fwrite(dg, 1, 32, f) == 32 && fwrite(slot.data(), 1, slot.size(), f) == slot.size();
     fclose(f);
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
   }

@@ -251,7 +251,7 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
   const size_t nrounds = proof.commits.size();
   if (proof.pow.size() != nrounds) return false;
   const unsigned log_gmax = (unsigned)(nrounds + lb + prm.log_final_poly_len);
-  if (log_gmax > 40) return false;
+  if (log_gmax > GL_TWO_ADICITY) return false;  // no subgroup of that order: gl_two_adic_generator is defined up to 2^32
   std::vector<E2> betas;
   for (size_t i = 0; i < nrounds; i++) {
     ch.observe_cap(proof.commits[i]);
