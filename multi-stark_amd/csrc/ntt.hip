@@ -363,19 +363,36 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
                                                const u64* __restrict__ twc, const u64* __restrict__ twc3,
                                                const u64* __restrict__ t0, const u64* __restrict__ t1,
                                                const u64* __restrict__ ttab, unsigned src_div, const u64* __restrict__ scale,
-                                               u64 out_mul) {
+                                               u64 out_mul, u32 gx, u32 ncols) {
   __shared__ u64 sm[NTT12_LDS];
   const size_t n = size_t(1) << logn;
   const unsigned logB = 8 + logS;
   const unsigned tiles = 1u << (logS - 4);
-  const size_t col = blockIdx.y;
+  // Tile -> workgroup mapping. The coset scale and the inter-pass twiddle of a tile are the same for every column, and
+  // together they are as many bytes as the tile itself: with one column per grid row they were fetched again for each of
+  // the 56 / 104 columns (FETCH_SIZE 1.40 x the algorithmic bytes, profiles/r01_traffic.json). Workgroups are dispatched
+  // round-robin over the 8 XCDs, each with its own L2: XCD x now walks through ALL columns of one tile before it moves
+  // to the next, so a table tile enters an L2 once and serves every column from there.
+  size_t col;
+  u32 bx;
+  {
+    const size_t id = blockIdx.x;
+    if ((gx & 7u) == 0) {
+      const size_t q = id >> 3;
+      col = q % ncols;
+      bx = (u32)((q / ncols) * 8 + (id & 7));
+    } else {
+      col = id % ncols;
+      bx = (u32)(id / ncols);
+    }
+  }
   const u32 t = threadIdx.x, hq = t >> 4, l = t & 15;  // hq: low 4 bits of h in the strided round, high 4 in the other
   const unsigned esh = TW_LOG - logB;
   const u32 rev_hq = bitrev32(hq, 4);
   u64 x[16];
   if (!DIT) {
-    const u32 lg = ((blockIdx.x & (tiles - 1)) << 4) + l;
-    const size_t base = size_t(blockIdx.x >> (logS - 4)) << logB;
+    const u32 lg = ((bx & (tiles - 1)) << 4) + l;
+    const size_t base = size_t(bx >> (logS - 4)) << logB;
     const u64* s = src + (col / src_div) * n + base;
     const u64* sc = scale ? scale + (col % src_div) * n + base : nullptr;
     u64* d = dst + col * n + base;
@@ -406,8 +423,8 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
       d[(size_t(hq * 16 + j) << logS) + lg] = v;
     }
   } else {
-    const u32 tile = blockIdx.x & (tiles - 1);
-    const size_t blk = blockIdx.x >> (logS - 4);
+    const u32 tile = bx & (tiles - 1);
+    const size_t blk = bx >> (logS - 4);
     const u32 l0 = tile << 4;
     const size_t base = blk << logB;
     const u64* s = src + (col / src_div) * n + base;
@@ -490,12 +507,15 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
     const int id = DIT ? K_NTT8S_DIT : K_NTT8S_DIF;
     hipEvent_t ev8 = ctx.prof_begin(id);
     const u64* ttab = ntt8s_table(ctx, logB, inverse);
+    if (gx8 * ncols > 0x7FFFFFFFull) throw std::runtime_error("ntt: too many tiles in one launch");
     if (inverse)
-      hipLaunchKernelGGL((ntt8s_k<(DIT != 0), true>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twci, MSAMD_R16TW ? ctx.twfi : ctx.twc3i, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt8s_k<(DIT != 0), true>), dim3((unsigned)(gx8 * ncols)), dim3(256), 0, ctx.stream, src, dst, logS, logn,
+                         ctx.twci, MSAMD_R16TW ? ctx.twfi : ctx.twc3i, ctx.tw0i, ctx.tw1i, ttab, src_div, scale, out_mul, (u32)gx8,
+                         (u32)ncols);
     else
-      hipLaunchKernelGGL((ntt8s_k<(DIT != 0), false>), dim3((unsigned)gx8, (unsigned)ncols), dim3(256), 0, ctx.stream, src, dst, logS,
-                         logn, ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt8s_k<(DIT != 0), false>), dim3((unsigned)(gx8 * ncols)), dim3(256), 0, ctx.stream, src, dst, logS, logn,
+                         ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul, (u32)gx8,
+                         (u32)ncols);
     ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
