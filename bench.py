@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="goldilocks", choices=["goldilocks", "babybear"], help="goldilocks: BASELINE config 2 / 3 (the "
+                    "headline); babybear: BASELINE config 4, the reference's second StarkGenericConfig (BabyBear, degree-4 extension, "
+                    "Poseidon2; src/test_circuits/baby_bear_config.rs) on MulAir at 2^log-adds rows, N = 1 only")
     ap.add_argument("--log-adds", type=int, default=20, help="log2 of U32 additions per proof / per rank (BASELINE: 20)")
     ap.add_argument("--cpu-log-adds", type=int, default=20, help="size of the CPU baseline leg (same workload as the GPU by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,6 +222,96 @@ def single_gpu(args, pkg, fe, ctx, torch):
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(fe, system.blob, args.cpu_log_adds)
     return result
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+VALU_PEAK_TOPS = 39.4      # integer lane-ops/s at one VALU instruction per cycle and SIMD lane (tools/micro/b3_rate.hip: 58 G BLAKE3/s x 680)
+POSEIDON2_INSTR = 9.0e3    # VALU instructions per Poseidon2-16 permutation and lane (profiles/r01_config4_kernel_stats.txt: SQ counters)
+
+
+def babybear(args, pkg, fe, ctx, torch):
+    """BASELINE config 4: BabyBear + degree-4 extension + Poseidon2 (the reference's test-suite instantiation,
+    src/test_circuits/baby_bear_config.rs:28-127), MulAir at 2^20 rows with the test parameters (blowup 2, 64 queries). The
+    witness is resident in HBM (include/mstark_bb.h has no host-resident form; the 12.6 MB trace would add ~0.2 ms)."""
+    bb = pkg.babybear
+    consts = fe.poseidon2_constants()
+    rows = 1 << args.log_adds
+    with fe.field(fe.BABYBEAR):
+        params = fe.test_params()
+        system = bb.System.new(ctx, params, fe.mul_air_inputs(), consts)
+        trace = fe.mul_air_trace(rows)
+        packed = fe.pack_claims([])
+    witness = system.witness([trace], packed)
+
+    def step():
+        return system.prove_multiple_claims(witness)
+
+    proof, dominant = profile_first_step(ctx, step, 0)
+    for _ in range(max(args.warmup, 1) - 1):
+        proof = step()
+    ctx.set_profile([dominant])
+    ctx.reset_stats()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    dom = ctx.kernel_stats()[dominant]
+    ctx.set_profile([])
+    log("timed region done: %.3f ms per step" % (1e3 * elapsed / args.steps))
+    assert system.verify(packed, proof.to_bytes()) == 0, "the library's own verifier rejects the proof"
+    stage = system.prove_multiple_claims(witness, want_times=True).stage_ms
+    result = base_line(args, 1, rows * args.steps / elapsed, 1e3 * elapsed / args.steps)
+    result["dtype"] = "u32"
+    result["config"] = {
+        "workload": "BASELINE config 4: MulAir (a * b = c with a self-cancelling lookup pair), 2^%d rows, BabyBear / degree-4 extension / "
+                    "Poseidon2-16 sponge and compression / DuplexChallenger (src/test_circuits/baby_bear_config.rs), log_blowup 1, 64 queries; "
+                    "witness resident in HBM, proof bytes returned to host" % args.log_adds,
+        "rows_per_proof": rows,
+        "proof_bytes": len(proof.to_bytes()),
+        "parallelism": "single GPU",
+        "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+    }
+    rl = roofline_of(dominant, dom)
+    rl["traffic"], rl["traffic_source"] = None, "not collected for this configuration"
+    if dom.get("units"):
+        perms_per_s = dom["units"] / max(dom["ms"], 1e-12) * 1e3
+        rl["valu"] = {"what": "Poseidon2 permutations of this kernel class priced at %.0f VALU instructions each against the integer "
+                              "issue peak: the bound that actually binds (the class moves a few per cent of the HBM peak)" % POSEIDON2_INSTR,
+                      "permutations_per_s": perms_per_s, "achieved_Tops": perms_per_s * POSEIDON2_INSTR / 1e12, "peak_Tops": VALU_PEAK_TOPS,
+                      "frac": perms_per_s * POSEIDON2_INSTR / 1e12 / VALU_PEAK_TOPS}
+    result["roofline"] = rl
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_babybear(system.blob, trace, packed, proof.to_bytes(), rows)
+    return result
+
+
+def cpu_baseline_babybear(blob, trace, packed, gpu_proof, rows):
+    """the oracle built for the BabyBear configuration (oracle/libms_oracle_bb.so), same input, same bytes"""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    load_oracle()
+    import oracle_bb as ob
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(32, avail)
+    ob.set_threads(cores)
+    osys = ob.System(blob)
+    best = None
+    t_all = time.time()
+    runs = 0
+    while runs < 3 and (runs == 0 or time.time() - t_all < 20):
+        t0 = time.perf_counter()
+        want = osys.prove([trace], packed)
+        dt = time.perf_counter() - t0
+        runs += 1
+        best = dt if best is None else min(best, dt)
+        log("cpu baseline (BabyBear): proof %d took %.3f s" % (runs, dt))
+    assert want == gpu_proof, "GPU proof differs from the oracle's"
+    return {"value": rows / best, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": "oracle C++ restatement built with -DMSO_BABYBEAR (OpenMP, %d threads), same circuit, parameters and trace as the GPU "
+                      "step (2^%d rows), best of %d proofs, %.3f s/proof, bytes identical to the GPU proof" % (
+                          cores, rows.bit_length() - 1, runs, best)}
 
 
 # ------------------------------------------------------------------------------------------------ N > 1
@@ -435,7 +528,11 @@ def main():
     pkg = load_package()
     fe = pkg.frontend
     ctx = pkg.Context(local_rank)
-    if dist is None:
+    if args.config == "babybear":
+        if dist is not None:
+            raise SystemExit("--config babybear is a single-GPU measurement")
+        result = babybear(args, pkg, fe, ctx, torch)
+    elif dist is None:
         result = single_gpu(args, pkg, fe, ctx, torch)
     else:
         result = multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus)

@@ -55,6 +55,7 @@ extern "C" {
     pub fn ms_ctx_set_profile_mask(ctx: *mut ms_ctx, mask: u32) -> i32;
     pub fn ms_ctx_kernel_stats(ctx: *mut ms_ctx, kernel_id: i32, launches: *mut u64, ms: *mut f64, alg_bytes: *mut f64) -> i32;
     pub fn ms_ctx_reset_stats(ctx: *mut ms_ctx) -> i32;
+    pub fn ms_ctx_kernel_units(ctx: *mut ms_ctx, kernel_id: i32, units: *mut f64) -> i32;
     pub fn ms_ctx_debug_fail_alloc(ctx: *mut ms_ctx, nth: i32) -> i32;
     pub fn ms_kernel_count() -> i32;
     pub fn ms_kernel_name(kernel_id: i32) -> *const c_char;

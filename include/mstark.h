@@ -65,6 +65,8 @@ int32_t ms_ctx_trim(ms_ctx* ctx);
 /* Per-kernel-class timing with HIP events on the library's stream. mask bit i enables class i. */
 int32_t ms_ctx_set_profile_mask(ms_ctx* ctx, uint32_t mask);
 int32_t ms_ctx_kernel_stats(ms_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* ms, double* alg_bytes);
+/* work items other than bytes recorded for a class (Poseidon2 permutations of the hash classes on the BabyBear path) */
+int32_t ms_ctx_kernel_units(ms_ctx* ctx, int32_t kernel_id, double* units);
 int32_t ms_ctx_reset_stats(ms_ctx* ctx);
 /* Diagnostics: the nth device allocation from now fails (0 = off). Lets a test check that an error in the middle of a
  * proof leaves the library usable (queued read-backs dropped, pool intact). */

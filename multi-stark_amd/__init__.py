@@ -42,7 +42,7 @@ def lib():
 def exported_symbols():
     """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
-            "ms_ctx_kernel_stats", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
+            "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
             "ms_comm_rccl_table", "ms_comm_rccl_bytes_moved", "ms_comm_rccl_destroy", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
@@ -120,7 +120,9 @@ class Context:
         for i, n in enumerate(self.kernel_names()):
             launches, ms, byts = C.c_uint64(), C.c_double(), C.c_double()
             _check(lib().ms_ctx_kernel_stats(self.h, C.c_int32(i), C.byref(launches), C.byref(ms), C.byref(byts)))
-            out[n] = {"launches": launches.value, "ms": ms.value, "alg_bytes": byts.value}
+            units = C.c_double()
+            _check(lib().ms_ctx_kernel_units(self.h, C.c_int32(i), C.byref(units)))
+            out[n] = {"launches": launches.value, "ms": ms.value, "alg_bytes": byts.value, "units": units.value}
         return out
 
     # ---- PCS-level entry points

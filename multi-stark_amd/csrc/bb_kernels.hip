@@ -12,6 +12,19 @@ namespace msbb {
 using msamd::PNode;
 
 static inline unsigned blocks_for(size_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+// HIP-event timing of one launch for a kernel class (ms_ctx_set_profile_mask): the classes are those of the Goldilocks
+// path; `units` counts Poseidon2 permutations for the hash classes (bench.py prices them against the VALU issue peak)
+struct ProfScope {
+  Ctx& ctx;
+  int id;
+  hipEvent_t ev;
+  double bytes, units;
+  ProfScope(Ctx& c, int kid, double alg_bytes, double n_units = 0) : ctx(c), id(kid), ev(c.prof_begin(kid)), bytes(alg_bytes), units(n_units) {}
+  ~ProfScope() {
+    if (ev) ctx.stats[id].units += units;
+    ctx.prof_end(id, ev, bytes);
+  }
+};
 
 __device__ __forceinline__ size_t bitrev_dev(size_t x, unsigned bits) { return bits ? (size_t)(__brevll((unsigned long long)x) >> (64 - bits)) : 0; }
 
@@ -186,6 +199,7 @@ void bb_dif(Ctx& ctx, u32* data, size_t ld, unsigned n, size_t ncols) {
   unsigned l0 = 0;
   const bool lds_passes = getenv("MSBB_NTT_LDS") != nullptr;  // the plain LDS radix-2 passes (tests)
   while (!lds_passes && n - l0 >= 12) {  // eight layers per register pass (the low index keeps >= 4 bits: 64-byte runs)
+    ProfScope prof(ctx, msamd::K_NTT8S_DIF, 8.0 * double(size_t(1) << n) * double(ncols));
     if (n - l0 >= 13) {
       dim3 grid((unsigned)((size_t(1) << n) >> 13), (unsigned)ncols);
       ntt_r16_k<32><<<grid, 512, 0, ctx.stream>>>(data, ld, n, l0, tw);
@@ -197,12 +211,14 @@ void bb_dif(Ctx& ctx, u32* data, size_t ld, unsigned n, size_t ncols) {
   }
   while (n - l0 > 12) {  // 7 layers per LDS pass
     dim3 grid((unsigned)((size_t(1) << n) >> 12), (unsigned)ncols);
+    ProfScope prof(ctx, msamd::K_NTT_STRIDED, 8.0 * double(size_t(1) << n) * double(ncols));
     ntt_strided_k<7, 32><<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, tw);
     l0 += 7;
   }
   if (l0 == n) return;
   unsigned log_ts = std::min(n, 12u);
   dim3 grid((unsigned)((size_t(1) << n) >> log_ts), (unsigned)ncols);
+  ProfScope prof(ctx, msamd::K_NTT_CONTIG, 8.0 * double(size_t(1) << n) * double(ncols));
   ntt_contig_k<<<grid, 256, 0, ctx.stream>>>(data, ld, n, l0, log_ts, tw);
 }
 
@@ -232,7 +248,10 @@ void bb_coset_lde(Ctx& ctx, const BMat& evals, unsigned lb, BMat& out) {
   bb_dif(ctx, tmp.p, n, log_n, w);
   u32 n_inv = bb_inv(bb_to_monty((u32)(n % BB_P)));
   dim3 grid(blocks_for(N, 256), (unsigned)w);
-  idft_gather_k<<<grid, 256, 0, ctx.stream>>>(tmp.p, n, log_n, out.buf.p, out.ld, N, n_inv, bb_to_monty(BB_GENERATOR));
+  {
+    ProfScope prof(ctx, msamd::K_TRANSPOSE, 4.0 * double(n + N) * double(w));
+    idft_gather_k<<<grid, 256, 0, ctx.stream>>>(tmp.p, n, log_n, out.buf.p, out.ld, N, n_inv, bb_to_monty(BB_GENERATOR));
+  }
   bb_dif(ctx, out.buf.p, out.ld, log_n + lb, w);  // (tmp returns to the pool: reuse is ordered by the stream)
 }
 
@@ -444,6 +463,8 @@ static void hash_group(Ctx& ctx, const Poseidon2* d_perm, const std::vector<cons
     for (size_t c = 0; c < m->w; c++) cols.push_back(m->col(c));
   DBuf<const u32*> d_cols(ctx, std::max<size_t>(cols.size(), 1));
   if (!cols.empty()) ctx.h2d(d_cols.p, cols.data(), cols.size() * sizeof(const u32*));
+  // PaddingFreeSponge<_, 16, 8, 8>: one permutation per 8 row elements
+  ProfScope prof(ctx, msamd::K_LEAF_HASH, double(rows) * (4.0 * cols.size() + 32.0), double(rows) * double(std::max<size_t>((cols.size() + 7) / 8, 1)));
   if (rows <= COOP_MAX)
     leaf_hash_coop_k<<<blocks_for(rows * 16, 256), 256, 0, ctx.stream>>>(d_cols.p, (unsigned)cols.size(), rows, d_perm, out);
   else
@@ -463,6 +484,7 @@ static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, cons
         a.level[a.n_levels++] = t.layers.back().p;
         if (n == 1) break;
       }
+      ProfScope prof(ctx, msamd::K_COMPRESS, 96.0 * double(cur), double(cur));
       tree_tail_k<<<1, 1024, 0, ctx.stream>>>(a, d_perm);
       break;
     }
@@ -474,6 +496,7 @@ static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, cons
       hash_group(ctx, d_perm, group, nl, inj.p);
     }
     DBuf<Digest8> next(ctx, nl);
+    ProfScope prof(ctx, msamd::K_COMPRESS, 96.0 * double(nl), double(nl) * (group.empty() ? 1.0 : 2.0));
     if (nl <= COOP_MAX)
       compress_coop_k<<<blocks_for(nl * 16, 256), 256, 0, ctx.stream>>>(t.layers.back().p, nl, group.empty() ? nullptr : inj.p, d_perm, next.p);
     else
@@ -508,10 +531,13 @@ void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t 
   t.cap_height = cap_height;
   t.layers.emplace_back(ctx, rows);
   t.sizes.push_back(rows);
-  if (rows <= COOP_MAX)
-    leaf_hash8_coop_k<<<blocks_for(rows * 16, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
-  else
-    leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
+  {
+    ProfScope prof(ctx, msamd::K_LEAF_HASH, 64.0 * double(rows), double(rows));
+    if (rows <= COOP_MAX)
+      leaf_hash8_coop_k<<<blocks_for(rows * 16, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
+    else
+      leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
+  }
   build_upper_layers(ctx, d_perm, t, {}, 0);
 }
 
@@ -883,6 +909,7 @@ void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals) {
   p.scratch = scratch.p, p.stride = chunk;
   for (size_t row0 = 0; row0 < N; row0 += chunk) {
     p.row0 = row0, p.rows = std::min(chunk, N - row0);
+    ProfScope prof(ctx, msamd::K_QUOTIENT, double(p.rows) * (8.0 * double(in.s1->w + in.s2->w + (in.pre ? in.pre->w : 0)) + 16.0));
     quotient_k<<<blocks_for(p.rows, 256), 256, 0, ctx.stream>>>(p);
   }
 }
@@ -957,6 +984,7 @@ void bb_deep(Ctx& ctx, const BMat& m, const E4* d_apow, int npoints, const E4* c
     p.K[k] = k < npoints ? K[k] : e4_zero();
     p.off[k] = k < npoints ? off[k] : e4_zero();
   }
+  ProfScope prof(ctx, msamd::K_DEEP, double(m.h) * (4.0 * double(m.w) + 32.0));
   deep_k<<<blocks_for(m.h, 256), 256, 0, ctx.stream>>>(p);
 }
 // FRI fold of one layer (p3 TwoAdicFriFolding::fold_matrix, arity 2): rows (lo, hi) are the values at (x, -x) with

@@ -147,6 +147,13 @@ int32_t ms_ctx_kernel_stats(ms_ctx* ctx, int32_t id, uint64_t* launches, double*
   return MS_OK;
   MS_CATCH
 }
+int32_t ms_ctx_kernel_units(ms_ctx* ctx, int32_t id, double* units) {
+  MS_TRY if (id < 0 || id >= K_COUNT) throw std::runtime_error("kernel id out of range");
+  ctx->ctx.prof_collect();
+  *units = ctx->ctx.stats[id].units;
+  return MS_OK;
+  MS_CATCH
+}
 int32_t ms_ctx_reset_stats(ms_ctx* ctx) {
   MS_TRY ctx->ctx.prof_collect();
   for (auto& s : ctx->ctx.stats) s = KernelStat();

@@ -55,6 +55,7 @@ struct KernelStat {
   uint64_t launches = 0;
   double ms = 0;
   double alg_bytes = 0;  // algorithmic bytes moved (each logical input read once, each output written once)
+  double units = 0;      // work items other than bytes where a class has them (Poseidon2 permutations of the BabyBear path)
 };
 
 struct Ctx {
