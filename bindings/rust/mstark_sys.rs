@@ -69,6 +69,7 @@ extern "C" {
     pub fn ms_witness_create_host(sys: *mut ms_system, traces: *const *const u64, heights: *const u64, n_claims: usize,
                                   claim_offsets: *const u64, claim_data: *const u64, pinned: *mut i32,
                                   out: *mut *mut ms_witness) -> i32;
+    pub fn ms_witness_prefetch(w: *mut ms_witness, on: i32) -> i32;
     pub fn ms_witness_u32_add_bench(sys: *mut ms_system, num_adds: usize, a0: u32, b0: u32, out: *mut *mut ms_witness) -> i32;
     pub fn ms_witness_destroy(w: *mut ms_witness);
     pub fn ms_prove(sys: *mut ms_system, w: *mut ms_witness, proof_out: *mut u8, cap: usize, proof_len: *mut usize, stage_ms: *mut f64) -> i32;

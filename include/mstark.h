@@ -101,6 +101,13 @@ int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const u
 int32_t ms_witness_create_host(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, size_t n_claims,
                                const uint64_t* claim_offsets, const uint64_t* claim_data, int32_t* pinned /* nullable */,
                                ms_witness** out);
+/* Proving in a stream (a prover service proves one witness after another): with on = 1 every ms_prove of this host-resident
+ * witness also queues the upload for the NEXT ms_prove of it, into a second set of device buffers, behind its own; that
+ * upload travels over PCIe while the current proof is computed, and the next ms_prove starts with its inputs in HBM. The
+ * first proof after switching on still uploads by itself; the last prefetch is unused; on = 0 drops a pending one. (The
+ * host buffers are fixed for the life of the witness anyway, see ms_witness_create_host.) bench.py reports this mode as
+ * config.pipelined_ms_per_proof, never as the primary figure (whose every step starts with the witness in host memory). */
+int32_t ms_witness_prefetch(ms_witness* w, int32_t on);
 /* The bench workload's witness and claims generated in HBM for the system [ByteTable, U32Add]: build_witness +
  * build_claims of benches/multi_stark.rs:171-238 (two xorshift32 streams from a0, b0; the reference uses 0xdeadbeef,
  * 0xcafebabe) followed by from_stage_1 on the device. Nothing crosses PCIe. */

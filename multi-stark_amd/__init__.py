@@ -43,7 +43,7 @@ def exported_symbols():
     """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
-            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host",
+            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_witness_prefetch",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
             "ms_comm_rccl_table", "ms_comm_rccl_bytes_moved", "ms_comm_rccl_destroy", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_pcs_commit", "ms_pcs_open", "ms_pcs_verify", "ms_challenger_create",
@@ -386,6 +386,10 @@ class SystemWitness:
         if getattr(self, "h", None):
             lib().ms_witness_destroy(self.h)
             self.h = None
+
+    def prefetch(self, on=True):
+        """host-resident witness: every proof also uploads the inputs of the next one while it computes (ms_witness_prefetch)"""
+        _check(lib().ms_witness_prefetch(self.h, C.c_int32(1 if on else 0)))
 
     # ---- Level 2 (include/mstark.h): the prover's steps one by one, everything staying on the device
     def commit_stage1(self, heights, widths):

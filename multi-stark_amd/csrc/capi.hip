@@ -221,6 +221,19 @@ int32_t ms_witness_create_host(ms_system* sys, const uint64_t* const* traces, co
   return MS_OK;
   MS_CATCH
 }
+int32_t ms_witness_prefetch(ms_witness* w, int32_t on) {
+  MS_TRY HWitness& wit = *w->w;
+  if (!wit.host_resident) throw std::runtime_error("ms_witness_prefetch: only a host-resident witness is uploaded per proof");
+  Ctx& ctx = *wit.sys->ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  wit.prefetch = on != 0;
+  if (!wit.prefetch) {
+    HIP_CHECK(hipStreamSynchronize(ctx.copy_stream));
+    for (auto& st : wit.stage) st.clear();
+  }
+  return MS_OK;
+  MS_CATCH
+}
 int32_t ms_witness_u32_add_bench(ms_system* sys, size_t num_adds, uint32_t a0, uint32_t b0, ms_witness** out) {
   *out = nullptr;
   MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());

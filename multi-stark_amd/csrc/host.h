@@ -105,6 +105,25 @@ struct HWitness {
   std::vector<const u64*> h_traces;                 // the caller's row-major buffers (pinned by hipHostRegister)
   std::vector<std::vector<u64>> h_mult, h_args;     // only for circuits whose lookup prefix needs the host sweep
   std::vector<void*> registered;                    // ranges this witness pinned; unpinned by the destructor
+  // One upload of the witness: the device buffers and the events that mark their arrival. `next` is filled while a proof
+  // runs when prefetching is on (ms_witness_prefetch): the following proof then finds its inputs already in HBM.
+  struct Staged {
+    bool valid = false, has_host_lookups = false;
+    std::vector<DBuf<u64>> traces, mult, args;
+    DBuf<u64> claim_offsets, claim_data;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // traces, host lookup values, claims
+    void clear() {
+      valid = false;
+      traces.clear();
+      mult.clear();
+      args.clear();
+      claim_offsets.reset();
+      claim_data.reset();
+    }
+  };
+  Staged stage[2];
+  int cur = 0;             // stage[cur] feeds the running proof, stage[cur ^ 1] is the prefetched one
+  bool prefetch = false;
   bool pinned = true;                               // every uploaded range is page-locked
   void pin(const void* p, size_t bytes);
   HWitness() {}

@@ -490,11 +490,14 @@ void HWitness::pin(const void* p, size_t bytes) {
   }
 }
 HWitness::~HWitness() {
-  if (registered.empty()) return;
+  if (!host_resident) return;
   if (sys && sys->ctx) {
     (void)hipSetDevice(sys->ctx->device);
-    (void)hipStreamSynchronize(sys->ctx->copy_stream);
+    (void)hipStreamSynchronize(sys->ctx->copy_stream);  // a prefetch may still be writing into the staged buffers
   }
+  for (auto& st : stage)
+    for (auto& e : st.ev)
+      if (e) (void)hipEventDestroy(e);
   for (void* p : registered) (void)hipHostUnregister(p);
 }
 
@@ -561,17 +564,22 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
 namespace {
 // Per-proof upload of a host-resident witness. Everything is queued on the copy stream in the order the proof needs it
 // (traces, then claims); the kernels of ctx.stream wait on events, so the claims travel while stage 1 is computed.
-// The device buffers live in the witness for the duration of the proof only.
+// The device buffers live in the witness for the duration of the proof only. With prefetching on, the upload for the
+// FOLLOWING proof is queued right behind this one's, into a second set of buffers, and travels while this proof is computed.
 struct HostUpload {
   HWitness& w;
   Ctx& ctx;
   bool on = false;
   HostUpload(HWitness& wit, Ctx& c) : w(wit), ctx(c) {}
-  void start() {
-    if (!w.host_resident) return;
-    on = true;
+  void issue(HWitness::Staged& st) {
     HSystem& sys = *w.sys;
     const size_t C = sys.circuits.size();
+    for (auto& e : st.ev)
+      if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    st.clear();
+    st.traces.resize(C);
+    st.mult.resize(C);
+    st.args.resize(C);
     // buffers first: pool blocks handed out here may still be in use by kernels queued earlier on ctx.stream
     HIP_CHECK(hipEventRecord(ctx.copy_ev[3], ctx.stream));
     HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[3], 0));
@@ -579,43 +587,60 @@ struct HostUpload {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
       if (!h) continue;
-      w.traces[ci] = DBuf<u64>(ctx, h * c.main_width);
-      HIP_CHECK(hipMemcpyAsync(w.traces[ci].p, w.h_traces[ci], h * c.main_width * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+      st.traces[ci] = DBuf<u64>(ctx, h * c.main_width);
+      HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], h * c.main_width * 8, hipMemcpyHostToDevice, ctx.copy_stream));
     }
-    HIP_CHECK(hipEventRecord(ctx.copy_ev[0], ctx.copy_stream));
-    bool host_lookups = false;
+    HIP_CHECK(hipEventRecord(st.ev[0], ctx.copy_stream));
+    st.has_host_lookups = false;
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
       if (!h || !c.num_lookups) continue;
-      DLookups& lk = w.lookups[ci];
-      lk.mult = DBuf<u64>(ctx, h * c.num_lookups);
-      lk.args = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
+      st.mult[ci] = DBuf<u64>(ctx, h * c.num_lookups);
+      st.args[ci] = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
       if (!w.h_mult[ci].empty()) {
-        host_lookups = true;
-        HIP_CHECK(hipMemcpyAsync(lk.mult.p, w.h_mult[ci].data(), w.h_mult[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+        st.has_host_lookups = true;
+        HIP_CHECK(hipMemcpyAsync(st.mult[ci].p, w.h_mult[ci].data(), w.h_mult[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
         if (!w.h_args[ci].empty())
-          HIP_CHECK(hipMemcpyAsync(lk.args.p, w.h_args[ci].data(), w.h_args[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+          HIP_CHECK(hipMemcpyAsync(st.args[ci].p, w.h_args[ci].data(), w.h_args[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
       }
     }
-    if (host_lookups) HIP_CHECK(hipEventRecord(ctx.copy_ev[1], ctx.copy_stream));
-    has_host_lookups = host_lookups;
+    if (st.has_host_lookups) HIP_CHECK(hipEventRecord(st.ev[1], ctx.copy_stream));
     const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
-    w.d_claim_offsets = DBuf<u64>(ctx, n_claims + 1);
-    w.d_claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
-    HIP_CHECK(hipMemcpyAsync(w.d_claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
-    if (tot) HIP_CHECK(hipMemcpyAsync(w.d_claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
-    HIP_CHECK(hipEventRecord(ctx.copy_ev[2], ctx.copy_stream));
+    st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
+    st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
+    HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    HIP_CHECK(hipEventRecord(st.ev[2], ctx.copy_stream));
+    st.valid = true;
   }
-  bool has_host_lookups = false;
+  void start() {
+    if (!w.host_resident) return;
+    on = true;
+    if (w.prefetch && w.stage[w.cur ^ 1].valid)
+      w.cur ^= 1;  // the previous proof has already brought this one's inputs over
+    else
+      issue(w.stage[w.cur]);
+    HWitness::Staged& st = w.stage[w.cur];
+    // the proof reads through the witness's usual members
+    for (size_t ci = 0; ci < st.traces.size(); ci++) {
+      w.traces[ci] = std::move(st.traces[ci]);
+      w.lookups[ci].mult = std::move(st.mult[ci]);
+      w.lookups[ci].args = std::move(st.args[ci]);
+    }
+    w.d_claim_offsets = std::move(st.claim_offsets);
+    w.d_claim_data = std::move(st.claim_data);
+    st.valid = false;
+    if (w.prefetch) issue(w.stage[w.cur ^ 1]);
+  }
   void wait_traces() {
-    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.copy_ev[0], 0));
+    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[0], 0));
   }
   // SystemWitness::from_stage_1 (src/system.rs:244-328) as one kernel per circuit, from the traces just uploaded
   void lookup_values() {
     if (!on) return;
     HSystem& sys = *w.sys;
-    if (has_host_lookups) HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.copy_ev[1], 0));
+    if (w.stage[w.cur].has_host_lookups) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[1], 0));
     for (size_t ci = 0; ci < sys.circuits.size(); ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
@@ -627,11 +652,12 @@ struct HostUpload {
     }
   }
   void wait_claims() {
-    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.copy_ev[2], 0));
+    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[2], 0));
   }
   ~HostUpload() {
     if (!on) return;
-    // the copies may still be in flight when a proof is abandoned: wait before the blocks return to the pool
+    // this proof's copies may still be in flight when it is abandoned: wait before the blocks return to the pool (a
+    // prefetch queued behind them is then complete as well, which costs nothing: it is shorter than the proof)
     (void)hipStreamSynchronize(ctx.copy_stream);
     for (auto& t : w.traces) t.reset();
     for (auto& lk : w.lookups) {

@@ -196,6 +196,35 @@ def test_host_resident_witness(pkg, ctx, oracle, fe, case):
             g.host_witness(bad, packed)
 
 
+# ms_witness_prefetch: each proof of a host-resident witness also uploads the inputs of the next one; same bytes, also
+# across switching it on and off, interleaved with other witnesses, and after an injected mid-proof failure
+def test_host_witness_prefetch(pkg, ctx, oracle, fe):
+    traces, claims = fe.u32_add_bench_witness(1 << 12)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    want = oracle.System(g.blob).prove(traces, packed)
+    hw = g.host_witness(traces, packed)
+    dw = g.witness(traces, packed)
+    with pytest.raises(pkg.MstarkError):
+        dw.prefetch(True)
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    hw.prefetch(True)
+    for _ in range(4):
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+    assert g.prove_multiple_claims(dw).to_bytes() == want
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    ctx.debug_fail_alloc(25)
+    with pytest.raises(pkg.MstarkError, match="injected"):
+        g.prove_multiple_claims(hw)
+    ctx.debug_fail_alloc(0)
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    hw.prefetch(False)
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    hw.prefetch(True)
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    del hw   # a prefetch is pending: the destructor waits for it
+
+
 # BASELINE config 5: 2^26 additions (228 GiB of the 288 GiB HBM; about a minute with witness generation and the oracle
 # verifier). Runs by default; MSAMD_SKIP_STRESS=1 leaves it out on a box that is short of memory. The recorded runs are
 # profiles/r01_config5_stress.txt and profiles/r02_config5.txt (tools/stress.py is the same flow as a script).
