@@ -505,21 +505,27 @@ class System:
         height = max(1, 1 << (num_adds - 1).bit_length())
         return SystemWitness(h, 256 + height, self)
 
-    def prove_multiple_claims(self, witness, want_times=False):
+    def _out_buffer(self):
+        # one output buffer per system, reused: a fresh 2 MB array per proof costs an mmap and a page fault per 4 KB touched
         cap = getattr(self, "_proof_cap", 1 << 21)
+        buf = getattr(self, "_proof_buf", None)
+        if buf is None or buf.size != cap:
+            buf = self._proof_buf = np.zeros(cap, dtype=np.uint8)
+        return buf, cap
+
+    def prove_multiple_claims(self, witness, want_times=False):
         times = np.zeros(6, dtype=np.float64)
         while True:
-            out = np.empty(cap, dtype=np.uint8)
+            out, cap = self._out_buffer()
             n = C.c_size_t()
             rc = lib().ms_prove(self.h, witness.h, _b(out), C.c_size_t(cap), C.byref(n),
                                 times.ctypes.data_as(C.POINTER(C.c_double)) if want_times else None)
             if rc == -3:
-                cap = n.value
-                self._proof_cap = cap
+                self._proof_cap = n.value
                 continue
             _check(rc)
             keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]
-            return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
+            return Proof(C.string_at(out.ctypes.data, n.value), dict(zip(keys, times.tolist())) if want_times else None)
 
     prove = prove_multiple_claims
 
@@ -539,24 +545,22 @@ class System:
     def prove_sharded(self, witness, comm, owners, want_times=False):
         """The same Proof computed by `comm.world` ranks (ms_prove_sharded; see multi-stark_amd/sharded.py for `comm`).
         owners[i] = rank computing circuit i, -1 = replicated. Collective: every rank calls it; every rank gets the bytes."""
-        cap = getattr(self, "_proof_cap", 1 << 21)
         times = np.zeros(6, dtype=np.float64)
         own = np.ascontiguousarray(owners, dtype=np.int32)
         if own.size != self.n_circuits:
             raise MstarkError("expected one owner per circuit")
         while True:
-            out = np.empty(cap, dtype=np.uint8)
+            out, cap = self._out_buffer()
             n = C.c_size_t()
             rc = lib().ms_prove_sharded(self.h, witness.h, C.byref(comm.struct), own.ctypes.data_as(C.POINTER(C.c_int32)), _b(out),
                                         C.c_size_t(cap), C.byref(n), times.ctypes.data_as(C.POINTER(C.c_double)) if want_times else None)
             comm.reraise()
             if rc == -3:
-                cap = n.value
-                self._proof_cap = cap
+                self._proof_cap = n.value
                 continue
             _check(rc)
             keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]
-            return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
+            return Proof(C.string_at(out.ctypes.data, n.value), dict(zip(keys, times.tolist())) if want_times else None)
 
     def preprocessed_mmcs(self, heights_widths):
         """the ProverKey's preprocessed prover data as a commitment handle (None without preprocessed traces);

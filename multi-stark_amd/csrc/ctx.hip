@@ -351,7 +351,8 @@ void Ctx::sync_and_deliver() {
       if (!d.copied) HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + d.off, d.src, d.n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
   }
-  for (auto& d : down_pending) memcpy(d.dst, pinned + pinned_half + d.off, d.n);
+  for (auto& d : down_pending)
+    if (d.dst) memcpy(d.dst, pinned + pinned_half + d.off, d.n);
   down_pending.clear();
   down_direct = false;
   down_used = 0;
@@ -396,6 +397,27 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   down_pending.push_back(pd);
   down_used += need;
   tl_pending_ctx = this;
+}
+
+const uint8_t* Ctx::d2h_queue_staged(const void* src, size_t n) {
+  const size_t need = (n + 63) & ~size_t(63);
+  if (!pinned || n == 0 || down_used + need > pinned_half) return nullptr;
+  PendingD2H pd;
+  pd.dst = nullptr;  // nothing to deliver: the caller reads the staging buffer
+  pd.src = src;
+  pd.off = down_used;
+  pd.n = n;
+  pd.copied = false;
+  if (!flag_host || n > (size_t(64) << 10)) {
+    HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
+    pd.copied = true;
+    down_direct = true;
+  }
+  down_pending.push_back(pd);
+  const uint8_t* at = pinned + pinned_half + down_used;
+  down_used += need;
+  tl_pending_ctx = this;
+  return at;
 }
 
 void Ctx::d2h(void* dst, const void* src, size_t n) {

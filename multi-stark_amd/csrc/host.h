@@ -64,6 +64,7 @@ struct HCircuit {
   DProgram prog;
   DProgram prefix_prog;           // lookup-expression prefix only (SystemWitness::from_stage_1)
   JitKernel stage2_jit;           // stage-2 terms kernel specialised to this circuit's lookups (quotient_jit.hip)
+  JitKernel stage2_trace_jit;     // the same fed by the trace: lookup expressions evaluated in the kernel (host-resident witnesses)
   bool prefix_on_device = false;
   size_t quotient_degree() const {
     size_t d = (max_constraint_degree > 2 ? max_constraint_degree : 2) - 1, q = 1;

@@ -261,6 +261,31 @@ void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* ou
   HIP_CHECK(hipGetLastError());
 }
 
+void stage2_from_trace_async(Ctx& ctx, const JitKernel& trace_jit, const u64* d_trace, const u64* d_pre, size_t n, size_t num_lookups,
+                             size_t args_width, E2 beta, E2 gamma, u64* out, E2* total_dev) {
+  if (!trace_jit.function || num_lookups == 0) throw std::runtime_error("stage2_from_trace: no fused kernel for this circuit");
+  const unsigned logn = log2_strict(n);
+  const u32 L = (u32)num_lookups;
+  DBuf<E2> rowsum(ctx, n), prefix(ctx, n), terms(ctx, n * L);
+  dim3 grid((unsigned)((n + 255) / 256));
+  Stage2TraceParams sp;
+  sp.trace = d_trace;
+  sp.pre = d_pre;
+  sp.n = n;
+  sp.beta = beta;
+  sp.gp = gamma_pows(gamma, MAX_GPOW);
+  sp.terms = terms.p;
+  sp.rowsum = rowsum.p;
+  hipEvent_t ev = ctx.prof_begin(K_STAGE2);
+  stage2_trace_jit_launch(ctx, trace_jit, sp);
+  ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + args_width));
+  scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev);
+  ev = ctx.prof_begin(K_STAGE2);
+  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out);
+  ctx.prof_end(K_STAGE2, ev, double(n) * 16.0 * L);
+  HIP_CHECK(hipGetLastError());
+}
+
 E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, const JitKernel* jit) {
   DBuf<E2> tot(ctx, 1);
   stage2_build_async(ctx, lk, beta, gamma, out, tot.p, jit);

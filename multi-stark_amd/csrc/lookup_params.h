@@ -22,4 +22,17 @@ struct Stage2Params {
   E2* rowsum;        // n
 };
 
+// the same pass fed by the TRACE: the circuit's lookup expressions (the prefix of its node program) are evaluated in the
+// kernel, so that no LookupValues are materialised (host-resident witnesses: src/system.rs:244-328 fused into
+// src/lookup.rs:472-543)
+struct Stage2TraceParams {
+  const u64* trace;  // n x main_w row-major, as uploaded
+  const u64* pre;    // n x pre_w row-major (or null)
+  size_t n;
+  E2 beta;
+  GammaPows gp;
+  E2* terms;
+  E2* rowsum;
+};
+
 }  // namespace msamd

@@ -116,6 +116,10 @@ struct Ctx {
   void h2d(void* dst, const void* src, size_t n);
   void d2h(void* dst, const void* src, size_t n);        // synchronous (waits for the stream)
   void d2h_queue(void* dst, const void* src, size_t n);  // delivered to dst by the next d2h / sync_and_deliver
+  // the same without the final host copy: the bytes can be read at the returned address of the pinned staging buffer after
+  // the next synchronisation and until the next read-back is queued (nullptr: does not fit, use d2h_queue)
+  const uint8_t* d2h_queue_staged(const void* src, size_t n);
+  std::vector<uint8_t> host_scratch;  // grows once; large per-proof host buffers that would otherwise be page-faulted in anew
   const u64* lde_scale(unsigned log_n, unsigned log_blowup);
   // profiling hooks around one launch
   bool prof_on(int id) const { return (prof_mask >> id) & 1u; }
@@ -246,6 +250,9 @@ E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmaj
 // launches only: the contribution is left in *total_dev (device memory)
 void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev,
                         const JitKernel* jit = nullptr);
+// the same from the row-major trace (and preprocessed trace) with the circuit's fused kernel: no LookupValues needed
+void stage2_from_trace_async(Ctx& ctx, const JitKernel& trace_jit, const u64* d_trace, const u64* d_pre, size_t n, size_t num_lookups,
+                             size_t args_width, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev);
 void claims_accumulator_async(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma,
                               E2* out_dev);
 E2 claims_accumulator(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, E2 beta, E2 gamma);

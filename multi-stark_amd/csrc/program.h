@@ -26,11 +26,16 @@ void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint3
 void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq);
 // the circuit's stage-2 terms kernel (messages, batch inverse, mult / message) for its list of argument counts
 struct Stage2Params;
+struct Stage2TraceParams;
 void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out);
 void stage2_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2Params& p);
+// the terms pass fed by the trace (lookup expressions evaluated in the kernel); empty `out` = not available for this circuit
+void stage2_trace_jit_build(const std::vector<PNode>& nodes, const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups,
+                            size_t main_w, size_t pre_w, size_t prefix_len, JitKernel& out);
+void stage2_trace_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2TraceParams& p);
 
 // lookup values of SystemWitness::from_stage_1 on the device; false = prefix too large for the LDS slot file
 bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, const u64* d_pre, size_t h, size_t main_w,
-                          size_t pre_w, size_t args_w, u64* d_mult, u64* d_args);
+                          size_t pre_w, size_t args_w, u64* d_mult, u64* d_args, hipStream_t on_stream = nullptr);
 
 }  // namespace msamd

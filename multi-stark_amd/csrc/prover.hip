@@ -263,6 +263,7 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
       std::vector<uint32_t> counts;
       for (auto& l : c.lookups) counts.push_back((uint32_t)l.second.size());
       stage2_jit_build(counts, c.stage2_jit);
+      stage2_trace_jit_build(c.nodes, c.lookups, c.main_width, c.pre_width, c.lookup_prefix_len, c.stage2_trace_jit);
     }
     {
       // the lookup prefix may only read trace columns and row selectors (src/graph.rs: Stage2InBaseContext; publics
@@ -571,6 +572,11 @@ struct HostUpload {
   Ctx& ctx;
   bool on = false;
   HostUpload(HWitness& wit, Ctx& c) : w(wit), ctx(c) {}
+  // does stage 2 of this circuit run from the uploaded trace (stage2_terms_trace_jit)?
+  bool fused(size_t ci) const {
+    const HCircuit& c = w.sys->circuits[ci];
+    return w.host_resident && c.stage2_trace_jit.function && w.h_mult[ci].empty();
+  }
   void issue(HWitness::Staged& st) {
     HSystem& sys = *w.sys;
     const size_t C = sys.circuits.size();
@@ -596,6 +602,7 @@ struct HostUpload {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
       if (!h || !c.num_lookups) continue;
+      if (fused(ci)) continue;  // stage 2 reads the trace itself: no LookupValues for this circuit
       st.mult[ci] = DBuf<u64>(ctx, h * c.num_lookups);
       st.args[ci] = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
       if (!w.h_mult[ci].empty()) {
@@ -605,13 +612,24 @@ struct HostUpload {
           HIP_CHECK(hipMemcpyAsync(st.args[ci].p, w.h_args[ci].data(), w.h_args[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
       }
     }
-    if (st.has_host_lookups) HIP_CHECK(hipEventRecord(st.ev[1], ctx.copy_stream));
     const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
     st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
     st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
     HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
     if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
     HIP_CHECK(hipEventRecord(st.ev[2], ctx.copy_stream));
+    // SystemWitness::from_stage_1 (src/system.rs:244-328) as one kernel per circuit, from the traces just uploaded, queued on
+    // the copy stream behind the copies: it writes 344 MB at config 2 and runs beside the transforms of stage 1 (which are
+    // bound by the vector ALU) instead of in front of stage 2
+    for (size_t ci = 0; ci < C; ci++) {
+      const HCircuit& c = sys.circuits[ci];
+      const size_t h = w.heights[ci];
+      if (!h || !c.num_lookups || !w.h_mult[ci].empty() || fused(ci)) continue;
+      if (!lookup_values_device(ctx, c.prefix_prog, st.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h, c.main_width, c.pre_width,
+                                c.args_width, st.mult[ci].p, st.args[ci].p, ctx.copy_stream))
+        throw std::runtime_error("host-resident witness: lookup prefix does not fit the device sweep");
+    }
+    HIP_CHECK(hipEventRecord(st.ev[1], ctx.copy_stream));
     st.valid = true;
   }
   void start() {
@@ -636,20 +654,9 @@ struct HostUpload {
   void wait_traces() {
     if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[0], 0));
   }
-  // SystemWitness::from_stage_1 (src/system.rs:244-328) as one kernel per circuit, from the traces just uploaded
+  // the lookup values (uploaded, or computed on the copy stream from the uploaded traces) are complete
   void lookup_values() {
-    if (!on) return;
-    HSystem& sys = *w.sys;
-    if (w.stage[w.cur].has_host_lookups) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[1], 0));
-    for (size_t ci = 0; ci < sys.circuits.size(); ci++) {
-      const HCircuit& c = sys.circuits[ci];
-      const size_t h = w.heights[ci];
-      if (!h || !c.num_lookups || !w.h_mult[ci].empty()) continue;
-      DLookups& lk = w.lookups[ci];
-      if (!lookup_values_device(ctx, c.prefix_prog, w.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h, c.main_width, c.pre_width,
-                                c.args_width, lk.mult.p, lk.args.p))
-        throw std::runtime_error("host-resident witness: lookup prefix does not fit the device sweep");
-    }
+    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[1], 0));
   }
   void wait_claims() {
     if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[2], 0));
@@ -1128,7 +1135,10 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   }
   const size_t qbytes = out_off;
   const size_t nq = (size_t)prm.num_queries;
-  std::vector<uint8_t> g(qbytes * nq);
+  // the gathered openings (about 1 MB at the bench parameters) are read where the read-back lands - the pinned staging
+  // buffer - when they fit there; otherwise, and for the host-driven gathers, in a scratch vector that is allocated once
+  std::vector<uint8_t>& g_vec = ctx.host_scratch;
+  const uint8_t* g = nullptr;
   std::vector<u64> dq(1 + nq);  // device query step: [0] = PoW witness, [1..] = indices
   if (dev_rounds) {
     DBuf<u64> d_q;
@@ -1137,11 +1147,17 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     if (dev_query) {
       d_q = DBuf<u64>(ctx, 1 + nq);
       fri_query_challenge(ctx, d_state.p, fin_src, (unsigned)prm.query_pow_bits, (uint32_t)nq, log_max_height, d_q.p);
-      d_g = DBuf<uint8_t>(ctx, std::max<size_t>(g.size(), 1));
+      d_g = DBuf<uint8_t>(ctx, std::max<size_t>(qbytes * nq, 1));
       d_segs = DBuf<GatherSeg>(ctx, std::max<size_t>(segs.size(), 1));
       gather_queries_launch(ctx, segs, d_segs.p, d_q.p + 1, nq, qbytes, d_g.p);
       ctx.d2h_queue(dq.data(), d_q.p, dq.size() * 8);
-      ctx.d2h_queue(g.data(), d_g.p, g.size());
+      // (not when the input openings are fetched from other ranks afterwards: those read-backs reuse the staging buffer)
+      g = remote ? nullptr : ctx.d2h_queue_staged(d_g.p, qbytes * nq);
+      if (!g) {
+        if (g_vec.size() < qbytes * nq) g_vec.resize(qbytes * nq);
+        ctx.d2h_queue(g_vec.data(), d_g.p, qbytes * nq);
+        g = g_vec.data();
+      }
     }
     std::vector<FriTailRound> recs(n_total);
     fin.resize(stop);
@@ -1205,7 +1221,9 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     query_pow = grind(ctx, ch, (unsigned)prm.query_pow_bits);
     for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
     tr.mark("final_poly+grind");
-    gather_queries(ctx, segs, indices, qbytes, g.data());
+    if (g_vec.size() < qbytes * nq) g_vec.resize(qbytes * nq);
+    gather_queries(ctx, segs, indices, qbytes, g_vec.data());
+    g = g_vec.data();
     tr.mark("query_gather");
   }
 
@@ -1219,6 +1237,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
 
   // ---- FriProof bytes
   PW& w = fri_bytes;
+  w.b.reserve(w.b.size() + nq * (qbytes + input_qbytes + 64 * (trees.size() + shape.widths.size() * 4 + 8)) + 4096);
   w.u64_(commits.size());
   for (auto& c : commits) w.cap(c);
   w.u64_(pow_w.size());
@@ -1343,7 +1362,6 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
   }
-  up.lookup_values();
   up.wait_claims();
   // claims, length-prefixed (src/prover.rs:369-373). Large claim sets are hashed on the device: the transcript
   // since the last sample is `ch.input || words`, and the next operation is a sample, so the digest is all
@@ -1408,13 +1426,18 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   // ---- lookup construction (src/prover.rs:391-409) + stage 2 commit (:413-421)
   t0 = now_ms();
   phase.next("stark/lookup_construction");
+  up.lookup_values();
   std::vector<DBuf<u64>> s2_evals(NA);
   for (size_t pos = 0; pos < NA; pos++) {
     size_t ci = aidx[pos];
     const HCircuit& c = sys.circuits[ci];
     size_t n = wit.heights[ci];
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
-    stage2_build_async(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos, &c.stage2_jit);
+    if (up.fused(ci))
+      stage2_from_trace_async(ctx, c.stage2_trace_jit, wit.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, n, c.num_lookups,
+                              c.args_width, beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
+    else
+      stage2_build_async(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos, &c.stage2_jit);
   }
   lap(1);
   t0 = now_ms();
@@ -1532,6 +1555,13 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
   // ---- Proof bytes, field order of src/prover.rs:213-238
   PW w;
+  {
+    size_t vals = 0;
+    for (auto& r : opened)
+      for (auto& m : r)
+        for (auto& pt : m) vals += pt.size() + 2;
+    w.b.reserve(fri.b.size() + 16 * vals + 64 * (NA + 8) + 32 * (s1_cap.size() + s2_cap.size() + q_cap.size()) + 4096);
+  }
   w.u64_(C);
   for (auto a : active) w.u8(a);
   w.cap(s1_cap);

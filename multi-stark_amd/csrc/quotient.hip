@@ -317,7 +317,7 @@ void build_program(Ctx& ctx, const std::vector<PNode>& nodes, const std::vector<
 
 
 bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, const u64* d_pre, size_t h, size_t main_w,
-                          size_t pre_w, size_t args_w, u64* d_mult, u64* d_args) {
+                          size_t pre_w, size_t args_w, u64* d_mult, u64* d_args, hipStream_t on_stream) {
   unsigned threads = 256;
   while (threads > 64 && prefix.n_slots * threads * 8 > 64 * 1024) threads >>= 1;
   if (prefix.n_slots * threads * 8 > 64 * 1024) return false;  // very large prefix: the caller sweeps on the host
@@ -337,7 +337,7 @@ bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, 
   p.mult = d_mult;
   p.args = d_args;
   hipLaunchKernelGGL(lookup_values_k, dim3((unsigned)((h + threads - 1) / threads)), dim3(threads), prefix.n_slots * threads * 8,
-                     ctx.stream, p);
+                     on_stream ? on_stream : ctx.stream, p);
   HIP_CHECK(hipGetLastError());
   return true;
 }

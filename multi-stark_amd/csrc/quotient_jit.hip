@@ -365,6 +365,95 @@ std::string stage2_source(const std::vector<uint32_t>& counts) {
   o << "  p.rowsum[r] = s;\n}\n";
   return o.str();
 }
+// The terms pass with the lookup expressions evaluated in the kernel from the row-major trace (this row and the next one,
+// wrapping): the lookup prefix of the node program as straight-line code, then the same fingerprints and batch inversion.
+std::string stage2_trace_source(const std::vector<PNode>& nodes, const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups,
+                                size_t main_w, size_t pre_w) {
+  const size_t nn = nodes.size(), L = lookups.size();
+  std::vector<char> needed(nn, 0);
+  for (auto& l : lookups) {
+    needed[l.first] = 1;
+    for (auto a : l.second) needed[a] = 1;
+  }
+  for (size_t i = nn; i-- > 0;) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    if (n.kind == OP_ADD || n.kind == OP_SUB || n.kind == OP_MUL) needed[n.a] = needed[n.b] = 1;
+    if (n.kind == OP_NEG) needed[n.a] = 1;
+  }
+  // which columns of which row are read: [source 0 = preprocessed, 1 = main][offset][column]
+  std::vector<char> used[2][2];
+  for (int s2 = 0; s2 < 2; s2++)
+    for (int of = 0; of < 2; of++) used[s2][of].assign(s2 ? main_w : pre_w, 0);
+  for (size_t i = 0; i < nn; i++)
+    if (needed[i] && nodes[i].kind == OP_VAR) used[nodes[i].source][nodes[i].offset][nodes[i].a] = 1;
+  std::ostringstream o;
+  o << "#include \"lookup_params.h\"\nusing namespace msamd;\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void stage2_terms_trace_jit(Stage2TraceParams p) {\n"
+       "  const size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;\n"
+       "  if (r >= p.n) return;\n"
+       "  const size_t rn = r + 1 == p.n ? 0 : r + 1;\n"
+       "  const u64 is_first = r == 0, is_last = r + 1 == p.n, is_trans = r + 1 != p.n;\n"
+       "  (void)is_first; (void)is_last; (void)is_trans; (void)rn;\n";
+  for (int s2 = 0; s2 < 2; s2++)
+    for (int of = 0; of < 2; of++) {
+      const size_t W = s2 ? main_w : pre_w;
+      const char* base = s2 ? "p.trace" : "p.pre";
+      const std::string nm = std::string(s2 ? "m" : "q") + (of ? "n" : "c");  // mc / mn / qc / qn + column
+      bool any = false;
+      for (char u : used[s2][of]) any = any || u;
+      if (!any) continue;
+      o << "  const u64* __restrict__ " << nm << " = " << base << " + " << (of ? "rn" : "r") << " * " << W << ";\n";
+      if (W % 2 == 0) {  // rows are 16-byte aligned: fetch pairs with one load
+        for (size_t k = 0; k < W; k += 2)
+          if (used[s2][of][k] || used[s2][of][k + 1])
+            o << "  const ulonglong2 " << nm << "p" << k << " = reinterpret_cast<const ulonglong2*>(" << nm << ")[" << k / 2 << "]; const u64 "
+              << nm << k << " = " << nm << "p" << k << ".x, " << nm << k + 1 << " = " << nm << "p" << k << ".y; (void)" << nm << k << "; (void)"
+              << nm << k + 1 << ";\n";
+      } else {
+        for (size_t k = 0; k < W; k++)
+          if (used[s2][of][k]) o << "  const u64 " << nm << k << " = " << nm << "[" << k << "];\n";
+      }
+    }
+  for (size_t i = 0; i < nn; i++) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    o << "  const u64 v" << i << " = ";
+    switch (n.kind) {
+      case OP_CONST: o << n.a << "ULL"; break;
+      case OP_VAR: o << (n.source ? "m" : "q") << (n.offset ? "n" : "c") << n.a; break;
+      case OP_IS_FIRST: o << "is_first"; break;
+      case OP_IS_LAST: o << "is_last"; break;
+      case OP_IS_TRANS: o << "is_trans"; break;
+      case OP_ADD: o << "gl_add(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_SUB: o << "gl_sub(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_MUL: o << "gl_mul(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_NEG: o << "gl_neg(v" << n.a << ")"; break;
+      default: o << "0ULL"; break;  // publics / stage-2 columns cannot occur here (checked by the caller)
+    }
+    o << ";\n";
+  }
+  o << "  E2 s = e2(0);\n  E2* __restrict__ trow = p.terms + r * " << L << ";\n";
+  for (size_t j0 = 0; j0 < L; j0 += 16) {
+    const size_t cnt = std::min<size_t>(16, L - j0);
+    o << "  {\n    E2 msg[16];\n";
+    for (size_t t = 0; t < cnt; t++) {
+      const auto& l = lookups[j0 + t];
+      o << "    { GlAcc g0, g1; acc_init(g0); acc_init(g1);\n";
+      for (size_t k = 0; k < l.second.size(); k++)
+        o << "      acc_mad(g0, v" << l.second[k] << ", p.gp.g[" << k << "].c0); acc_mad(g1, v" << l.second[k] << ", p.gp.g[" << k << "].c1);\n";
+      o << "      msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.beta.c0), gl_add(acc_reduce(g1), p.beta.c1)); }\n";
+    }
+    o << "    e2_batch_inverse<16>(msg, " << cnt << ");\n";
+    for (size_t t = 0; t < cnt; t++) {
+      const size_t j = j0 + t;
+      o << "    { const E2 v = e2_mul_base(msg[" << t << "], v" << lookups[j].first << "); trow[" << j << "] = v; s = e2_add(s, v); }\n";
+    }
+    o << "  }\n";
+  }
+  o << "  p.rowsum[r] = s;\n}\n";
+  return o.str();
+}
 }  // namespace
 
 // Compiles (or fetches) the circuit's kernel; leaves `out` empty when the interpreter should be used.
@@ -386,6 +475,27 @@ void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out) {
   }
   if (aw > 1024) return;
   load_kernel(code_object(stage2_source(arg_counts)), "stage2_terms_jit", out);
+}
+
+void stage2_trace_jit_build(const std::vector<PNode>& nodes, const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups,
+                            size_t main_w, size_t pre_w, size_t prefix_len, JitKernel& out) {
+  if (getenv("MSAMD_NO_JIT") || getenv("MSAMD_NO_STAGE2_FUSION") || lookups.empty() || lookups.size() > 256 || prefix_len > 3000) return;
+  size_t aw = 0;
+  for (auto& l : lookups) {
+    if (l.second.size() > (size_t)MAX_GPOW) return;
+    aw += l.second.size();
+  }
+  if (aw > 1024) return;
+  for (size_t i = 0; i < prefix_len; i++)  // only trace columns and row selectors may feed a lookup at witness time
+    if (nodes[i].kind == OP_PUBLIC || (nodes[i].kind == OP_VAR && nodes[i].source == 2)) return;
+  load_kernel(code_object(stage2_trace_source(nodes, lookups, main_w, pre_w)), "stage2_terms_trace_jit", out);
+}
+
+void stage2_trace_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2TraceParams& p) {
+  Stage2TraceParams copy = p;
+  size_t size = sizeof(Stage2TraceParams);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((p.n + 255) / 256), 1, 1, 256, 1, 1, 0, ctx.stream, nullptr, config));
 }
 
 void stage2_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2Params& p) {

@@ -154,13 +154,13 @@ def test_full_size_proof_equals_oracle(pkg, ctx, oracle, fe):
 
 # ms_witness_create_host: the witness stays in host memory and every proof uploads it (traces, claims) and runs
 # from_stage_1 on the device; same bytes as the device-resident witness and as the oracle, on every kind of system
-@pytest.mark.parametrize("case", ["bench6", "bench12", "byte_ops", "even_odd_dead", "squares", "pythagorean", "host_sweep"])
+@pytest.mark.parametrize("case", ["bench6", "bench12", "bench12_nofusion", "byte_ops", "even_odd_dead", "squares", "pythagorean", "host_sweep"])
 def test_host_resident_witness(pkg, ctx, oracle, fe, case):
     import os
 
     params = fe.test_params()
     if case.startswith("bench") or case == "host_sweep":
-        traces, claims = fe.u32_add_bench_witness(1 << (12 if case == "bench12" else 6))
+        traces, claims = fe.u32_add_bench_witness(1 << (12 if case.startswith("bench12") else 6))
         inputs, params = fe.u32_add_system_inputs(), fe.bench_params()
     elif case == "byte_ops":
         traces, claims = fe.byte_operations_witness([(0, 10, 5), (1, 30, 20), (2, 100, 40), (3, 200, 100)])
@@ -172,7 +172,12 @@ def test_host_resident_witness(pkg, ctx, oracle, fe, case):
         traces, claims, inputs = fe.squares_traces(64), [], fe.squares_inputs()
     else:
         traces, claims, inputs = [fe.pythagorean_trace(64)], [], fe.pythagorean_inputs()
-    g = pkg.System.new(ctx, params, inputs)
+    if case == "bench12_nofusion":   # stage 2 from materialised lookup values (from_stage_1 as its own kernel) instead of the fused kernel
+        os.environ["MSAMD_NO_STAGE2_FUSION"] = "1"
+    try:
+        g = pkg.System.new(ctx, params, inputs)
+    finally:
+        os.environ.pop("MSAMD_NO_STAGE2_FUSION", None)
     packed = fe.pack_claims(claims)
     want = oracle.System(g.blob).prove(traces, packed)
     if case == "host_sweep":   # lookup values swept on the host at creation and uploaded with every proof
