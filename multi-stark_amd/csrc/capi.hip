@@ -664,7 +664,12 @@ int32_t ms_stage2_build(ms_witness* w, const uint64_t beta[2], const uint64_t ga
     ev.h = n;
     ev.w = c.stage2_width;
     ev.buf = DBuf<u64>(ctx, n * c.stage2_width);
-    const E2 tot = stage2_build(ctx, wit.lookups[ci], e2(beta[0], beta[1]), e2(gamma[0], gamma[1]), ev.d(), &c.stage2_jit);
+    E2 tot;
+    {
+      DBuf<E2> d_tot(ctx, 1);
+      stage2_circuit_async(ctx, sys, wit, ci, e2(beta[0], beta[1]), e2(gamma[0], gamma[1]), ev.d(), d_tot.p);
+      ctx.d2h(&tot, d_tot.p, sizeof(E2));
+    }
     acc = e2_add(acc, tot);
     accs_out[2 * pos] = acc.c0;
     accs_out[2 * pos + 1] = acc.c1;

@@ -122,7 +122,7 @@ Ctx::Ctx(int dev) : device(dev) {
     (void)hipGetLastError();
     pinned = nullptr;  // transfers fall back to pageable staging by the runtime
   }
-  if (pinned && !getenv("MSAMD_NO_FLAG_SYNC")) {
+  if (pinned) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, pinned, 0) == hipSuccess && dp) {
       pinned_dev = (uint8_t*)dp;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void flag_copy_k(FlagCopyArgs a) {
 
 void Ctx::sync_and_deliver() {
   bool done = false;
-  if (flag_host && !down_pending.empty() && down_pending.size() <= 12 && !down_direct) {
+  if (flag_host && !down_pending.empty() && down_pending.size() <= 12 && !down_direct && !getenv("MSAMD_NO_FLAG_SYNC")) {
     FlagCopyArgs a;
     memset(&a, 0, sizeof(a));
     size_t total = 0;

@@ -162,6 +162,11 @@ bool pcs_verify_standalone(const Params& prm, const std::vector<std::vector<Dige
                            const std::vector<E2>& opened_flat, const uint8_t* fri, size_t fri_len, Challenger& ch);
 
 void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, PcsData& out);
+// LookupValues::stage_2_traces of one circuit (src/lookup.rs:472-555): from the witness's lookup values, or - when the witness
+// holds none for this circuit - straight from its trace with the circuit's fused kernel. Launches only; the circuit's
+// total is left in *total_dev.
+void stage2_circuit_async(Ctx& ctx, const HSystem& sys, const HWitness& wit, size_t ci, E2 beta, E2 gamma, u64* out_colmajor_bitrev,
+                          E2* total_dev);
 // the claims part of the transcript (src/prover.rs:369-373) for a device-resident witness: long lists are hashed on the device
 void observe_claims(Ctx& ctx, Challenger& ch, HWitness& wit);
 void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out);

@@ -389,6 +389,7 @@ std::unique_ptr<HWitness> witness_from_device(HSystem& sys, std::vector<DBuf<u64
     for (auto& l : c.lookups) offs.push_back(offs.back() + (uint32_t)l.second.size());
     lk.arg_offsets = DBuf<uint32_t>(ctx, offs.size());
     ctx.h2d(lk.arg_offsets.p, offs.data(), offs.size() * 4);
+    if (c.stage2_trace_jit.function && !getenv("MSAMD_MATERIALISE_LOOKUPS")) continue;  // stage 2 reads the trace itself
     lk.mult = DBuf<u64>(ctx, h * c.num_lookups);
     lk.args = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
     if (!c.prefix_on_device || !lookup_values_device(ctx, c.prefix_prog, w->traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h,
@@ -441,6 +442,9 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
     for (auto& l : c.lookups) offs.push_back(offs.back() + (uint32_t)l.second.size());
     lk.arg_offsets = DBuf<uint32_t>(ctx, offs.size());
     ctx.h2d(lk.arg_offsets.p, offs.data(), offs.size() * 4);
+    // from_stage_1 requested and the circuit has a fused stage-2 kernel: the lookup values are never materialised (the
+    // kernel evaluates the lookup expressions from the trace; MSAMD_MATERIALISE_LOOKUPS=1 keeps the separate pass)
+    if (!(mult && mult[ci]) && c.stage2_trace_jit.function && !getenv("MSAMD_MATERIALISE_LOOKUPS") && !getenv("MSAMD_HOST_LOOKUP_VALUES")) continue;
     lk.mult = DBuf<u64>(ctx, h * c.num_lookups);
     lk.args = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
     if (mult && mult[ci]) {
@@ -1278,6 +1282,18 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
 }
 }  // namespace
 
+void stage2_circuit_async(Ctx& ctx, const HSystem& sys, const HWitness& wit, size_t ci, E2 beta, E2 gamma, u64* out, E2* total_dev) {
+  const HCircuit& c = sys.circuits[ci];
+  const DLookups& lk = wit.lookups[ci];
+  if (c.num_lookups && !lk.mult.p) {  // no LookupValues were materialised for this circuit: evaluate them in the kernel
+    if (!c.stage2_trace_jit.function || !wit.traces[ci].p) throw std::runtime_error("stage 2: this circuit has neither lookup values nor a fused kernel");
+    stage2_from_trace_async(ctx, c.stage2_trace_jit, wit.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, wit.heights[ci], c.num_lookups,
+                            c.args_width, beta, gamma, out, total_dev);
+    return;
+  }
+  stage2_build_async(ctx, lk, beta, gamma, out, total_dev, &c.stage2_jit);
+}
+
 // claims, length-prefixed (src/prover.rs:369-373), absorbed into `ch`. Large claim sets are hashed on the device: the
 // transcript since the last sample is `ch.input || words` and the next operation is a sample, so the digest is all the
 // challenger needs (prove() below does the same with the stage-1 commitment patched in on the device).
@@ -1433,11 +1449,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     const HCircuit& c = sys.circuits[ci];
     size_t n = wit.heights[ci];
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
-    if (up.fused(ci))
-      stage2_from_trace_async(ctx, c.stage2_trace_jit, wit.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, n, c.num_lookups,
-                              c.args_width, beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
-    else
-      stage2_build_async(ctx, wit.lookups[ci], beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos, &c.stage2_jit);
+    stage2_circuit_async(ctx, sys, wit, ci, beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
   }
   lap(1);
   t0 = now_ms();

@@ -365,7 +365,8 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
 # every alternative code path selectable by environment variable must give the same proof bytes: host-driven FRI rounds,
 # host-side query step, no single-workgroup FRI tail, host sweep for the lookup values, interpreter kernels instead of
 # the hiprtc-compiled ones (the library reads these variables at call time)
-@pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE"])
+@pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE",
+                                 "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC"])
 def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     import os
 
