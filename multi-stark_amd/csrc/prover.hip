@@ -1188,6 +1188,8 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
   }
   tr.mark("fri_commit_phase");
+  const bool host_trace = getenv("MSAMD_TRACE_HOST") != nullptr;
+  const double t_sync = host_trace ? now_ms() : 0;
   // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
   if (fin.size() != stop) throw std::runtime_error("FRI: unexpected final length");
   std::vector<E2> final_poly(final_len);
@@ -1279,6 +1281,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   w.u64_(final_poly.size());
   for (auto& e : final_poly) w.ext(e);
   w.u64_(query_pow);
+  if (host_trace) fprintf(stderr, "[msamd] host work after the FRI read-back: %.1f us (transcript replay + FriProof bytes)\n", 1e3 * (now_ms() - t_sync));
 }
 }  // namespace
 
@@ -1560,19 +1563,16 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     rounds.push_back(std::move(r0));
   }
-  std::vector<OpenedRound> opened;
-  PW fri;
-  pcs_open(sys, rounds, ch, opened, fri);
-  lap(4);
-
-  // ---- Proof bytes, field order of src/prover.rs:213-238
+  // ---- Proof bytes, field order of src/prover.rs:213-238: the fields in front of the opening proof are known by now,
+  // so the FriProof is serialised straight behind them (no second copy of its ~1 MB)
   PW w;
   {
     size_t vals = 0;
-    for (auto& r : opened)
-      for (auto& m : r)
-        for (auto& pt : m) vals += pt.size() + 2;
-    w.b.reserve(fri.b.size() + 16 * vals + 64 * (NA + 8) + 32 * (s1_cap.size() + s2_cap.size() + q_cap.size()) + 4096);
+    for (size_t pos = 0; pos < NA; pos++) {
+      const HCircuit& c = sys.circuits[aidx[pos]];
+      vals += 2 * (c.main_width + c.stage2_width + c.pre_width + 2) + 2 * c.quotient_degree() + 16;
+    }
+    w.b.reserve(16 * vals + 64 * (NA + 8) + 32 * (s1_cap.size() + s2_cap.size() + q_cap.size()) + 8192);
   }
   w.u64_(C);
   for (auto a : active) w.u8(a);
@@ -1583,7 +1583,9 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   for (auto& a : accs) w.ext(a);
   w.u64_(log_degrees.size());
   for (unsigned ld : log_degrees) w.u8((uint8_t)ld);
-  w.raw(fri.b.data(), fri.b.size());
+  std::vector<OpenedRound> opened;
+  pcs_open(sys, rounds, ch, opened, w);
+  lap(4);
   write_round(w, opened[2]);
   w.u8(sys.has_pre ? 1 : 0);
   if (sys.has_pre) write_round(w, opened[3]);
@@ -1591,6 +1593,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   write_round(w, opened[1]);
   ctx.prof_collect();
   if (times) times->v[5] = now_ms() - t_begin;
+  if (getenv("MSAMD_TRACE_HOST")) fprintf(stderr, "[msamd] prove(): %.1f us in all\n", 1e3 * (now_ms() - t_begin));
   return std::move(w.b);
 }
 
