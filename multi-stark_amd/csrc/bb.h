@@ -54,7 +54,15 @@ void bb_quotient_lde(Ctx& ctx, BMat& q_evals, unsigned log_n, unsigned log_q, un
 void bb_commit(Ctx& ctx, const Poseidon2* d_perm, std::vector<BMat>&& ldes, unsigned cap_height, BPcsData& out);
 void bb_permute_batch(Ctx& ctx, const Poseidon2* d_perm, u32* d_states, size_t n);
 // Merkle tree over a vector of E4 pairs (FRI layer: row i = (v[2i], v[2i+1]) flattened to 8 base columns)
-void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& out);
+struct DevChallenger;
+struct FriBeta;
+// with d_ch the launch that produces the root also runs the round's challenger step (observe the cap, sample beta -> *d_beta_out)
+void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& out,
+                     DevChallenger* d_ch = nullptr, FriBeta* d_beta_out = nullptr);
+// a whole commit-phase round in one launch (fold with the previous round's beta, leaf digests, tree, challenger step)
+bool bb_fri_round_fusable(size_t rows, unsigned cap_height);
+void bb_fri_round_fused(Ctx& ctx, const Poseidon2* d_perm, const E4* cur, size_t rows, const FriBeta* prev, const E4* roll_in, E4* out,
+                        BTree& t, DevChallenger* d_ch, FriBeta* d_beta_out);
 
 // ---- node programs (graph::Node, src/graph.rs:35-46) on the device
 struct BProgram {

@@ -470,9 +470,33 @@ static void hash_group(Ctx& ctx, const Poseidon2* d_perm, const std::vector<cons
   else
     leaf_hash_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(d_cols.p, (unsigned)cols.size(), rows, d_perm, out);
 }
-static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const std::vector<const BMat*>& order, size_t pos) {
+// every remaining level of t (whose last layer has `cur` <= 2^16 digests, no injection left) in one launch; with `chp` the
+// launch ends with the round's challenger step. Defined next to the kernel (subtree_k) further down.
+struct FriRoundCh {
+  DevChallenger* ch;
+  FriBeta* beta_out;
+};
+static void launch_subtree(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const FriRoundCh* chp);
+// A sixteen-lane Poseidon2 permutation is ~1.2 k dependent instructions (2 us on a SIMD of its own, 8 us when four waves
+// share it), so - unlike the BLAKE3 trees of the Goldilocks path - a level with more than 64 nodes is faster as its own
+// chip-wide launch than inside one workgroup (measured: a 2^16-child tree 86 us in one launch against ~70 us layer by layer).
+// The one-launch form therefore takes over only where a level fits one pass of the 64 groups; MSBB_SUBTREE_MAX_LOG moves it.
+static size_t subtree_max() {
+  const char* e = getenv("MSBB_SUBTREE_MAX_LOG");
+  return size_t(1) << (e ? atoi(e) : 7);
+}
+
+static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const std::vector<const BMat*>& order, size_t pos,
+                               const FriRoundCh* chp = nullptr) {
+  const bool fused_ok = !getenv("MSBB_NO_SUBTREE");
   while (t.sizes.back() > 1) {
     size_t cur = t.sizes.back(), nl = cur / 2;
+    if (fused_ok && pos == order.size() && cur <= subtree_max()) {
+      const bool with_ch = chp && t.cap_height == 0;  // a cap of several digests is observed by the separate step below
+      launch_subtree(ctx, d_perm, t, with_ch ? chp : nullptr);
+      if (with_ch) chp = nullptr;
+      break;
+    }
     if (pos == order.size() && cur <= 128) {  // nothing left to inject: the rest of the tree in one launch
       TailArgs a;
       a.n0 = (unsigned)cur;
@@ -505,6 +529,10 @@ static void build_upper_layers(Ctx& ctx, const Poseidon2* d_perm, BTree& t, cons
     t.sizes.push_back(nl);
   }
   if (pos != order.size()) throw std::runtime_error("mmcs commit: a matrix height was never reached");
+  if (chp) {  // the tree was finished by the layer-by-layer kernels (or is a single leaf): the challenger step on its own
+    const size_t cl = t.cap_layer();
+    bb_fri_challenge(ctx, chp->ch, t.layers[cl].p, t.sizes[cl], d_perm, chp->beta_out);
+  }
 }
 void bb_commit(Ctx& ctx, const Poseidon2* d_perm, std::vector<BMat>&& ldes, unsigned cap_height, BPcsData& out) {
   out.ldes = std::move(ldes);
@@ -526,7 +554,8 @@ void bb_commit(Ctx& ctx, const Poseidon2* d_perm, std::vector<BMat>&& ldes, unsi
   hash_group(ctx, d_perm, group, maxh, t.layers[0].p);
   build_upper_layers(ctx, d_perm, t, order, pos);
 }
-void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& t) {
+void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& t, DevChallenger* d_ch,
+                     FriBeta* d_beta_out) {
   t = BTree();
   t.cap_height = cap_height;
   t.layers.emplace_back(ctx, rows);
@@ -538,7 +567,8 @@ void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t 
     else
       leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
   }
-  build_upper_layers(ctx, d_perm, t, {}, 0);
+  FriRoundCh chp{d_ch, d_beta_out};
+  build_upper_layers(ctx, d_perm, t, {}, 0, d_ch ? &chp : nullptr);
 }
 
 // ------------------------------------------------------------------ node programs
@@ -1014,21 +1044,18 @@ void bb_fri_fold(Ctx& ctx, const E4* cur, size_t rows, E4 beta, const E4* roll_i
 // ---- the commit-phase transcript on the device (proof-of-work bits = 0): one 16-lane group replays the duplex challenger -
 // observe the round's cap, sample beta - so that the FRI rounds queue up without a host round trip; the host replays
 // the same steps afterwards on its own challenger and rejects any divergence.
-__global__ __launch_bounds__(64) void fri_challenge_k(DevChallenger* ch, const Digest8* __restrict__ cap, u32 n_cap, const Poseidon2* __restrict__ perm,
-                                                      u32 half, FriBeta* __restrict__ out) {
-  const int l = threadIdx.x & 15;
-  if (threadIdx.x >= 16) return;  // one DPP row does the work: lane l holds state word l and queued input l
+// one 16-lane group: observe `n_words` words of the cap (lane-visible memory), sample beta; updates *ch, fills *out
+__device__ __forceinline__ void duplex_round(DevChallenger* ch, const u32* cw, u32 n_words, const Poseidon2& perm, u32 half, FriBeta* out, int l) {
   u32 s = ch->state[l];
   u32 pend = l < 8 ? ch->input[l] : 0;
   u32 n_in = ch->n_in, n_out = ch->n_out;
   auto duplex = [&]() {
     if ((u32)l < n_in) s = pend;
     n_in = 0;
-    s = coop_poseidon2(*perm, s, l);
+    s = coop_poseidon2(perm, s, l);
     n_out = 8;
   };
-  const u32* cw = (const u32*)cap;
-  for (u32 k = 0; k < n_cap * 8; k++) {  // observe: clears the output buffer, queues, absorbs at 8
+  for (u32 k = 0; k < n_words; k++) {  // observe: clears the output buffer, queues, absorbs at 8
     n_out = 0;
     u32 v = cw[k];
     if ((u32)l == n_in) pend = v;
@@ -1039,7 +1066,7 @@ __global__ __launch_bounds__(64) void fri_challenge_k(DevChallenger* ch, const D
 #pragma unroll
   for (int c = 0; c < 4; c++) {  // sample_algebra_element: four pops from the back of the output buffer
     if (n_in > 0 || n_out == 0) duplex();
-    beta.c[c] = (u32)__shfl((int)s, (int)(n_out - 1), 64);
+    beta.c[c] = (u32)__shfl((int)s, (int)(n_out - 1), 16);
     n_out--;
   }
   ch->state[l] = s;
@@ -1051,6 +1078,11 @@ __global__ __launch_bounds__(64) void fri_challenge_k(DevChallenger* ch, const D
     out->half_beta = e4_mul_base(beta, half);
     out->beta2 = e4_square(beta);
   }
+}
+__global__ __launch_bounds__(64) void fri_challenge_k(DevChallenger* ch, const Digest8* __restrict__ cap, u32 n_cap, const Poseidon2* __restrict__ perm,
+                                                      u32 half, FriBeta* __restrict__ out) {
+  if (threadIdx.x >= 16) return;  // one DPP row does the work: lane l holds state word l and queued input l
+  duplex_round(ch, (const u32*)cap, n_cap * 8, *perm, half, out, threadIdx.x & 15);
 }
 void bb_fri_challenge(Ctx& ctx, DevChallenger* d_ch, const Digest8* d_cap, size_t n_cap, const Poseidon2* d_perm, FriBeta* d_out) {
   fri_challenge_k<<<1, 64, 0, ctx.stream>>>(d_ch, d_cap, (u32)n_cap, d_perm, bb_inv(bb_to_monty(2)), d_out);
@@ -1069,6 +1101,182 @@ __global__ void fri_fold_dev_k(const E4* __restrict__ cur, size_t rows, unsigned
   if (roll) r = e4_add(r, e4_mul(fb->beta2, roll[i]));
   out[i] = r;
 }
+// ---- every level above a layer of `len` digests in ONE launch, the BabyBear / Poseidon2 counterpart of hash.hip::subtree_k:
+// a workgroup (64 sixteen-lane groups, one permutation each) owns `sub` children - a sub-tree held in LDS -, publishes its
+// root write-through, draws a ticket, and the last workgroup to arrive reads all roots and finishes the tree
+// (MI355X_MICROARCH.md, inter-workgroup visibility: `sc1` stores, drained, agent-scope counter, `sc1` loads).
+// CH: that workgroup continues with the round's DuplexChallenger step (no proof of work: observe the root, sample beta).
+// FOLD: the children are the leaf digests of a FRI layer produced here: the previous layer is folded with the beta the
+// previous round left on the device, the folded layer is written and its rows hashed - a commit-phase round per launch.
+struct SubtreeArgs {
+  Digest8* level[24];  // level[0] = the children (len digests), level[k] = len >> k digests
+  u32 len, sub;        // sub = children per workgroup (2 <= sub <= 1024, a power of two); len / sub workgroups (<= 1024)
+  u32* counter;
+  DevChallenger* ch;
+  FriBeta* beta_out;
+  u32 half;
+  u32 log_rows;        // FOLD: log2 of the folded layer's length (= 2 * len)
+  u32 g_inv;
+  const E4* cur;
+  const E4* roll;
+  E4* out;
+  const FriBeta* prev;
+};
+template <bool CH, bool FOLD>
+__global__ __launch_bounds__(1024) void subtree_k(SubtreeArgs a, const Poseidon2* __restrict__ perm) {
+  __shared__ __attribute__((aligned(16))) u32 sh_a[1024 * 8];  // the children of the current level ...
+  __shared__ __attribute__((aligned(16))) u32 sh_b[512 * 8];   // ... and its nodes (the two swap roles level by level)
+  __shared__ u32 s_last;
+  u32* sh = sh_a;
+  u32* sh_next = sh_b;
+  const u32 t = threadIdx.x, nb = gridDim.x;
+  const int l = t & 15;
+  const u32 group = t >> 4;  // 64 groups
+  u32 b = blockIdx.x;
+  // ---- the children of this workgroup into LDS
+  if (FOLD) {
+    const FriBeta fb = *a.prev;
+    for (u32 j = group; j < a.sub; j += 64) {
+      const size_t c = size_t(b) * a.sub + j;  // leaf c = row (out[2c], out[2c + 1]) of the folded layer
+      if (l < 2) {
+        const size_t i = 2 * c + l;
+        const u32 gp = bb_pow(a.g_inv, bitrev_dev(i, a.log_rows));
+        const E4 pw = e4_mul_base(fb.half_beta, gp);
+        const E4 lo = a.cur[2 * i], hi = a.cur[2 * i + 1];
+        E4 x = pw, y = e4_neg(pw);
+        x.c[0] = bb_add(x.c[0], a.half);
+        y.c[0] = bb_add(y.c[0], a.half);
+        E4 r = e4_add(e4_mul(x, lo), e4_mul(y, hi));
+        if (a.roll) r = e4_add(r, e4_mul(fb.beta2, a.roll[i]));
+        a.out[i] = r;
+#pragma unroll
+        for (int d = 0; d < 4; d++) sh[j * 8 + 4 * l + d] = r.c[d];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      u32 s = l < 8 ? sh[j * 8 + l] : 0;
+      s = coop_poseidon2(*perm, s, l);
+      if (l < 8) {
+        sh[j * 8 + l] = s;
+        a.level[0][c].w[l] = s;
+      }
+    }
+  } else {
+    const u32* src = (const u32*)(a.level[0] + size_t(b) * a.sub);
+    for (u32 i = t; i < a.sub * 8; i += 1024) sh[i] = src[i];
+  }
+  __syncthreads();
+  u32 n = a.sub >> 1, lvl = 1;
+#pragma unroll 1
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1) {
+      if (nb == 1) break;
+      u32* roots = (u32*)a.level[lvl - 1];  // the layer of nb digests this phase just completed
+      if (t < 8) __hip_atomic_store(roots + size_t(b) * 8 + t, sh[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const u32 ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == nb - 1 ? 1u : 0u;
+      }
+      __syncthreads();
+      if (!s_last) return;
+      sh = sh_a;  // room for 1024 roots
+      sh_next = sh_b;
+      for (u32 i = t; i < nb * 8; i += 1024) sh[i] = __hip_atomic_load(roots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      b = 0;
+      n = nb >> 1;
+    }
+#pragma unroll 1
+    for (; n >= 1; n >>= 1, lvl++) {
+#pragma unroll 1
+      for (u32 node = group; node < n; node += 64) {  // n <= 512
+        u32 s = sh[node * 16 + l];  // left || right are adjacent digests
+        s = coop_poseidon2(*perm, s, l);
+        if (l < 8) {
+          sh_next[node * 8 + l] = s;
+          a.level[lvl][size_t(b) * n + node].w[l] = s;
+        }
+      }
+      __syncthreads();
+      u32* tmp = sh;
+      sh = sh_next;
+      sh_next = tmp;
+    }
+  }
+  if (CH && t < 16) duplex_round(a.ch, sh, 8, *perm, a.half, a.beta_out, l);
+}
+
+static u32 subtree_children_per_group(size_t len) {
+  // one workgroup up to 1024 children; above that about 256 workgroups (one per CU), each owning 2 .. 1024 children
+  if (len <= 1024) return (u32)len;
+  size_t sub = len / 256;
+  if (sub < 2) sub = 2;
+  if (sub > 1024) sub = 1024;
+  return (u32)sub;
+}
+// allocates the layers above t's last one and fills the kernel's level table
+static void subtree_levels(Ctx& ctx, BTree& t, SubtreeArgs& a) {
+  const size_t len = t.sizes.back();
+  if (len < 2 || len > (size_t(1) << 20)) throw std::runtime_error("subtree: layer length out of range");
+  memset(&a, 0, sizeof(a));
+  a.level[0] = t.layers.back().p;
+  int k = 1;
+  for (size_t n = len / 2; n >= 1; n /= 2) {
+    t.layers.emplace_back(ctx, n);
+    t.sizes.push_back(n);
+    a.level[k++] = t.layers.back().p;
+    if (n == 1) break;
+  }
+  a.len = (u32)len;
+  a.sub = subtree_children_per_group(len);
+  a.counter = ctx.tree_counter;
+  a.half = bb_inv(bb_to_monty(2));
+}
+static void launch_subtree(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const FriRoundCh* chp) {
+  SubtreeArgs a;
+  const size_t len = t.sizes.back();
+  subtree_levels(ctx, t, a);
+  if (chp && t.cap_height != 0) throw std::runtime_error("subtree: the fused challenger step needs a root-only commitment");
+  ProfScope prof(ctx, msamd::K_COMPRESS, 96.0 * double(len), double(len));
+  if (chp) {
+    a.ch = chp->ch;
+    a.beta_out = chp->beta_out;
+    subtree_k<true, false><<<(unsigned)(len / a.sub), 1024, 0, ctx.stream>>>(a, d_perm);
+  } else {
+    subtree_k<false, false><<<(unsigned)(len / a.sub), 1024, 0, ctx.stream>>>(a, d_perm);
+  }
+}
+bool bb_fri_round_fusable(size_t rows, unsigned cap_height) {
+  return rows >= 4 && rows / 2 <= subtree_max() && cap_height == 0 && !getenv("MSBB_NO_SUBTREE") && !getenv("MSBB_NO_FRI_FUSED");
+}
+// One commit-phase round in one launch: fold `cur` (2 * rows elements) with the beta of `prev` into `out` (rows elements),
+// hash the rows / 2 leaves of the folded layer, build its tree `t` and run the challenger step on the root.
+void bb_fri_round_fused(Ctx& ctx, const Poseidon2* d_perm, const E4* cur, size_t rows, const FriBeta* prev, const E4* roll_in, E4* out,
+                        BTree& t, DevChallenger* d_ch, FriBeta* d_beta_out) {
+  const size_t leaves = rows / 2;
+  t = BTree();
+  t.cap_height = 0;
+  t.layers.emplace_back(ctx, leaves);
+  t.sizes.push_back(leaves);
+  SubtreeArgs a;
+  subtree_levels(ctx, t, a);
+  const unsigned lr = log2_host(rows);
+  a.ch = d_ch;
+  a.beta_out = d_beta_out;
+  a.log_rows = lr;
+  a.g_inv = bb_inv(bb_two_adic_generator(lr + 1));
+  a.cur = cur;
+  a.roll = roll_in;
+  a.out = out;
+  a.prev = prev;
+  ProfScope prof(ctx, msamd::K_FRI_FOLD, 48.0 * double(rows) + 64.0 * double(leaves), 2.0 * double(leaves));
+  subtree_k<true, true><<<(unsigned)(leaves / a.sub), 1024, 0, ctx.stream>>>(a, d_perm);
+}
+
 void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows, const FriBeta* d_beta, const E4* roll_in, E4* out) {
   unsigned lr = log2_host(rows);
   fri_fold_dev_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(cur, rows, lr, d_beta, bb_inv(bb_to_monty(2)), bb_inv(bb_two_adic_generator(lr + 1)), roll_in,

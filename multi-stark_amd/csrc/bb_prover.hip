@@ -551,7 +551,9 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
   // the device and the rounds queue up back to back; the host replays them afterwards. Off by default: measured at
   // 2^20 rows it does not pay (7.2 vs 6.9 ms) - the rounds are ~10 launches of ~5 us each, so the host's launch rate, not
   // its read-backs, is what spaces them; it needs the launches captured in a graph (or fewer of them) to win.
-  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && getenv("MSBB_DEV_FRI");
+  // (round 2: the rounds are fused - one launch per round below 2^17 leaves - and the device transcript is the default;
+  // MSBB_HOST_FRI=1 restores the host-driven rounds)
+  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && !getenv("MSBB_HOST_FRI");
   DBuf<DevChallenger> d_ch;
   DBuf<FriBeta> d_betas;
   size_t n_rounds = 0;
@@ -567,17 +569,29 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
     ctx.h2d(d_ch.p, &hc, sizeof(hc));
   }
   size_t round = 0;
+  bool tree_done = false;  // the previous round's fused launch already built this round's tree and ran its challenger step
   while (cur_len > stop) {
     size_t rows = cur_len / 2;
-    fri_trees.emplace_back();
-    bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back());
+    if (!tree_done) {
+      fri_trees.emplace_back();
+      if (dev_rounds)  // the launch that produces the root also observes it and samples beta
+        bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back(), d_ch.p, d_betas.p + round);
+      else
+        bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back());
+    }
+    tree_done = false;
     const E4* roll = nullptr;
     if (next_in < inputs.size() && inputs[next_in].second == rows) roll = inputs[next_in++].first;
     DBuf<E4> out(ctx, rows);
     if (dev_rounds) {
-      const BTree& t = fri_trees.back();
-      bb_fri_challenge(ctx, d_ch.p, t.layers[t.cap_layer()].p, t.sizes[t.cap_layer()], sys.d_perm.p, d_betas.p + round);
-      bb_fri_fold_dev(ctx, cur, rows, d_betas.p + round, roll, out.p);
+      if (rows > stop && bb_fri_round_fusable(rows, (unsigned)prm.cap_height)) {
+        // the next round - this fold, its leaf digests, its tree, its challenger step - is ONE launch
+        fri_trees.emplace_back();
+        bb_fri_round_fused(ctx, sys.d_perm.p, cur, rows, d_betas.p + round, roll, out.p, fri_trees.back(), d_ch.p, d_betas.p + round + 1);
+        tree_done = true;
+      } else {
+        bb_fri_fold_dev(ctx, cur, rows, d_betas.p + round, roll, out.p);
+      }
     } else {
       std::vector<Digest8> cap = tree_cap(ctx, fri_trees.back());
       ch.observe_cap(cap);

@@ -197,16 +197,22 @@ def test_product_verifier_agrees_with_oracle_on_corrupted_proofs(ctx):
             assert g.verify(pc, proof) != 0 and o.verify(pc, proof) != 0
 
 
-def test_device_side_fri_transcript(ctx, monkeypatch):
-    """MSBB_DEV_FRI=1: the commit-phase challenger steps on the device (duplex sponge on 16 lanes), replayed and checked
-    by the host; same bytes. With proof-of-work bits the host-driven rounds are used regardless."""
-    monkeypatch.setenv("MSBB_DEV_FRI", "1")
+@pytest.mark.parametrize("var", ["", "MSBB_HOST_FRI", "MSBB_NO_FRI_FUSED", "MSBB_NO_SUBTREE"])
+def test_device_side_fri_transcript(ctx, monkeypatch, var):
+    """The commit-phase challenger steps run on the device (duplex sponge on 16 lanes; replayed and checked by the host) and a
+    round is one launch (fold + leaf digests + tree + challenger step); MSBB_HOST_FRI / MSBB_NO_FRI_FUSED / MSBB_NO_SUBTREE
+    select the host-driven rounds, the unfused rounds and the layer-by-layer trees: same bytes every way. With
+    proof-of-work bits the host-driven rounds are used regardless."""
+    if var:
+        monkeypatch.setenv(var, "1")
     with fe.field(fe.BABYBEAR):
         inputs, trace = fe.mul_air_inputs(), fe.mul_air_trace(1 << 11)
         assert _prove_both(ctx, fe.test_params(), inputs, [trace], [])[0] == 0
         assert _prove_both(ctx, fe.Params(2, 2, 1, 1, 9, 0, 3), inputs, [trace], [])[0] == 0   # caps of 4 digests, final poly of 2
         assert _prove_both(ctx, fe.Params(2, 0, 0, 1, 9, 4, 0), inputs, [trace], [])[0] == 0   # PoW: host rounds
         ev_in, ev_tr = fe.even_odd_inputs(), fe.even_odd_traces()
+        big = fe.mul_air_trace(1 << 17)   # rounds above the fused kernel's size, trees with 1024 sub-tree roots
+        assert _prove_both(ctx, fe.test_params(), inputs, [big], [])[0] == 0
     assert _prove_both(ctx, fe.test_params(), ev_in, ev_tr, [[0, 4, 1]])[0] == 0
 
 
