@@ -16,8 +16,8 @@ ranks together (ms_prove_sharded): rank k computes adder k (2^20 rows, its own x
 one Merkle tree over all matrices, so the LDE row ranges are exchanged before leaf hashing (all-to-all), sub-tree
 roots / logUp totals / opened values / reduced openings are all-gathered, and every rank returns the same proof bytes.
 The exchanges run on the library's own RCCL transport (csrc/comm_rccl.hip: grouped ncclSend / ncclRecv and ncclAllGather
-called from C); torch.distributed only bootstraps (the 128-byte RCCL id, the barrier, the max over ranks). In this mode
-each rank's witness is resident in HBM (ms_prove_sharded takes device-resident witnesses). The independent-proof mode
+called from C); torch.distributed only bootstraps (the 128-byte RCCL id, the barrier, the max over ranks). As at N = 1 the
+witness is host-resident: every step uploads the rank's own trace and its 1/N slice of the claims. The independent-proof mode
 (one [ByteTable, U32Add] proof per GPU, host-resident witnesses, commitments all-gathered) is measured in the same run
 and reported as the secondary object `replicas`. Rank 0 prints ONE JSON line.
 """
@@ -422,7 +422,8 @@ def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
     owners = sharded.u32_add_owners(world)
     tr = [byte.cpu().numpy().astype(np.uint64)] + [traces[1] if k == rank else None for k in range(world)]
     remote = {1 + k: traces[1].shape[0] for k in range(world) if k != rank}
-    witness = system.witness(tr, packed, remote_heights=remote)
+    # host-resident, as at N = 1: every step uploads this rank's trace (and the byte table) and its slice of the claims
+    witness = system.host_witness(tr, packed, remote_heights=remote)
     transport = args.transport if args.backend == "nccl" else "torch"
     if transport == "rccl":
         # bootstrap only: rank 0 draws the RCCL id, torch.distributed hands it round; the exchanges themselves are C
@@ -486,8 +487,8 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
     result = base_line(args, n_gpus, info["value"], info["ms_per_step"])
     result["config"] = {
         "workload": WORKLOAD % (args.log_adds, "rank" if joint_primary else "proof",
-                                "each rank's witness resident in HBM (ms_prove_sharded takes device-resident witnesses)" if joint_primary
-                                else HOST_RESIDENT),
+                                "each rank's witness (its trace and all claims) in pinned host memory at step start: the rank uploads its trace and "
+                                "its slice of the claims inside the step, as at N = 1" if joint_primary else HOST_RESIDENT),
         "rows_per_proof": rows,
         "proof_bytes": info["proof_bytes"],
         "parallelism": ("one joint proof over %d GPUs (ms_prove_sharded, transport %s)" % (n_gpus, info.get("transport"))) if joint_primary

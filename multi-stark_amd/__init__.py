@@ -478,16 +478,18 @@ class System:
         _check(lib().ms_witness_create(self.h, tptr, _p(hs), mptr, aptr, C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(h)))
         return SystemWitness(h, int(hs.sum()), self)
 
-    def host_witness(self, traces, claims_packed):
+    def host_witness(self, traces, claims_packed, remote_heights=None):
         """A SystemWitness that stays in HOST memory (ms_witness_create_host): every prove_multiple_claims uploads it,
         as the reference's prove() would receive it (benches/multi_stark.rs:292-296). The arrays are kept alive (and
-        page-locked) by the returned object."""
+        page-locked) by the returned object. remote_heights {circuit: height}: circuits another rank computes
+        (prove_sharded): no trace here, height only."""
+        remote_heights = remote_heights or {}
         trs = [_u64(t) if t is not None and len(t) else np.zeros((0, 1), dtype=np.uint64) for t in traces]
         n = self.n_circuits
         if len(trs) != n:
             raise MstarkError("expected one trace per circuit")
-        tptr = (u64p * n)(*[_p(t) for t in trs])
-        hs = _u64([t.shape[0] for t in trs])
+        tptr = (u64p * n)(*[None if i in remote_heights else _p(t) for i, t in enumerate(trs)])
+        hs = _u64([remote_heights.get(i, t.shape[0]) for i, t in enumerate(trs)])
         offs, data = claims_packed
         data = data if data.size else np.zeros(1, dtype=np.uint64)
         h = C.c_void_p()

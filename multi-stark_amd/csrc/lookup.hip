@@ -189,14 +189,16 @@ __global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
-// words[0] = n; claim i: words[1 + i + offs[i]] = len_i, then its elements
+// words[0] = total; claim j: words[1 + j + offs[j]] = len_j, then its elements. The call covers claims [first, first + n):
+// offs points at the offset of claim `first`, offsets are absolute, `data` and `words` are addressed absolutely (a rank
+// that holds a slice passes pointers shifted back by the slice's start)
 __global__ __launch_bounds__(256) void claims_words_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n,
-                                                      u64* __restrict__ words) {
+                                                      u64* __restrict__ words, size_t first, size_t total) {
   size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (i == 0) words[0] = (u64)n;
+  if (i == 0 && first == 0) words[0] = (u64)total;
   if (i >= n) return;
   u64 o = offs[i], len = offs[i + 1] - o;
-  u64* w = words + 1 + i + o;
+  u64* w = words + 1 + first + i + o;
   w[0] = len;
   for (u64 k = 0; k < len; k++) w[1 + k] = data[o + k];
 }
@@ -318,9 +320,16 @@ E2 claims_accumulator(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, 
 
 size_t claims_transcript_words(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, size_t total_elems, u64* d_words) {
   size_t nwords = 1 + n + total_elems;
-  hipLaunchKernelGGL(claims_words_k, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, ctx.stream, d_data, d_offs, n, d_words);
+  hipLaunchKernelGGL(claims_words_k, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, ctx.stream, d_data, d_offs, n, d_words, size_t(0), n);
   HIP_CHECK(hipGetLastError());
   return nwords;
+}
+
+void claims_transcript_words_slice(Ctx& ctx, const u64* d_data_abs, const u64* d_offs_first, size_t first, size_t count, size_t n_total,
+                                   u64* d_words_abs) {
+  hipLaunchKernelGGL(claims_words_k, dim3((unsigned)((count + 255) / 256 + 1)), dim3(256), 0, ctx.stream, d_data_abs, d_offs_first, count,
+                     d_words_abs, first, n_total);
+  HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace msamd

@@ -261,6 +261,11 @@ E2 claims_accumulator(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offs
 size_t claims_transcript_words(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims,
                                size_t total_elems, u64* d_words);
 
+// the same for claims [first, first + count) only: d_offs_first points at the (absolute) offset of claim `first`; d_data_abs and
+// d_words_abs are addressed absolutely, i.e. shifted back by the start of the slice the caller holds
+void claims_transcript_words_slice(Ctx& ctx, const u64* d_data_abs, const u64* d_offs_first, size_t first, size_t count, size_t n_total,
+                                   u64* d_words_abs);
+
 // ---------------------------------------------------------------- quotient.hip
 // a circuit's quotient kernel compiled with hiprtc at System::new (quotient_jit.hip); empty = use the interpreter
 struct JitKernel {

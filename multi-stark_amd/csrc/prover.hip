@@ -528,7 +528,10 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
     if (log2_strict(h) > NTT_MAX_LOG || log2_strict(h) + sys.params.log_blowup > TW_LOG)
       throw std::runtime_error("trace height exceeds the supported maximum");
     if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
-    if (!traces[ci]) throw std::runtime_error("host-resident witness: every active circuit needs its trace");
+    if (!traces[ci]) {  // computed by another rank (ms_prove_sharded): only the height is known here
+      w->has_remote = true;
+      continue;
+    }
     const size_t cnt = h * c.main_width;
     for (size_t i = 0; i < cnt; i++)
       if (traces[ci][i] >= GL_P) throw std::runtime_error("non-canonical trace value");
@@ -575,6 +578,7 @@ struct HostUpload {
   HWitness& w;
   Ctx& ctx;
   bool on = false;
+  bool skip_claims = false;  // the multi-rank prover uploads per-rank slices of the claims itself
   HostUpload(HWitness& wit, Ctx& c) : w(wit), ctx(c) {}
   // does stage 2 of this circuit run from the uploaded trace (stage2_terms_trace_jit)?
   bool fused(size_t ci) const {
@@ -596,7 +600,7 @@ struct HostUpload {
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
-      if (!h) continue;
+      if (!h || !w.h_traces[ci]) continue;  // inactive, or computed by another rank
       st.traces[ci] = DBuf<u64>(ctx, h * c.main_width);
       HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], h * c.main_width * 8, hipMemcpyHostToDevice, ctx.copy_stream));
     }
@@ -605,7 +609,7 @@ struct HostUpload {
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
-      if (!h || !c.num_lookups) continue;
+      if (!h || !c.num_lookups || !w.h_traces[ci]) continue;
       if (fused(ci)) continue;  // stage 2 reads the trace itself: no LookupValues for this circuit
       st.mult[ci] = DBuf<u64>(ctx, h * c.num_lookups);
       st.args[ci] = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
@@ -617,10 +621,12 @@ struct HostUpload {
       }
     }
     const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
-    st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
-    st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
-    HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
-    if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    if (!skip_claims) {
+      st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
+      st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
+      HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+      if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    }
     HIP_CHECK(hipEventRecord(st.ev[2], ctx.copy_stream));
     // SystemWitness::from_stage_1 (src/system.rs:244-328) as one kernel per circuit, from the traces just uploaded, queued on
     // the copy stream behind the copies: it writes 344 MB at config 2 and runs beside the transforms of stage 1 (which are
@@ -628,7 +634,7 @@ struct HostUpload {
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
-      if (!h || !c.num_lookups || !w.h_mult[ci].empty() || fused(ci)) continue;
+      if (!h || !c.num_lookups || !w.h_mult[ci].empty() || fused(ci) || !w.h_traces[ci]) continue;
       if (!lookup_values_device(ctx, c.prefix_prog, st.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, h, c.main_width, c.pre_width,
                                 c.args_width, st.mult[ci].p, st.args[ci].p, ctx.copy_stream))
         throw std::runtime_error("host-resident witness: lookup prefix does not fit the device sweep");

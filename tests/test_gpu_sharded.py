@@ -41,6 +41,11 @@ def _worker(rank, world, port, log_adds, variant, q):
             w = system.witness(mine, packed, remote_heights=remote)
             comm = sharded.TorchComm(0)
             proof = system.prove_sharded(w, comm, owners).to_bytes()
+            # the same from a HOST-resident witness: this rank's traces and its slice of the claims are uploaded inside the proof
+            hw = system.host_witness(mine, packed, remote_heights=remote)
+            for _ in range(2):
+                assert system.prove_sharded(hw, comm, owners).to_bytes() == proof, "host-resident sharded proof differs"
+            del hw
             again = system.prove_sharded(w, comm, owners, want_times=True)
             assert again.to_bytes() == proof and again.stage_ms["total"] > 0
             if remote:
