@@ -23,7 +23,7 @@ def _hipcc():
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]  # .inc: sources included by a .hip
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mstark.h"))
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mstark_bb.h"))
     hdr_mtime = max(os.path.getmtime(h) for h in headers)

@@ -335,7 +335,8 @@ struct DeepPoints {
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro,
                  const E2* alpha_pows_host = nullptr);
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
-void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out);
+// row0 / rows_total: `cur`, `roll_in`, `out` are the slice [row0, row0 + rows) of a folded layer of rows_total rows (0 = whole layer)
+void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out, size_t row0 = 0, size_t rows_total = 0);
 // Merkle tree of one FRI layer: leaf i = BLAKE3 of the 32-byte row (cur[2i], cur[2i+1]) (ExtensionMmcs flattening)
 // With fc, the launch that produces the root also runs the challenger step of that round (see challenge_dev.h);
 // cur == nullptr means the leaf layer of t (already allocated) was written by fri_fold_dev.

@@ -220,12 +220,13 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
 }
 
 // out[i] = (1/2 + pw) lo + (1/2 - pw) hi, pw = (beta/2) w_{2R}^{-bitrev(i)}; optional roll-in out[i] += f * in[i]
+// (row0 != 0: `cur` / `roll` / `out` are a rank's slice of the layer, which starts at row `row0` of 2^log_rows)
 __global__ __launch_bounds__(256) void fri_fold_k(const E2* __restrict__ cur, size_t rows, unsigned log_rows, E2 half_beta, u64 half,
                                                   const E2* __restrict__ roll, E2 roll_f, const u64* __restrict__ t0i,
-                                                  const u64* __restrict__ t1i, E2* __restrict__ out) {
+                                                  const u64* __restrict__ t1i, E2* __restrict__ out, size_t row0) {
   size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (i >= rows) return;
-  u32 e = bitrev32((u32)i, log_rows) << (TW_LOG - log_rows - 1);
+  u32 e = bitrev32((u32)(i + row0), log_rows) << (TW_LOG - log_rows - 1);
   u64 gp = gl_mul(t1i[e >> TW_HALF], t0i[e & ((1u << TW_HALF) - 1)]);
   E2 pw = e2_mul_base(half_beta, gp);
   (void)half;
@@ -651,15 +652,15 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
   HIP_CHECK(hipGetLastError());
 }
 
-void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in, E2* out) {
-  unsigned lr = log2_strict(rows);
+void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in, E2* out, size_t row0, size_t rows_total) {
+  unsigned lr = log2_strict(rows_total ? rows_total : rows);
   if (lr + 1 > TW_LOG) throw std::runtime_error("FRI layer above 2^28 is not supported");
   u64 half = gl_inv(2);
   E2 hb = e2_mul_base(beta, half);
   E2 rf = e2_sqr(beta);  // roll-in factor beta^2
   hipEvent_t ev = ctx.prof_begin(K_FRI_FOLD);
   hipLaunchKernelGGL(fri_fold_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, hb, half, roll_in, rf,
-                     ctx.tw0i, ctx.tw1i, out);
+                     ctx.tw0i, ctx.tw1i, out, row0);
   ctx.prof_end(K_FRI_FOLD, ev, 48.0 * rows);
   HIP_CHECK(hipGetLastError());
 }

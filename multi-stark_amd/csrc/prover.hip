@@ -780,8 +780,24 @@ void add_gather_seg(std::vector<GatherSeg>& segs, size_t& out_off, const void* b
   segs.push_back(q);
   out_off += kind == 0 ? size_t(count) * 8 : kind == 1 ? 32 : 16;
 }
+// Commit-phase rounds that ran BEFORE fri_prove on row shards spread over ranks (prover_sharded.inc): their commitments
+// and proof-of-work witnesses go in front of fri_prove's own, the query indices keep the full height, and each query's
+// openings of those rounds (sibling value, then the path) arrive through `remote`, behind the input rounds' bytes.
+struct FriHead {
+  unsigned n_rounds = 0;
+  unsigned log_max_height = 0;                 // log2 of the tallest reduced-opening vector (what the indices are sampled for)
+  std::vector<std::vector<Digest>> commits;    // per head round
+  std::vector<u64> pow;
+  std::vector<size_t> nsib;                    // path length of each head round's opening
+  size_t qbytes() const {
+    size_t b = 0;
+    for (size_t n : nsib) b += 16 + 32 * n;
+    return b;
+  }
+};
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
-               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr);
+               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr,
+               const FriHead* head = nullptr);
 
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
 void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes) {
@@ -963,8 +979,10 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
 // every matrix row, then the sibling digests bottom-up) or, when the committed data is spread over ranks, by
 // `remote`, called with the sampled indices and filling the same layout.
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
-               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr) {
+               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr, const FriHead* head) {
   Ctx& ctx = *sys.ctx;
+  const unsigned head_rounds = head ? head->n_rounds : 0;
+  if (head && !remote) throw std::runtime_error("FRI: head rounds need the remote gather");
   const Params& prm = sys.params;
   const unsigned lb = (unsigned)prm.log_blowup;
   (void)log_gmax;
@@ -983,7 +1001,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   std::vector<u64> pow_w;
   DBuf<E2> folded = std::move(inputs[0]);
   size_t next_in = 1;
-  const unsigned log_max_height = log2_strict(folded.n);
+  const unsigned log_max_height = head ? head->log_max_height : log2_strict(folded.n);
   std::vector<E2> fin;                // final folded vector (host)
   DBuf<Digest> tail_tree;
   DBuf<E2> tail_layers;
@@ -1138,10 +1156,11 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   }
   auto n_siblings = [](const DTree& t) { return t.cap_layer(); };
   for (size_t i = 0; i < trees.size(); i++) {
-    // sibling value of round i sits at element (index >> i) ^ 1 of that round's vector
-    add_gather_seg(segs, out_off, layers[i], 0, 1, 2, (uint32_t)i, 1);
+    // sibling value of round i sits at element (index >> i) ^ 1 of that round's vector (rounds count from the head's)
+    const uint32_t gr = (uint32_t)i + head_rounds;
+    add_gather_seg(segs, out_off, layers[i], 0, 1, 2, gr, 1);
     const DTree& t = trees[i];
-    for (size_t l = 0; l < n_siblings(t); l++) add_gather_seg(segs, out_off, t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(i + 1 + l), 1);
+    for (size_t l = 0; l < n_siblings(t); l++) add_gather_seg(segs, out_off, t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(gr + 1 + l), 1);
   }
   const size_t qbytes = out_off;
   const size_t nq = (size_t)prm.num_queries;
@@ -1241,23 +1260,28 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
 
   // ---- openings of the input rounds held elsewhere
   std::vector<uint8_t> input_g;
+  const size_t remote_qbytes = input_qbytes + (head ? head->qbytes() : 0);
   if (remote) {
-    input_g.resize(input_qbytes * nq);
-    (*remote)(indices, input_qbytes, input_g.data());
+    input_g.resize(remote_qbytes * nq);
+    (*remote)(indices, remote_qbytes, input_g.data());
     tr.mark("remote_input_openings");
   }
 
   // ---- FriProof bytes
   PW& w = fri_bytes;
-  w.b.reserve(w.b.size() + nq * (qbytes + input_qbytes + 64 * (trees.size() + shape.widths.size() * 4 + 8)) + 4096);
-  w.u64_(commits.size());
+  w.b.reserve(w.b.size() + nq * (qbytes + remote_qbytes + 64 * (trees.size() + head_rounds + shape.widths.size() * 4 + 8)) + 4096);
+  w.u64_(commits.size() + head_rounds);
+  if (head)
+    for (auto& c : head->commits) w.cap(c);
   for (auto& c : commits) w.cap(c);
-  w.u64_(pow_w.size());
+  w.u64_(pow_w.size() + head_rounds);
+  if (head)
+    for (u64 x : head->pow) w.u64_(x);
   for (u64 x : pow_w) w.u64_(x);
   w.u64_(indices.size());
   size_t pos = 0;
   for (size_t qi = 0; qi < indices.size(); qi++) {
-    const uint8_t* ip = remote ? &input_g[qi * input_qbytes] : &g[pos];
+    const uint8_t* ip = remote ? &input_g[qi * remote_qbytes] : &g[pos];
     w.u64_(shape.widths.size());
     for (size_t ri = 0; ri < shape.widths.size(); ri++) {
       w.u64_(shape.widths[ri].size());
@@ -1272,7 +1296,16 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
       ip += ns * 32;
     }
     if (!remote) pos += input_qbytes;
-    w.u64_(trees.size());
+    w.u64_(trees.size() + head_rounds);
+    for (unsigned hr = 0; hr < head_rounds; hr++) {  // rounds that ran on row shards: bytes fetched from the owning rank
+      w.u8(1);  // log_arity
+      w.u64_(1);
+      w.raw(ip, 16);
+      ip += 16;
+      w.u64_(head->nsib[hr]);
+      w.raw(ip, head->nsib[hr] * 32);
+      ip += head->nsib[hr] * 32;
+    }
     for (size_t i = 0; i < trees.size(); i++) {
       w.u8(1);  // log_arity
       w.u64_(1);
