@@ -64,7 +64,8 @@ void abandon_pending() {
     if (!g_live.count(c)) return;
   }
   (void)hipStreamSynchronize(c->copy_stream);
-  (void)hipStreamSynchronize(c->stream);
+  c->side_join();
+  (void)hipStreamSynchronize(c->main_stream);
   (void)hipGetLastError();
   c->down_pending.clear();
   c->down_used = 0;
@@ -115,6 +116,10 @@ Ctx::Ctx(int dev) : device(dev) {
   if (dev < 0 || dev >= count) throw std::runtime_error("HIP device index out of range");
   HIP_CHECK(hipSetDevice(dev));
   HIP_CHECK(hipStreamCreate(&stream));
+  main_stream = stream;
+  HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+  for (auto& e : side_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  side_config();
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   for (auto& e : copy_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   pinned_half = size_t(8) << 20;
@@ -217,6 +222,8 @@ Ctx::~Ctx() {
   }
   (void)hipSetDevice(device);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (side_stream) (void)hipStreamSynchronize(side_stream);
+  stream = main_stream;
   (void)hipStreamSynchronize(stream);
   for (auto& p : prof_pending) {
     (void)hipEventDestroy(p.a);
@@ -225,6 +232,12 @@ Ctx::~Ctx() {
   for (auto e : event_pool) (void)hipEventDestroy(e);
   for (auto& kv : pool_free) (void)hipFree(kv.second);
   for (auto& kv : pool_live) (void)hipFree(kv.first);
+  for (auto& kv : pool_free_side) (void)hipFree(kv.second);
+  for (auto& kv : side_live) (void)hipFree(kv.first);
+  for (auto& kv : side_deferred) (void)hipFree(kv.second);
+  for (auto e : side_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (side_stream) (void)hipStreamDestroy(side_stream);
   for (auto& kv : lde_scales) (void)hipFree(kv.second);
   if (pinned) (void)hipHostFree(pinned);
   if (tw0) (void)hipFree(tw0);
@@ -241,11 +254,13 @@ void* Ctx::alloc(size_t bytes) {
   if (fail_alloc_countdown > 0 && --fail_alloc_countdown == 0) throw std::runtime_error("injected allocation failure (ms_ctx_debug_fail_alloc)");
   size_t sz = (bytes + 255) & ~size_t(255);
   if (sz == 0) sz = 256;
-  auto it = pool_free.find(sz);
+  const bool side = side_depth > 0;
+  std::multimap<size_t, void*>& free_list = side ? pool_free_side : pool_free;
+  auto it = free_list.find(sz);
   void* p = nullptr;
-  if (it != pool_free.end()) {
+  if (it != free_list.end()) {
     p = it->second;
-    pool_free.erase(it);
+    free_list.erase(it);
   } else {
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
@@ -256,24 +271,71 @@ void* Ctx::alloc(size_t bytes) {
     }
     pool_bytes += sz;
   }
-  pool_live[p] = sz;
+  if (side)
+    side_live[p] = sz;
+  else
+    pool_live[p] = sz;
   return p;
 }
 
 void Ctx::release(void* p) {
   auto it = pool_live.find(p);
-  if (it == pool_live.end()) return;
-  pool_free.emplace(it->second, p);
-  pool_live.erase(it);
+  if (it != pool_live.end()) {
+    pool_free.emplace(it->second, p);
+    pool_live.erase(it);
+    return;
+  }
+  it = side_live.find(p);
+  if (it == side_live.end()) return;
+  // a side block may still be in use by launches of the side stream that the main stream has not waited for
+  if (side_forked)
+    side_deferred.emplace_back(it->second, p);
+  else
+    pool_free_side.emplace(it->second, p);
+  side_live.erase(it);
 }
 
 void Ctx::trim() {
-  (void)hipStreamSynchronize(stream);
+  side_join();
+  (void)hipStreamSynchronize(main_stream);
   for (auto& kv : pool_free) {
     (void)hipFree(kv.second);
     pool_bytes -= kv.first;
   }
   pool_free.clear();
+  for (auto& kv : pool_free_side) {
+    (void)hipFree(kv.second);
+    pool_bytes -= kv.first;
+  }
+  pool_free_side.clear();
+}
+
+void Ctx::side_config() {
+  side_enabled = !getenv("MSAMD_NO_SIDE_STREAM");
+  const char* v = getenv("MSAMD_SIDE_MAX_LOG");
+  side_max_log = v ? (unsigned)atoi(v) : 12u;
+  if (side_max_log > 40) side_max_log = 40;
+}
+
+void Ctx::side_fork() {
+  if (!side_enabled) return;
+  if (side_forked) side_join();
+  HIP_CHECK(hipEventRecord(side_ev[0], main_stream));
+  HIP_CHECK(hipStreamWaitEvent(side_stream, side_ev[0], 0));
+  side_forked = true;
+}
+
+void Ctx::side_join() {
+  if (!side_forked) return;
+  side_forked = false;
+  hipError_t e = hipEventRecord(side_ev[1], side_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, side_ev[1], 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(side_stream);  // fall back to a host-side wait: the blocks below must be idle
+  }
+  for (auto& kv : side_deferred) pool_free_side.emplace(kv.first, kv.second);
+  side_deferred.clear();
 }
 
 // Small read-backs without the runtime's copy + wake-up path: ONE kernel moves every queued segment into the pinned
@@ -309,6 +371,8 @@ __global__ __launch_bounds__(256) void flag_copy_k(FlagCopyArgs a) {
 }  // namespace
 
 void Ctx::sync_and_deliver() {
+  side_join();  // read-backs and the staging halves are shared: everything the side stream was given completes first
+  hipStream_t stream = main_stream;
   bool done = false;
   if (flag_host && !down_pending.empty() && down_pending.size() <= 12 && !down_direct && !getenv("MSAMD_NO_FLAG_SYNC")) {
     FlagCopyArgs a;
@@ -357,6 +421,7 @@ void Ctx::sync_and_deliver() {
   down_direct = false;
   down_used = 0;
   up_used = 0;  // every queued upload has executed
+  if (side_depth > 0) side_fork();  // synchronised from inside a SideScope: what the scope queues next is joined again
 }
 
 void Ctx::h2d(void* dst, const void* src, size_t n) {
@@ -453,7 +518,8 @@ void Ctx::prof_end(int id, hipEvent_t a, double bytes) {
 
 void Ctx::prof_collect() {
   if (prof_pending.empty()) return;
-  HIP_CHECK(hipStreamSynchronize(stream));
+  side_join();
+  HIP_CHECK(hipStreamSynchronize(main_stream));
   for (auto& p : prof_pending) {
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));

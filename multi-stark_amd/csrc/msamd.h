@@ -62,6 +62,23 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // bulk uploads of a host-resident witness, running beside the kernels of `stream`
+  // Side stream for the short circuits of a system (prover.hip): between side_fork() and side_join() the launches queued
+  // inside a SideScope go to `side_stream` (the scope swaps `stream`) and run beside the long kernels of the main stream
+  // instead of in front of them. Blocks allocated inside a scope come from a pool of their own (`pool_free_side`), and a
+  // release of such a block while the streams are forked is deferred to the join, so no block ever changes streams
+  // without an event in between.
+  hipStream_t main_stream = nullptr, side_stream = nullptr;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
+  bool side_forked = false;
+  int side_depth = 0;
+  bool side_enabled = true;
+  unsigned side_max_log = 12;  // circuits of at most 2^side_max_log rows count as short (MSAMD_SIDE_MAX_LOG)
+  std::multimap<size_t, void*> pool_free_side;
+  std::map<void*, size_t> side_live;                      // live blocks of the side pool
+  std::vector<std::pair<size_t, void*>> side_deferred;    // released while forked
+  void side_config(); // read MSAMD_NO_SIDE_STREAM / MSAMD_SIDE_MAX_LOG (at the start of every proof: tests flip them)
+  void side_fork();   // the side stream waits for everything queued on the main stream so far
+  void side_join();   // the main stream waits for everything queued on the side stream so far
   hipEvent_t copy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   u64 *tw0 = nullptr, *tw1 = nullptr, *tw0i = nullptr, *tw1i = nullptr;
   // compact per-order tables: table r (root of order 2^r, r = 1..12) holds w^i for i < 2^(r-1) at offset 2^(r-1) - 1
@@ -136,6 +153,21 @@ struct RoctxRange {
   explicit RoctxRange(const char* name);
   ~RoctxRange();
   void next(const char* name);  // close the current range and open another one
+};
+
+// launches, copies and allocations inside the scope go to the side stream (no-op unless the streams are forked)
+struct SideScope {
+  Ctx& ctx;
+  bool on;
+  SideScope(Ctx& c, bool use) : ctx(c), on(use && c.side_forked) {
+    if (on) {
+      ctx.side_depth++;
+      ctx.stream = ctx.side_stream;
+    }
+  }
+  ~SideScope() {
+    if (on && --ctx.side_depth == 0) ctx.stream = ctx.main_stream;
+  }
 };
 
 // drop read-backs queued by the calling thread whose destinations an error has unwound (called by the C-ABI catch blocks)

@@ -830,11 +830,30 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         size_t k = point_index(z);
         uh[k] = std::max(uh[k], r.data->ldes[mi].h);
       }
+  // short matrices beside tall ones: their launches go to the side stream (see prove()), queued behind the tall ones'
+  ctx.side_config();
+  const size_t short_h = size_t(1) << (ctx.side_max_log + lb);
+  const bool use_side = ctx.side_enabled && gmax > short_h && [&]() {
+    for (auto& r : rounds)
+      for (size_t mi = 0; mi < r.data->ldes.size(); mi++)
+        if (r.data->ldes[mi].h <= short_h && !r.points[mi].empty()) return true;
+    return false;
+  }();
+  struct SideSession {
+    Ctx& c;
+    ~SideSession() { c.side_join(); }
+  } side_session{ctx};
   std::vector<DBuf<E2>> dens(upts.size()), xdens(upts.size());
-  for (size_t k = 0; k < upts.size(); k++) {
-    dens[k] = DBuf<E2>(ctx, uh[k]);
-    xdens[k] = DBuf<E2>(ctx, uh[k] >> lb);  // weights of the trace-domain coset: a prefix in bit-reversed storage
-    inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p, xdens[k].p, uh[k] >> lb);
+  for (int pass = 0; pass < 2; pass++) {
+    // the short matrices' sums also read the tall points' weights: fork once those are queued
+    if (pass == 1 && use_side) ctx.side_fork();
+    for (size_t k = 0; k < upts.size(); k++) {
+      if ((int)(use_side && uh[k] <= short_h) != pass) continue;
+      SideScope sc(ctx, pass == 1);
+      dens[k] = DBuf<E2>(ctx, uh[k]);
+      xdens[k] = DBuf<E2>(ctx, uh[k] >> lb);  // weights of the trace-domain coset: a prefix in bit-reversed storage
+      inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p, xdens[k].p, uh[k] >> lb);
+    }
   }
 
   tr.mark("inv_denoms");
@@ -848,7 +867,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       total_vals += r.points[mi].size() * r.data->ldes[mi].w;
     }
   DBuf<E2> d_sums(ctx, std::max<size_t>(total_vals, 1));
-  {
+  for (int pass = 0; pass < 2; pass++) {
     size_t off = 0;
     for (auto& r : rounds)
       for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
@@ -856,9 +875,12 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         auto& pts = r.points[mi];
         if (pts.empty()) continue;
         int np = (int)pts.size();
-        const E2* d0 = xdens[point_index(pts[0])].p;
-        const E2* d1 = np == 2 ? xdens[point_index(pts[1])].p : d0;
-        bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off);
+        if ((int)(use_side && m.h <= short_h) == pass) {
+          SideScope sc(ctx, pass == 1);
+          const E2* d0 = xdens[point_index(pts[0])].p;
+          const E2* d1 = np == 2 ? xdens[point_index(pts[1])].p : d0;
+          bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off);
+        }
         off += np * m.w;
       }
   }
@@ -939,9 +961,11 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     }
   }
   std::vector<DBuf<E2>> inputs;  // descending height
+  if (use_side) ctx.side_fork();  // behind the upload of the alpha powers
   for (int lh = 32; lh >= 0; lh--) {
     if (!present[lh]) continue;
     size_t h = size_t(1) << lh;
+    SideScope sc(ctx, use_side && h <= short_h);
     DBuf<E2> ro(ctx, h);
     if (lists[lh].empty())
       HIP_CHECK(hipMemsetAsync(ro.p, 0, h * sizeof(E2), ctx.stream));
@@ -949,6 +973,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p, apow.data());
     inputs.push_back(std::move(ro));
   }
+  ctx.side_join();  // the short reduced openings read the tall points' denominators, released next
   for (auto& d : dens) d.reset();
   for (auto& d : xdens) d.reset();
   tr.mark("deep_reduce");
@@ -1404,20 +1429,46 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   }
   if (aidx.empty()) throw std::runtime_error("cannot prove with every circuit deactivated (all traces empty)");
   const size_t NA = aidx.size();
+  std::vector<unsigned> log_degrees;
+  for (size_t ci : aidx) log_degrees.push_back(log2_strict(wit.heights[ci]));
+  // Short circuits next to long ones (the byte table beside 2^20 additions): a short circuit's kernels are a handful of
+  // workgroups each and cost launch latency, not work, so within every phase they are queued on the context's side stream
+  // AFTER the long circuits' launches and run beside those; the streams join again before the phase's commitment.
+  std::vector<char> on_side(NA, 0);
+  std::vector<size_t> order;  // positions: long circuits first
+  ctx.side_config();
+  {
+    bool any_long = false, any_short = false;
+    for (size_t pos = 0; pos < NA; pos++) (log_degrees[pos] <= ctx.side_max_log ? any_short : any_long) = true;
+    const bool use_side = ctx.side_enabled && any_long && any_short;
+    for (size_t pos = 0; pos < NA; pos++) on_side[pos] = use_side && log_degrees[pos] <= ctx.side_max_log;
+    for (int pass = 0; pass < 2; pass++)
+      for (size_t pos = 0; pos < NA; pos++)
+        if ((int)on_side[pos] == pass) order.push_back(pos);
+  }
+  const bool use_side = order.size() && on_side[order.back()];
+  struct SideSession {  // whatever happens, the streams are joined when prove() is left
+    Ctx& c;
+    ~SideSession() { c.side_join(); }
+  } side_session{ctx};
+  auto fork_side = [&]() {
+    if (use_side && !ctx.side_forked) ctx.side_fork();
+  };
 
   // ---- stage 1 commit (src/prover.rs:336-351)
   t0 = now_ms();
   RoctxRange phase("stark/stage1_commit");
-  std::vector<unsigned> log_degrees;
   PcsData s1;
   {
-    std::vector<DMat> ldes;
+    std::vector<DMat> ldes(NA);
     up.wait_traces();
-    for (size_t ci : aidx) {
-      size_t h = wit.heights[ci];
-      log_degrees.push_back(log2_strict(h));
-      ldes.push_back(lde_of_host_matrix(ctx, wit.traces[ci].p, h, sys.circuits[ci].main_width, lb));
+    fork_side();
+    for (size_t pos : order) {
+      const size_t ci = aidx[pos];
+      SideScope sc(ctx, on_side[pos]);
+      ldes[pos] = lde_of_host_matrix(ctx, wit.traces[ci].p, wit.heights[ci], sys.circuits[ci].main_width, lb);
     }
+    ctx.side_join();
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
   }
   up.wait_claims();
@@ -1486,10 +1537,12 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   phase.next("stark/lookup_construction");
   up.lookup_values();
   std::vector<DBuf<u64>> s2_evals(NA);
-  for (size_t pos = 0; pos < NA; pos++) {
+  fork_side();  // behind the claims accumulator and the lookup values: the side stream sees d_tot and the witness complete
+  for (size_t pos : order) {
     size_t ci = aidx[pos];
     const HCircuit& c = sys.circuits[ci];
     size_t n = wit.heights[ci];
+    SideScope sc(ctx, on_side[pos]);
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
     stage2_circuit_async(ctx, sys, wit, ci, beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
   }
@@ -1498,18 +1551,21 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   phase.next("stark/stage2_commit");
   PcsData s2;
   {
-    std::vector<DMat> ldes;
-    for (size_t pos = 0; pos < NA; pos++) {
+    std::vector<DMat> ldes(NA);
+    fork_side();
+    for (size_t pos : order) {
       const HCircuit& c = sys.circuits[aidx[pos]];
       size_t n = wit.heights[aidx[pos]];
+      SideScope sc(ctx, on_side[pos]);
       DMat lde;
       lde.h = n << lb;
       lde.w = c.stage2_width;
       lde.buf = DBuf<u64>(ctx, lde.h * lde.w);
       coset_lde(ctx, s2_evals[pos].p, lde.d(), log_degrees[pos], lb, lde.w);
       s2_evals[pos].reset();
-      ldes.push_back(std::move(lde));
+      ldes[pos] = std::move(lde);
     }
+    ctx.side_join();
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s2);
   }
   ctx.d2h_queue(h_tot.data(), d_tot.p, (NA + 1) * sizeof(E2));
@@ -1533,11 +1589,13 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   phase.next("stark/quotient");
   PcsData qd;
   {
-    std::vector<DMat> qldes;
-    E2 acc_in = acc_initial;
-    for (size_t pos = 0; pos < NA; pos++) {
+    std::vector<DMat> qldes(NA);
+    fork_side();
+    for (size_t pos : order) {
       size_t ci = aidx[pos];
       const HCircuit& c = sys.circuits[ci];
+      SideScope sc(ctx, on_side[pos]);
+      const E2 acc_in = pos ? accs[pos - 1] : acc_initial;
       unsigned log_n = log_degrees[pos], log_q = log2_strict(c.quotient_degree());
       size_t n = size_t(1) << log_n, nq = n << log_q;
       QuotientArgs qa;
@@ -1560,14 +1618,14 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
       qa.alpha = alpha;
       DBuf<u64> qv(ctx, nq * 2);
       quotient_eval(ctx, c.prog, qa, qv.p);
-      acc_in = accs[pos];
       DMat lde;
       lde.h = n << lb;
       lde.w = 2 << log_q;
       lde.buf = DBuf<u64>(ctx, lde.h * lde.w);
       quotient_lde(ctx, qv.p, lde.d(), log_n, log_q, lb, 2);
-      qldes.push_back(std::move(lde));
+      qldes[pos] = std::move(lde);
     }
+    ctx.side_join();
     commit_matrices(ctx, std::move(qldes), (unsigned)prm.cap_height, qd);
   }
   std::vector<Digest> q_cap = merkle_cap(ctx, qd.tree);

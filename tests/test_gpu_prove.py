@@ -366,7 +366,7 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
 # host-side query step, no single-workgroup FRI tail, host sweep for the lookup values, interpreter kernels instead of
 # the hiprtc-compiled ones (the library reads these variables at call time)
 @pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE",
-                                 "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC"])
+                                 "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC", "MSAMD_NO_SIDE_STREAM"])
 def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     import os
 
@@ -499,3 +499,27 @@ def test_random_systems_differential(pkg, ctx, oracle, fe):
     finally:
         del os.environ["MSAMD_NO_JIT"]
     assert tally.get("proved", 0) + tally.get("verified", 0) >= 60, tally
+
+
+# the side stream (short circuits' launches queued beside the long circuits' - prover.hip) with the threshold pulled down
+# so that the small random systems split into "short" and "long" circuits in every possible way
+@pytest.mark.parametrize("max_log", ["2", "4", "6"])
+def test_random_systems_differential_side_stream(pkg, ctx, oracle, fe, max_log):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+
+    os.environ["MSAMD_NO_JIT"] = "1"
+    os.environ["MSAMD_SIDE_MAX_LOG"] = max_log
+    try:
+        rng = np.random.default_rng(4052 + int(max_log))
+        tally = {}
+        for case in range(60):
+            r = fuzz_parity.one_case(pkg, fe, oracle, ctx, np.random.default_rng(rng.integers(0, 1 << 62)), case)
+            tally[r] = tally.get(r, 0) + 1
+    finally:
+        del os.environ["MSAMD_NO_JIT"]
+        del os.environ["MSAMD_SIDE_MAX_LOG"]
+    assert tally.get("proved", 0) + tally.get("verified", 0) >= 30, tally
