@@ -93,6 +93,7 @@ struct BQuotientIn {
   unsigned log_n, log_q, log_blowup;
   E4 publics[4];  // beta, gamma, acc_initial, acc_final
   E4 alpha;
+  const msamd::JitKernel* jit = nullptr;  // the circuit's compiled kernel (quotient_jit.hip), or none: the interpreter runs
 };
 void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals);
 

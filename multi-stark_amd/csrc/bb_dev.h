@@ -4,9 +4,15 @@
 // p3-monty-31 itself keeps and serialises - so digests and opened values go into the proof as the raw device words.
 // Host and device share this header (the host runs the DuplexChallenger transcript).
 #pragma once
+#if defined(__HIPCC_RTC__)  // hiprtc (the per-circuit quotient kernel, quotient_jit.hip) has no standard library headers
+typedef unsigned long uint64_t;
+typedef unsigned int uint32_t;
+typedef unsigned long size_t;
+#else
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#endif
 
 namespace msbb {
 

@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "bb.h"
+#include "bb_quotient_params.h"
 
 namespace msbb {
 
@@ -819,24 +820,6 @@ u32 bb_grind(Ctx& ctx, const Poseidon2* d_perm, const u32* state16, const u32* p
 }
 
 // ------------------------------------------------------------------ quotient (src/prover.rs:756-962)
-struct QuotArgs {
-  const u32 *kind, *na, *nb;
-  unsigned n_nodes;
-  const u32* zeros;
-  unsigned n_zeros;
-  const u32 *lk_mult, *lk_off, *lk_args;
-  unsigned L;
-  const u32 *pre, *s1, *s2;
-  size_t pre_ld, s1_ld, s2_ld;
-  unsigned log_n, log_q;
-  u32 publics[16], delta[4];
-  const E4* apow;  // constraint_count weights: alpha^(count - 1 - j) for constraint j (src/prover.rs:798-808)
-  u32* out;
-  size_t out_ld;
-  u32* scratch;
-  size_t row0, rows, stride;
-  u32 g, w_big, gn_inv, g_pow_n, w_q;
-};
 __global__ __launch_bounds__(256) void quotient_k(QuotArgs p) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.rows) return;
@@ -932,6 +915,13 @@ void bb_quotient(Ctx& ctx, const BQuotientIn& in, BMat& q_evals) {
   p.out = q_evals.buf.p, p.out_ld = q_evals.ld;
   p.g = bb_to_monty(BB_GENERATOR), p.w_big = bb_two_adic_generator(log_big), p.gn_inv = bb_inv(g_n);
   p.g_pow_n = bb_exp_pow2(p.g, in.log_n), p.w_q = bb_two_adic_generator(in.log_q);
+  if (in.jit && in.jit->function && !getenv("MSAMD_NO_JIT")) {
+    // the circuit's own kernel (quotient_jit.hip): node values live in registers, no slot file, one launch
+    p.scratch = nullptr, p.stride = 0, p.row0 = 0, p.rows = N;
+    ProfScope prof(ctx, msamd::K_QUOTIENT, double(N) * (8.0 * double(in.s1->w + in.s2->w + (in.pre ? in.pre->w : 0)) + 16.0));
+    msamd::bb_quotient_jit_launch(ctx, *in.jit, &p, sizeof(p), N);
+    return;
+  }
   // rows in chunks, so that the slot file (nodes x rows words) stays bounded
   size_t chunk = std::min<size_t>(N, std::max<size_t>(256, (size_t(1) << 28) / std::max<size_t>(in.prog->n, 1) / 256 * 256));
   if (const char* e = getenv("MSBB_QUOTIENT_CHUNK")) chunk = std::min<size_t>(N, std::max<size_t>(64, (size_t)atoll(e)));  // tests

@@ -92,6 +92,7 @@ struct BCircuit {
   size_t main_width = 0, pre_width = 0, pre_height = 0, num_lookups = 0, stage2_width = 0, constraint_count = 0, max_constraint_degree = 0,
          args_width = 0, lookup_prefix_len = 0;
   BProgram prog;
+  msamd::JitKernel quotient_jit;  // this circuit's quotient kernel, compiled at system creation (quotient_jit.hip); may be empty
   BLookupsDev lk;
   DBuf<u32> d_zeros;
   BMat pre;  // preprocessed trace (column-major, Montgomery), for witness preparation
@@ -268,6 +269,7 @@ std::unique_ptr<BSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
     if (c.quotient_degree() > (size_t(1) << p.log_blowup))  // src/system.rs:171-178
       throw std::runtime_error("circuit " + std::to_string(ci) + ": constraint degree needs a quotient degree beyond the blowup");
     bb_build_program(ctx, c.nodes, c.prog);
+    msamd::bb_quotient_jit_build(c.nodes, c.zeros, c.lookups, c.quotient_jit);
     c.lk.L = nl;
     c.lk.mult = DBuf<u32>(ctx, std::max<size_t>(nl, 1));
     c.lk.arg_off = DBuf<u32>(ctx, nl + 1);
@@ -829,6 +831,7 @@ std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
       unsigned log_q = log2_strict(c.quotient_degree());
       BQuotientIn in;
       in.prog = &c.prog, in.lk = &c.lk, in.d_zeros = c.d_zeros.p, in.n_zeros = c.zeros.size(), in.constraint_count = c.constraint_count;
+      in.jit = &c.quotient_jit;
       in.pre = sys.has_pre && sys.pre_indices[ci] >= 0 ? &sys.pre_data.ldes[sys.pre_indices[ci]] : nullptr;
       in.s1 = &s1.ldes[pos], in.s2 = &s2.ldes[pos];
       in.log_n = log_degrees[pos], in.log_q = log_q, in.log_blowup = lb;

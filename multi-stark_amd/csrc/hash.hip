@@ -532,6 +532,42 @@ __global__ __launch_bounds__(256) void chunk_cv_k(const uint8_t* __restrict__ pr
   store_digest(out + ch, cv);
 }
 
+// The chunks that hold prefix bytes (normally chunk 0 alone): their bytes come from two sources at byte granularity, which
+// in chunk_cv_k is a byte-wise load path - one lane walking it made that lane the longest of the whole launch (58 us).
+// Here a wave assembles the chunk in LDS (four bytes per lane and step) and lane 0 runs the 16 dependent compressions.
+__global__ __launch_bounds__(64) void chunk_cv_prefix_k(const uint8_t* __restrict__ prefix, size_t pl, const u64* __restrict__ words,
+                                                        size_t len, size_t nchunks, size_t c0, Digest* out) {
+  __shared__ u32 sh[256];
+  const size_t ch = c0 + blockIdx.x;
+  const size_t off = ch * 1024;
+  const size_t clen = len - off < 1024 ? len - off : 1024;
+  for (u32 i = threadIdx.x; i < 256; i += 64) {
+    u32 wv = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u32 idx = 4 * i + k;
+      const u32 byte = idx < clen ? stream_byte(prefix, pl, words, off + idx) : 0;
+      wv |= byte << (8 * k);
+    }
+    sh[i] = wv;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const u32 nblocks = clen == 0 ? 1 : (u32)((clen + 63) / 64);
+  u32 cv[8];
+  b3_iv(cv);
+  const bool single = nchunks == 1;
+  for (u32 b = 0; b < nblocks; b++) {
+    u32 m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = sh[16 * b + i];
+    const u32 bl = (u32)(clen - size_t(b) * 64 < 64 ? clen - size_t(b) * 64 : 64);
+    const u32 flags = (b == 0 ? B3_CHUNK_START : 0) | (b == nblocks - 1 ? (B3_CHUNK_END | (single ? B3_ROOT : 0)) : 0);
+    b3_compress(cv, m, ch, bl, flags);
+  }
+  store_digest(out + ch, cv);
+}
+
 // one level of the left-full tree: pair adjacent chaining values, carry an odd last one up unchanged
 __global__ __launch_bounds__(256) void cv_level_k(const Digest* __restrict__ prev, Digest* __restrict__ next, size_t n_prev,
                                                   u32 root_flag) {
@@ -827,8 +863,14 @@ void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, cons
   const size_t len = prefix_len + 8 * nwords, nchunks = blake3_num_chunks(prefix_len, nwords);
   if (c1 > nchunks) c1 = nchunks;
   if (c0 >= c1) return;
-  hipLaunchKernelGGL(chunk_cv_k, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, ctx.stream, d_prefix, prefix_len, d_words, len,
-                     nchunks, c0, c1, cvs);
+  const size_t pc = std::min(c1, (prefix_len + 1023) / 1024);  // chunks below pc hold prefix bytes
+  if (c0 < pc) {
+    hipLaunchKernelGGL(chunk_cv_prefix_k, dim3((unsigned)(pc - c0)), dim3(64), 0, ctx.stream, d_prefix, prefix_len, d_words, len, nchunks, c0, cvs);
+    c0 = pc;
+  }
+  if (c0 < c1)
+    hipLaunchKernelGGL(chunk_cv_k, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, ctx.stream, d_prefix, prefix_len, d_words, len,
+                       nchunks, c0, c1, cvs);
   HIP_CHECK(hipGetLastError());
 }
 

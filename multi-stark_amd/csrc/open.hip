@@ -61,58 +61,90 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
   return v;
 }
 
-constexpr int BARY_ROWS = 32;  // rows per thread
-constexpr int BARY_COLS = 7;   // columns per workgroup: 4 lazy accumulators each stay in registers for the whole block
+constexpr int BARY_T = 128;     // threads per workgroup
+constexpr int BARY_ROWS = 32;  // rows per thread (the reduction of a thread's accumulators costs as much as ~6 rows of products)
+constexpr int BARY_COLS = 4;   // columns per workgroup: their split accumulators (gl_dev.h GlAccS) stay in registers for the whole block
 // partial[(blk * w + c) * np + p] = sum over the block's rows of col_c[i] * xden_p[i], xden_p[i] = x_i / (z_p - x_i).
-// grid = (row blocks, column groups): every thread walks BARY_ROWS rows of BARY_COLS columns with 160-bit lazy
-// accumulators and the cross-lane reduction happens once per block, not once per column
+// grid = (row blocks, column groups): every thread walks BARY_ROWS rows of BARY_COLS columns, two rows per step with
+// all of the step's loads issued before its products (at 2-3 waves per SIMD the loop is otherwise a chain of load
+// latencies), accumulates unreduced, and the cross-lane reduction happens once per block through LDS.
 template <int NP>
-__global__ __launch_bounds__(256) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
+__global__ __launch_bounds__(BARY_T) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
                                                       const E2* __restrict__ xden0, const E2* __restrict__ xden1,
-                                                      E2* __restrict__ partial) {
-  __shared__ u64 sh[4][BARY_COLS][NP * 2];
+                                                      E2* __restrict__ partial, u32 nblk, u32 ngrp) {
+  constexpr int NV = BARY_COLS * NP * 2;  // sums per thread
+  __shared__ u64 sh[NV][BARY_T + 1];
   const size_t h = size_t(1) << log_h;
-  const size_t base = blockIdx.x * size_t(256 * BARY_ROWS);
-  const u32 c0 = blockIdx.y * BARY_COLS;
+  // Every column group of a row block reads the same weights (32 bytes per row against 8 per column): the linear
+  // workgroup id is decoded so that the groups of one row block follow each other on ONE XCD (workgroups are dealt
+  // round-robin to the 8 XCDs) and the weights enter that XCD's L2 once.
+  const u32 lin = blockIdx.x;
+  const u32 blk = (lin / (8 * ngrp)) * 8 + (lin & 7);
+  if (blk >= nblk) return;
+  const u32 grp = (lin >> 3) % ngrp;
+  const size_t base = blk * size_t(BARY_T * BARY_ROWS);
+  const u32 c0 = grp * BARY_COLS;
   const u32 nc = w - c0 < (u32)BARY_COLS ? w - c0 : (u32)BARY_COLS;
   const u64* __restrict__ col0 = mat + size_t(c0) * mat_h;
-  GlAcc acc[BARY_COLS][NP * 2];
+  GlAccS acc[BARY_COLS][NP * 2];
 #pragma unroll
   for (int c = 0; c < BARY_COLS; c++)
 #pragma unroll
-    for (int j = 0; j < NP * 2; j++) acc_init(acc[c][j]);
-  for (int k = 0; k < BARY_ROWS; k++) {
-    const size_t i = base + size_t(k) * 256 + threadIdx.x;
-    if (i >= h) break;
-    E2 xd[NP];
-    xd[0] = xden0[i];
-    if (NP == 2) xd[1] = xden1[i];
-    u64 v[BARY_COLS];
+    for (int j = 0; j < NP * 2; j++) accs_init(acc[c][j]);
+  // software pipeline: the loads of step k + 1 are issued before the products of step k
+  E2 xd[2][2][NP];
+  u64 v[2][2][BARY_COLS];
+  // every load is unconditional (clamped addresses, data selected afterwards): a load under a branch would make the
+  // compiler wait for ALL outstanding loads before the products, and the prefetch would hide nothing. Columns past the
+  // matrix's width re-read column 0; their sums are never written.
+  auto fetch = [&](int k, int buf) {
 #pragma unroll
-    for (int c = 0; c < BARY_COLS; c++) v[c] = (u32)c < nc ? col0[size_t(c) * mat_h + i] : 0;
-#pragma unroll
-    for (int c = 0; c < BARY_COLS; c++) {
-#pragma unroll
-      for (int p = 0; p < NP; p++) {
-        acc_mad(acc[c][2 * p], xd[p].c0, v[c]);
-        acc_mad(acc[c][2 * p + 1], xd[p].c1, v[c]);
+    for (int u = 0; u < 2; u++) {
+      const size_t i = base + size_t(k + u) * BARY_T + threadIdx.x;
+      const bool in = i < h;  // rows past the end contribute zeros
+      const size_t ii = in ? i : 0;
+      const E2 a = xden0[ii];
+      xd[buf][u][0] = e2(in ? a.c0 : 0, in ? a.c1 : 0);
+      if (NP == 2) {
+        const E2 b = xden1[ii];
+        xd[buf][u][NP - 1] = e2(in ? b.c0 : 0, in ? b.c1 : 0);
       }
-    }
-  }
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int c = 0; c < BARY_COLS; c++) {
-#pragma unroll
-    for (int j = 0; j < NP * 2; j++) {
-      u64 a = wave_sum(acc_reduce(acc[c][j]));
-      if (lane == 0) sh[wave][c][j] = a;
+      for (int c = 0; c < BARY_COLS; c++) v[buf][u][c] = col0[size_t((u32)c < nc ? c : 0) * mat_h + ii];
     }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int k = 0; k < BARY_ROWS; k += 2) {
+    const int buf = (k >> 1) & 1;
+    if (k + 2 < BARY_ROWS) fetch(k + 2, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);  // the scheduler would otherwise sink the prefetch down to its first use
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int c = 0; c < BARY_COLS; c++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          accs_mad(acc[c][2 * p], xd[buf][u][p].c0, v[buf][u][c]);
+          accs_mad(acc[c][2 * p + 1], xd[buf][u][p].c1, v[buf][u][c]);
+        }
   }
+#pragma unroll
+  for (int c = 0; c < BARY_COLS; c++)
+#pragma unroll
+    for (int j = 0; j < NP * 2; j++) sh[c * NP * 2 + j][threadIdx.x] = accs_reduce(acc[c][j]);
   __syncthreads();
-  if (threadIdx.x < nc * NP * 2) {
-    const u32 c = threadIdx.x / (NP * 2), j = threadIdx.x % (NP * 2);
-    u64 s = gl_add(gl_add(sh[0][c][j], sh[1][c][j]), gl_add(sh[2][c][j], sh[3][c][j]));
-    u64* dst = reinterpret_cast<u64*>(partial + (size_t(blockIdx.x) * w + c0 + c) * NP);
+  // BARY_T / NV threads per sum, NV entries each, then a shuffle tree inside the group
+  constexpr int TPV = BARY_T / NV;
+  const u32 val = threadIdx.x / TPV, part = threadIdx.x % TPV;
+  u64 s = 0;
+#pragma unroll
+  for (int e = 0; e < NV; e++) s = gl_add(s, sh[val][e * TPV + part]);
+#pragma unroll
+  for (int m = TPV / 2; m > 0; m >>= 1) s = gl_add(s, (u64)__shfl_xor((unsigned long long)s, m, 64));
+  const u32 c = val / (NP * 2), j = val % (NP * 2);
+  if (part == 0 && c < nc) {
+    u64* dst = reinterpret_cast<u64*>(partial + (size_t(blk) * w + c0 + c) * NP);
     dst[j] = s;
   }
 }
@@ -155,11 +187,11 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
   for (u32 m = 0; m < p.nmats; m++) {
     const DeepMat& dm = p.mats[m];
     // sum_c alpha^c * m[i][c]: base x ext terms, accumulated unreduced (one reduction per coordinate)
-    GlAcc a00, a01, a10, a11;
-    acc_init(a00);
-    acc_init(a01);
-    acc_init(a10);
-    acc_init(a11);
+    GlAccS a00, a01, a10, a11;
+    accs_init(a00);
+    accs_init(a01);
+    accs_init(a10);
+    accs_init(a11);
     const u64* __restrict__ md = dm.d + i;
     const u32 mw = dm.w;
     u32 c = 0;
@@ -170,21 +202,21 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const E2 a = apow[c + u];
-        acc_mad(a00, a.c0, v[u].x);
-        acc_mad(a01, a.c1, v[u].x);
-        acc_mad(a10, a.c0, v[u].y);
-        acc_mad(a11, a.c1, v[u].y);
+        accs_mad(a00, a.c0, v[u].x);
+        accs_mad(a01, a.c1, v[u].x);
+        accs_mad(a10, a.c0, v[u].y);
+        accs_mad(a11, a.c1, v[u].y);
       }
     }
     for (; c < mw; c++) {
       const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(md + size_t(c) * p.height);
       const E2 a = apow[c];
-      acc_mad(a00, a.c0, v.x);
-      acc_mad(a01, a.c1, v.x);
-      acc_mad(a10, a.c0, v.y);
-      acc_mad(a11, a.c1, v.y);
+      accs_mad(a00, a.c0, v.x);
+      accs_mad(a01, a.c1, v.x);
+      accs_mad(a10, a.c0, v.y);
+      accs_mad(a11, a.c1, v.y);
     }
-    const u64 s00 = acc_reduce(a00), s01 = acc_reduce(a01), s10 = acc_reduce(a10), s11 = acc_reduce(a11);
+    const u64 s00 = accs_reduce(a00), s01 = accs_reduce(a01), s10 = accs_reduce(a10), s11 = accs_reduce(a11);
     for (u32 k = 0; k < dm.npoints; k++) {
       // (c0 + c1 X)(s0 + s1 X) = c0 s0 + 7 c1 s1 + (c0 s1 + c1 s0) X
       const u64 c0 = dm.coeff[k].c0, c1 = dm.coeff[k].c1, c7 = dm.coeff7[k];
@@ -603,16 +635,17 @@ void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned 
                      E2* out_dev) {
   if (npoints == 0) return;
   size_t h = size_t(1) << log_h;
-  size_t nblk = (h + 256 * BARY_ROWS - 1) / (256 * BARY_ROWS);
+  size_t nblk = (h + BARY_T * BARY_ROWS - 1) / (BARY_T * BARY_ROWS);
   size_t ngrp = (w + BARY_COLS - 1) / BARY_COLS;
-  if (ngrp > 65535) throw std::runtime_error("bary: matrix too wide");
+  const size_t nlin = ((nblk + 7) / 8) * 8 * ngrp;
+  if (nlin > 0x7fffffffu) throw std::runtime_error("bary: matrix too large");
   DBuf<E2> partial(ctx, nblk * w * npoints);  // stream-ordered reuse keeps it valid until bary_final_k has run
   hipEvent_t ev = ctx.prof_begin(K_BARY);
-  dim3 grid((unsigned)nblk, (unsigned)ngrp);
+  dim3 grid((unsigned)nlin);
   if (npoints == 1)
-    hipLaunchKernelGGL(bary_partial_k<1>, grid, dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden0, partial.p);
+    hipLaunchKernelGGL(bary_partial_k<1>, grid, dim3(BARY_T), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden0, partial.p, (u32)nblk, (u32)ngrp);
   else
-    hipLaunchKernelGGL(bary_partial_k<2>, grid, dim3(256), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden1, partial.p);
+    hipLaunchKernelGGL(bary_partial_k<2>, grid, dim3(BARY_T), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden1, partial.p, (u32)nblk, (u32)ngrp);
   size_t tot = w * npoints;
   hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, out_dev);
   ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);

@@ -24,6 +24,10 @@ struct QParams;
 void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
                         const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, size_t quotient_degree, JitKernel& out);
 void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq);
+// the same for the BabyBear / Ext4 configuration (argument block: msbb::QuotArgs of bb_quotient_params.h, passed as bytes)
+void bb_quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                           const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out);
+void bb_quotient_jit_launch(Ctx& ctx, const JitKernel& k, const void* args, size_t args_size, size_t rows);
 // the circuit's stage-2 terms kernel (messages, batch inverse, mult / message) for its list of argument counts
 struct Stage2Params;
 struct Stage2TraceParams;

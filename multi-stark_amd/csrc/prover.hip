@@ -1455,6 +1455,41 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     if (use_side && !ctx.side_forked) ctx.side_fork();
   };
 
+  // claims, length-prefixed (src/prover.rs:369-373). Large claim sets are hashed on the device: the transcript since the
+  // last sample is `ch.input || words`, and the next operation is a sample, so the digest is all the challenger needs.
+  // The stage-1 commitment is part of that prefix; it is patched in on the device, so the commitment and the digest come
+  // back in ONE synchronisation. Only the BLAKE3 chunks that hold prefix bytes depend on the commitment: the chaining
+  // values of all the others - 41 000 of them at the bench size, latency-bound work - are computed on the side stream
+  // while the stage-1 tree is hashed, and what is left behind the commitment is chunk 0 and the tree above the chunks.
+  const size_t n_claims = wit.claim_offsets.size() - 1;
+  const size_t claim_elems = wit.claim_data.size();
+  const size_t claim_words = 1 + n_claims + claim_elems;
+  const bool device_claims = claim_words > 8192;
+  const bool early_claims = device_claims && ctx.side_enabled;
+  size_t max_lde_log = 0;
+  for (unsigned ld : log_degrees) max_lde_log = std::max<size_t>(max_lde_log, ld + lb);
+  const size_t ncap = size_t(1) << std::min<size_t>((size_t)prm.cap_height, max_lde_log);
+  std::vector<Digest> s1_cap;
+  size_t cap_off = 0, prefix_chunks = 0, nchunks = 0;
+  DBuf<u64> d_words;
+  DBuf<Digest> d_cvs;
+  if (device_claims) {
+    s1_cap.assign(ncap, Digest());
+    if (sys.has_pre) ch.observe_cap(sys.pre_commit);
+    cap_off = ch.input.size();
+    ch.observe_cap(s1_cap);  // placeholder bytes: the real digests are copied over them on the device
+    for (unsigned ld : log_degrees) ch.observe(ld);
+    nchunks = blake3_num_chunks(ch.input.size(), claim_words);
+    prefix_chunks = std::min(nchunks, (ch.input.size() + 1023) / 1024);
+  }
+  auto claims_chunks = [&]() {  // everything of the claims digest that does not depend on the stage-1 commitment
+    up.wait_claims();
+    d_words = DBuf<u64>(ctx, claim_words);
+    claims_transcript_words(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, claim_elems, d_words.p);
+    d_cvs = DBuf<Digest>(ctx, nchunks);
+    blake3_chunk_cvs(ctx, nullptr, ch.input.size(), d_words.p, claim_words, prefix_chunks, nchunks, d_cvs.p);
+  };
+
   // ---- stage 1 commit (src/prover.rs:336-351)
   t0 = now_ms();
   RoctxRange phase("stark/stage1_commit");
@@ -1469,18 +1504,15 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
       ldes[pos] = lde_of_host_matrix(ctx, wit.traces[ci].p, wit.heights[ci], sys.circuits[ci].main_width, lb);
     }
     ctx.side_join();
+    if (early_claims) {
+      // beside the leaf hashing and the tree levels of the commitment (integer-ALU work), not beside the transposes
+      ctx.side_fork();
+      SideScope sc(ctx, true);
+      claims_chunks();
+    }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
   }
   up.wait_claims();
-  // claims, length-prefixed (src/prover.rs:369-373). Large claim sets are hashed on the device: the transcript
-  // since the last sample is `ch.input || words`, and the next operation is a sample, so the digest is all
-  // the challenger needs. The stage-1 commitment is part of that prefix; it is patched in on the device, so the
-  // commitment and the digest come back in ONE synchronisation.
-  const size_t n_claims = wit.claim_offsets.size() - 1;
-  const size_t claim_elems = wit.claim_data.size();
-  const size_t claim_words = 1 + n_claims + claim_elems;
-  const bool device_claims = claim_words > 8192;
-  std::vector<Digest> s1_cap;
   if (!device_claims) {
     s1_cap = merkle_cap(ctx, s1.tree);
     lap(0);
@@ -1495,21 +1527,20 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
   } else {
     lap(0);
-    const size_t cl = s1.tree.cap_layer(), ncap = s1.tree.layer_len[cl];
+    const size_t cl = s1.tree.cap_layer();
+    if (s1.tree.layer_len[cl] != ncap) throw std::runtime_error("stage-1 cap size differs from the transcript's placeholder");
     const Digest* d_cap = s1.tree.base() + s1.tree.layer_off[cl];
-    s1_cap.assign(ncap, Digest());
-    if (sys.has_pre) ch.observe_cap(sys.pre_commit);
-    const size_t cap_off = ch.input.size();
-    ch.observe_cap(s1_cap);  // placeholder bytes: the real digests are copied over them on the device
-    for (unsigned ld : log_degrees) ch.observe(ld);
     DBuf<uint8_t> d_prefix(ctx, ch.input.size());
     ctx.h2d(d_prefix.p, ch.input.data(), ch.input.size());
     HIP_CHECK(hipMemcpyAsync(d_prefix.p + cap_off, d_cap, ncap * sizeof(Digest), hipMemcpyDeviceToDevice, ctx.stream));
-    DBuf<u64> d_words(ctx, claim_words);
-    claims_transcript_words(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, claim_elems, d_words.p);
+    if (!early_claims) claims_chunks();
+    ctx.side_join();
+    blake3_chunk_cvs(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, 0, prefix_chunks, d_cvs.p);
     ctx.d2h_queue(s1_cap.data(), d_cap, ncap * sizeof(Digest));
-    Digest d = blake3_device(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words);  // synchronises: s1_cap has arrived too
+    Digest d = blake3_from_cvs(ctx, d_cvs.p, nchunks);  // synchronises: s1_cap has arrived too
     ch.flush_with(d);
+    d_words.reset();
+    d_cvs.reset();
   }
   const E2 beta = ch.sample_ext();
   ch.observe_ext(beta);

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <sstream>
 
+#include "bb_dev.h"
 #include "host.h"
 #include "lookup_params.h"
 #include "quotient_params.h"
@@ -88,10 +89,10 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
     }
     o << ";\n";
   }
-  o << "  GlAcc fa0, fa1;\n  acc_init(fa0);\n  acc_init(fa1);\n";
+  o << "  GlAccS fa0, fa1;\n  accs_init(fa0);\n  accs_init(fa1);\n";
   size_t ci = 0;
   for (auto z : zeros) {
-    o << "  { const E2 a = " << AR << "[" << ci << "]; acc_mad(fa0, v" << z << ", a.c0); acc_mad(fa1, v" << z << ", a.c1); }\n";
+    o << "  { const E2 a = " << AR << "[" << ci << "]; accs_mad(fa0, v" << z << ", a.c0); accs_mad(fa1, v" << z << ", a.c1); }\n";
     ci++;
   }
   o << "  const u64 beta0 = p.publics[0], beta1 = p.publics[1];\n"
@@ -99,8 +100,8 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
        "  (void)beta0; (void)beta1;\n";
   auto fold2 = [&](const std::string& c0, const std::string& c1) {
     o << "  { const E2 a = " << AR << "[" << ci << "], b = " << AR << "[" << ci + 1 << "];\n"
-      << "    acc_mad(fa0, " << c0 << ", a.c0); acc_mad(fa0, " << c1 << ", b.c0);\n"
-      << "    acc_mad(fa1, " << c0 << ", a.c1); acc_mad(fa1, " << c1 << ", b.c1); }\n";
+      << "    accs_mad(fa0, " << c0 << ", a.c0); accs_mad(fa0, " << c1 << ", b.c0);\n"
+      << "    accs_mad(fa1, " << c0 << ", a.c1); accs_mad(fa1, " << c1 << ", b.c1); }\n";
     ci += 2;
   };
   const size_t L = lookups.size();
@@ -144,8 +145,111 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
   }
   o << (inl ? "  const u64 iv = p.zh_inv_in[qi & 7];\n" : "  const u64 iv = p.zh_inv[qi];\n")
     <<
-       "  p.out[t] = gl_mul(acc_reduce(fa0), iv);\n"
-       "  p.out[nq + t] = gl_mul(acc_reduce(fa1), iv);\n}\n";
+       "  p.out[t] = gl_mul(accs_reduce(fa0), iv);\n"
+       "  p.out[nq + t] = gl_mul(accs_reduce(fa1), iv);\n}\n";
+  return o.str();
+}
+
+// The BabyBear / Ext4 configuration's quotient kernel (bb_kernels.hip quotient_k is the interpreter it replaces: node
+// values in a slot file in global memory, nodes x rows words). Same structure as above over 31-bit Montgomery words:
+// selectors, the node program as locals, user constraints, logUp constraints as E4 products (src/lookup.rs:152-256),
+// alpha fold, division by the vanishing polynomial.
+std::string bb_circuit_source(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                              const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups) {
+  const size_t nn = nodes.size();
+  std::vector<char> needed(nn, 0);
+  for (auto z : zeros) needed[z] = 1;
+  for (auto& l : lookups) {
+    needed[l.first] = 1;
+    for (auto a : l.second) needed[a] = 1;
+  }
+  for (size_t i = nn; i-- > 0;) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    if (n.kind == OP_ADD || n.kind == OP_SUB || n.kind == OP_MUL) needed[n.a] = needed[n.b] = 1;
+    if (n.kind == OP_NEG) needed[n.a] = 1;
+  }
+  std::ostringstream o;
+  o << "#include \"bb_quotient_params.h\"\nusing namespace msbb;\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void bb_quotient_jit(QuotArgs p) {\n"
+       "  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;\n"
+       "  if (t >= p.rows) return;\n"
+       "  const unsigned log_big = p.log_n + p.log_q;\n"
+       "  const size_t N = size_t(1) << log_big, q = size_t(1) << p.log_q;\n"
+       "  const size_t st = p.row0 + t;\n"
+       "  const size_t i = quot_bitrev(st, log_big);\n"
+       "  const size_t st_next = quot_bitrev((i + q) & (N - 1), log_big);\n"
+       "  const u32 x = bb_mul(p.g, bb_pow(p.w_big, i));\n"
+       "  const u32 zh = bb_sub(bb_mul(p.g_pow_n, bb_pow(p.w_q, i & (q - 1))), BB_R1);\n"
+       "  const u32 d1 = bb_sub(x, BB_R1), d2 = bb_sub(x, p.gn_inv);\n"
+       "  const u32 d12 = bb_mul(d1, d2);\n"
+       "  const u32 all_inv = bb_inv(bb_mul(d12, zh));\n"
+       "  const u32 inv_zh = bb_mul(all_inv, d12);\n"
+       "  const u32 inv12 = bb_mul(all_inv, zh);\n"
+       "  const u32 is_first = bb_mul(zh, bb_mul(inv12, d2)), is_last = bb_mul(zh, bb_mul(inv12, d1)), is_trans = d2;\n"
+       "  (void)is_first; (void)is_last; (void)is_trans; (void)st_next;\n";
+  for (size_t i = 0; i < nn; i++) {
+    if (!needed[i]) continue;
+    const PNode& n = nodes[i];
+    o << "  const u32 v" << i << " = ";
+    switch (n.kind) {
+      case OP_CONST: o << msbb::bb_to_monty((uint32_t)n.a) << "u"; break;
+      case OP_VAR: {
+        const char* src = n.source == 1 ? "s1" : n.source == 0 ? "pre" : "s2";
+        o << "p." << src << "[size_t(" << n.a << ") * p." << src << "_ld + " << (n.offset ? "st_next" : "st") << "]";
+        break;
+      }
+      case OP_PUBLIC: o << "p.publics[" << n.a << "]"; break;
+      case OP_IS_FIRST: o << "is_first"; break;
+      case OP_IS_LAST: o << "is_last"; break;
+      case OP_IS_TRANS: o << "is_trans"; break;
+      case OP_ADD: o << "bb_add(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_SUB: o << "bb_sub(v" << n.a << ", v" << n.b << ")"; break;
+      case OP_MUL: o << "bb_mul(v" << n.a << ", v" << n.b << ")"; break;
+      default: o << "bb_neg(v" << n.a << ")"; break;
+    }
+    o << ";\n";
+  }
+  o << "  E4 acc = e4_zero();\n";
+  size_t cj = 0;
+  for (auto z : zeros) o << "  acc = e4_add(acc, e4_mul_base(p.apow[" << cj++ << "], v" << z << "));\n";
+  o << "  const E4 beta = E4{{p.publics[0], p.publics[1], p.publics[2], p.publics[3]}};\n"
+       "  const E4 gamma = E4{{p.publics[4], p.publics[5], p.publics[6], p.publics[7]}};\n"
+       "  (void)beta; (void)gamma;\n"
+       "  const E4 inj = E4{{bb_mul(is_last, p.delta[0]), bb_mul(is_last, p.delta[1]), bb_mul(is_last, p.delta[2]), bb_mul(is_last, p.delta[3])}};\n";
+  auto s2_at = [&](const char* row, size_t slot) {
+    std::ostringstream e;
+    e << "E4{{";
+    for (int k = 0; k < 4; k++) e << (k ? ", " : "") << "p.s2[size_t(" << 4 * slot + k << ") * p.s2_ld + " << row << "]";
+    e << "}}";
+    return e.str();
+  };
+  auto fold4 = [&](const std::string& c) {
+    for (int k = 0; k < 4; k++) o << "  acc = e4_add(acc, e4_mul_base(p.apow[" << cj++ << "], " << c << ".c[" << k << "]));\n";
+  };
+  const size_t L = lookups.size();
+  if (L == 0) {
+    o << "  const E4 pt = e4_add(e4_sub(" << s2_at("st_next", 0) << ", " << s2_at("st", 0) << "), inj);\n";
+    fold4("pt");
+  } else {
+    o << "  const E4 run0 = " << s2_at("st", 0) << ";\n";
+    for (size_t j = 0; j < L; j++) {
+      const auto& l = lookups[j];
+      if (j + 1 < L)
+        o << "  const E4 run" << j + 1 << " = " << s2_at("st", j + 1) << ";\n";
+      else
+        o << "  const E4 run" << j + 1 << " = e4_add(" << s2_at("st_next", 0) << ", inj);\n";
+      o << "  E4 c" << j << ";\n  {\n    E4 f = e4_zero();\n";
+      for (size_t k = l.second.size(); k-- > 0;) o << "    f = e4_mul(f, gamma); f.c[0] = bb_add(f.c[0], v" << l.second[k] << ");\n";
+      o << "    c" << j << " = e4_mul(e4_add(f, beta), e4_sub(run" << j + 1 << ", run" << j << "));\n"
+        << "    c" << j << ".c[0] = bb_sub(c" << j << ".c[0], v" << l.first << ");\n  }\n";
+      std::ostringstream c;
+      c << "c" << j;
+      fold4(c.str());
+    }
+  }
+  o << "  acc = e4_mul_base(acc, inv_zh);\n"
+       "  for (int k = 0; k < 4; k++) p.out[(size_t)k * p.out_ld + i] = acc.c[k];\n}\n";
   return o.str();
 }
 
@@ -235,7 +339,7 @@ const std::vector<char>* code_object(const std::string& src) {
   const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", inc.c_str()};
   std::string key = arch + '\0' + std::to_string(rtc.version) + '\0' + "-O3 -std=c++17" + '\0';
   // the headers are part of the program: a change to the field arithmetic must not reuse old code objects
-  for (const char* hdr : {"/csrc/gl_dev.h", "/csrc/quotient_params.h", "/csrc/lookup_params.h"}) {
+  for (const char* hdr : {"/csrc/gl_dev.h", "/csrc/quotient_params.h", "/csrc/lookup_params.h", "/csrc/bb_dev.h", "/csrc/bb_quotient_params.h"}) {
     std::vector<char> t;
     if (read_file(dir + hdr, t)) key.append(t.begin(), t.end());
     key += '\0';
@@ -464,6 +568,19 @@ void quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint3
   const bool inl = inline_tables_fit(zeros.size(), lookups.size(), quotient_degree);
   load_kernel(code_object(circuit_source(nodes, zeros, lookups, inl)), "quotient_jit", out);
   out.inline_tables = out.function && inl;
+}
+
+void bb_quotient_jit_build(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
+                           const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, JitKernel& out) {
+  if (getenv("MSAMD_NO_JIT") || nodes.size() > 3000) return;
+  load_kernel(code_object(bb_circuit_source(nodes, zeros, lookups)), "bb_quotient_jit", out);
+}
+
+void bb_quotient_jit_launch(Ctx& ctx, const JitKernel& k, const void* args, size_t args_size, size_t rows) {
+  std::vector<char> copy((const char*)args, (const char*)args + args_size);
+  size_t size = args_size;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, copy.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((rows + 255) / 256), 1, 1, 256, 1, 1, 0, ctx.stream, nullptr, config));
 }
 
 void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out) {

@@ -217,12 +217,26 @@ def test_device_side_fri_transcript(ctx, monkeypatch, var):
 
 
 def test_quotient_row_chunks(ctx, monkeypatch):
-    """the quotient sweep in several row chunks (what a very large trace x node-program product triggers)"""
+    """the interpreter quotient kernel (what runs without hiprtc, above 3000 nodes and under MSAMD_NO_JIT) with its sweep
+    in several row chunks (what a very large trace x node-program product triggers)"""
+    monkeypatch.setenv("MSAMD_NO_JIT", "1")
     monkeypatch.setenv("MSBB_QUOTIENT_CHUNK", "192")
     with fe.field(fe.BABYBEAR):
         assert _prove_both(ctx, fe.Params(2, 0, 0, 1, 10, 0, 0), fe.squares_inputs(), fe.squares_traces(256), [])[0] == 0  # 1024 rows
         inputs, trace = fe.mul_air_inputs(), fe.mul_air_trace(1 << 9)
     assert _prove_both(ctx, fe.test_params(), inputs, [trace], [])[0] == 0
+
+
+def test_interpreter_quotient_with_lookups(ctx, monkeypatch):
+    """MSAMD_NO_JIT=1: the per-circuit hiprtc quotient kernels (the default) replaced by the interpreter, on systems with
+    lookups, claims, a preprocessed table and mixed heights - same bytes as the oracle either way"""
+    monkeypatch.setenv("MSAMD_NO_JIT", "1")
+    with fe.field(fe.BABYBEAR):
+        inputs, traces = fe.even_odd_inputs(), fe.even_odd_traces()
+        assert _prove_both(ctx, fe.test_params(), inputs, traces, [[0, 4, 1]])[0] == 0
+        inputs = fe.u32_add_system_inputs()
+        traces, claims = fe.u32_add_bench_witness(1 << 8)
+        assert _prove_both(ctx, fe.Params(2, 0, 0, 1, 20, 2, 2), inputs, traces, claims)[0] == 0
 
 
 def test_error_paths(ctx):
