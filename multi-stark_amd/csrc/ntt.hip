@@ -590,6 +590,39 @@ __global__ void transpose_in_k(const u64* __restrict__ in, u64* __restrict__ out
   }
 }
 
+// The same with rows bit-reversed, for h >= 256. A block of 64 consecutive storage rows is 64 input rows that lie h / 64
+// rows apart: every read a lone row (112 bytes at the bench's width). Here a tile is 16 x 16 storage rows
+// rr = (A : mid : B), A the top and B the low four bits, i.e. natural rows (rev B : rev mid : rev A): for each of the 16
+// values of B the 16 values of A are CONSECUTIVE input rows (one run of 16 w words), and for each A the 16 values of B
+// are consecutive storage rows (128-byte runs per column). Columns go through LDS 16 at a time.
+__global__ __launch_bounds__(256) void transpose_in_br_k(const u64* __restrict__ in, u64* __restrict__ out, size_t h, size_t w,
+                                                         unsigned logh) {
+  __shared__ u64 tile[256][17];
+  const u32 mid = blockIdx.x;
+  const size_t rmid = size_t(bitrev32(mid, logh - 8)) << 4;
+  const u32 t = threadIdx.x;
+  const u32 lo = t & 15, hi = t >> 4;
+  for (size_t c0 = 0; c0 < w; c0 += 16) {
+    const u32 cols = (u32)((w - c0) < 16 ? (w - c0) : 16);
+    // read: thread (hi = natural low bits a, lo = column), 16 runs u = natural top bits
+    if (lo < cols) {
+      const u32 A = bitrev32(hi, 4);
+#pragma unroll 4
+      for (u32 u = 0; u < 16; u++) {
+        const size_t r = (size_t(u) << (logh - 4)) | rmid | hi;
+        tile[A * 16 + bitrev32(u, 4)][lo] = in[r * w + c0 + lo];
+      }
+    }
+    __syncthreads();
+    // write: thread (hi = A, lo = B), one column per step
+    {
+      const size_t rr = (size_t(hi) << (logh - 4)) | (size_t(mid) << 4) | lo;
+      for (u32 c = 0; c < cols; c++) out[(c0 + c) * h + rr] = tile[hi * 16 + lo][c];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void transpose_out_k(const u64* __restrict__ in, u64* __restrict__ out, size_t h, size_t w, unsigned logh,
                                 int bitrev_rows) {
   size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
@@ -713,8 +746,12 @@ void quotient_lde(Ctx& ctx, u64* qvals_bitrev, u64* lde, unsigned logn, unsigned
 void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, bool bitrev_rows) {
   if (h * w == 0) return;
   hipEvent_t ev = ctx.prof_begin(K_TRANSPOSE);
-  hipLaunchKernelGGL(transpose_in_k, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w,
-                     log2_strict(h), bitrev_rows ? 1 : 0);
+  const unsigned logh = log2_strict(h);
+  if (bitrev_rows && logh >= 8 && (size_t(1) << logh) == h && !getenv("MSAMD_OLD_TRANSPOSE"))
+    hipLaunchKernelGGL(transpose_in_br_k, dim3((unsigned)(h >> 8)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh);
+  else
+    hipLaunchKernelGGL(transpose_in_k, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
+                       bitrev_rows ? 1 : 0);
   ctx.prof_end(K_TRANSPOSE, ev, 16.0 * double(h) * double(w));
 }
 

@@ -48,6 +48,30 @@ void subtree_cv(const uint8_t* in, size_t len, u64 chunk_index, u32 root_flag, u
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// MSAMD_TRACE_HOST=1: host-side time stamps of one proof (where the host is when; printed when prove() returns)
+struct HostProbes {
+  bool on = false;
+  double t0 = 0;
+  std::vector<std::pair<const char*, double>> marks;
+  void start() {
+    on = getenv("MSAMD_TRACE_HOST") != nullptr;
+    marks.clear();
+    t0 = now_ms();
+  }
+  void mark(const char* what) {
+    if (on) marks.emplace_back(what, now_ms());
+  }
+  void print() const {
+    if (!on) return;
+    double prev = t0;
+    for (auto& m : marks) {
+      fprintf(stderr, "[msamd]   %-34s at %8.1f us (+%7.1f)\n", m.first, 1e3 * (m.second - t0), 1e3 * (m.second - prev));
+      prev = m.second;
+    }
+  }
+};
+thread_local HostProbes g_probes;
 }  // namespace
 
 void blake3_host(const uint8_t* in, size_t len, uint8_t out[32]) {
@@ -885,7 +909,9 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       }
   }
   std::vector<E2> h_sums(std::max<size_t>(total_vals, 1));
+  g_probes.mark("opened values queued");
   ctx.d2h(h_sums.data(), d_sums.p, total_vals * sizeof(E2));
+  g_probes.mark("sync 4 (opened values)");
   {
     size_t off = 0;
     for (auto& r : rounds) {
@@ -1216,7 +1242,9 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     std::vector<FriTailRound> recs(n_total);
     fin.resize(stop);
     ctx.d2h_queue(recs.data(), d_recs.p, n_total * sizeof(FriTailRound));
+    g_probes.mark("FRI queued");
     ctx.d2h(fin.data(), fin_src, stop * sizeof(E2));  // the one synchronisation of the FRI phase
+    g_probes.mark("sync 5 (FRI)");
     fin_hold.reset();
     for (size_t k = 0; k < n_total; k++) {
       Digest root;
@@ -1395,6 +1423,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   if (wit.sys != &sys || wit.heights.size() != C) throw std::runtime_error("witness does not belong to this system");
   if (wit.has_remote) throw std::runtime_error("this witness lacks traces that another rank computes: use ms_prove_sharded");
   double t_begin = now_ms(), t0;
+  g_probes.start();
   auto lap = [&](int slot) {
     if (times) {
       ctx.sync();
@@ -1405,6 +1434,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   RoctxRange whole("stark/prove");
   HostUpload up(wit, ctx);  // host-resident witness: uploads start now and run beside the transcript set-up
   up.start();
+  g_probes.mark("uploads issued");
   Challenger ch(sys.seed);
   // src/system.rs:211-222
   ch.observe((u64)C);
@@ -1512,6 +1542,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s1);
   }
+  g_probes.mark("stage 1 queued");
   up.wait_claims();
   if (!device_claims) {
     s1_cap = merkle_cap(ctx, s1.tree);
@@ -1538,6 +1569,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     blake3_chunk_cvs(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, 0, prefix_chunks, d_cvs.p);
     ctx.d2h_queue(s1_cap.data(), d_cap, ncap * sizeof(Digest));
     Digest d = blake3_from_cvs(ctx, d_cvs.p, nchunks);  // synchronises: s1_cap has arrived too
+    g_probes.mark("sync 1 (cap + claims digest)");
     ch.flush_with(d);
     d_words.reset();
     d_cvs.reset();
@@ -1600,7 +1632,9 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     commit_matrices(ctx, std::move(ldes), (unsigned)prm.cap_height, s2);
   }
   ctx.d2h_queue(h_tot.data(), d_tot.p, (NA + 1) * sizeof(E2));
+  g_probes.mark("stage 2 queued");
   std::vector<Digest> s2_cap = merkle_cap(ctx, s2.tree);  // synchronises: h_tot is complete as well
+  g_probes.mark("sync 2 (stage-2 cap)");
   const E2 acc_initial = h_tot[0];
   std::vector<E2> accs;
   {
@@ -1659,7 +1693,9 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     ctx.side_join();
     commit_matrices(ctx, std::move(qldes), (unsigned)prm.cap_height, qd);
   }
+  g_probes.mark("quotient queued");
   std::vector<Digest> q_cap = merkle_cap(ctx, qd.tree);
+  g_probes.mark("sync 3 (quotient cap)");
   ch.observe_cap(q_cap);
   lap(3);
 
@@ -1721,6 +1757,8 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   write_round(w, opened[1]);
   ctx.prof_collect();
   if (times) times->v[5] = now_ms() - t_begin;
+  g_probes.mark("proof bytes complete");
+  g_probes.print();
   if (getenv("MSAMD_TRACE_HOST")) fprintf(stderr, "[msamd] prove(): %.1f us in all\n", 1e3 * (now_ms() - t_begin));
   return std::move(w.b);
 }

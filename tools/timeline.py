@@ -5,7 +5,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last proof = from the last transpose_in_k of the big trace backwards: take kernels after the 2nd-to-last claims_words_k
-idx = [i for i, r in enumerate(rows) if "transpose_in_k" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "transpose_in" in r["Kernel_Name"]]
 start = idx[-2] if len(idx) >= 2 else 0
 # find beginning of last proof: last pair of transpose_in (byte table + main)
 rows = rows[start:]

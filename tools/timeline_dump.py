@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "transpose_in_k" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "transpose_in" in r["Kernel_Name"]]
 rows = rows[idx[-2]:]
 t0 = int(rows[0]["Start_Timestamp"])
 prev = t0
