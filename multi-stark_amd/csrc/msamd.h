@@ -224,6 +224,8 @@ void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64
 // row-major host layout (h x w) on device -> column-major, optionally with rows bit-reversed
 void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, bool bitrev_rows);
 void transpose_out(Ctx& ctx, const u64* colmajor, u64* rowmajor, size_t h, size_t w, bool bitrev_rows);
+// out[i] = the i-th little-endian `bytes`-byte value of `packed` (bytes = 1, 2, 4), on `stream`
+void widen_words(const uint8_t* packed, unsigned bytes, size_t count, u64* out, hipStream_t stream);
 // coefficients (unscaled inverse DFT output, natural order, column-major n x w) -> bit-reversed coset LDE (Bn x w)
 void lde_from_coeffs(Ctx& ctx, const u64* coef, u64* lde, unsigned logn, unsigned log_blowup, size_t w);
 // evaluations in bit-reversed row order (column-major n x w, destroyed) -> bit-reversed coset LDE (Bn x w)

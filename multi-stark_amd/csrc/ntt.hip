@@ -755,6 +755,50 @@ void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t
   ctx.prof_end(K_TRANSPOSE, ev, 16.0 * double(h) * double(w));
 }
 
+namespace {
+// four values per thread: one 4 / 8 / 16-byte load, two 16-byte stores
+template <class T>
+struct Vec4;
+template <>
+struct Vec4<uint8_t> {
+  typedef uchar4 type;
+};
+template <>
+struct Vec4<uint16_t> {
+  typedef ushort4 type;
+};
+template <>
+struct Vec4<uint32_t> {
+  typedef uint4 type;
+};
+template <class T>
+__global__ __launch_bounds__(256) void widen_k(const T* __restrict__ in, size_t count, u64* __restrict__ out) {
+  const size_t i = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * 4;
+  if (i + 4 <= count) {
+    const typename Vec4<T>::type q = reinterpret_cast<const typename Vec4<T>::type*>(in)[i >> 2];
+    ulonglong2 a, b;
+    a.x = q.x, a.y = q.y, b.x = q.z, b.y = q.w;
+    *reinterpret_cast<ulonglong2*>(out + i) = a;
+    *reinterpret_cast<ulonglong2*>(out + i + 2) = b;
+  } else {
+    for (size_t k = i; k < count; k++) out[k] = in[k];
+  }
+}
+}  // namespace
+void widen_words(const uint8_t* packed, unsigned bytes, size_t count, u64* out, hipStream_t stream) {
+  if (!count) return;
+  const dim3 grid((unsigned)((count + 1023) / 1024)), block(256);
+  if (bytes == 1)
+    hipLaunchKernelGGL(widen_k<uint8_t>, grid, block, 0, stream, packed, count, out);
+  else if (bytes == 2)
+    hipLaunchKernelGGL(widen_k<uint16_t>, grid, block, 0, stream, reinterpret_cast<const uint16_t*>(packed), count, out);
+  else if (bytes == 4)
+    hipLaunchKernelGGL(widen_k<uint32_t>, grid, block, 0, stream, reinterpret_cast<const uint32_t*>(packed), count, out);
+  else
+    throw std::runtime_error("widen_words: unsupported width");
+  HIP_CHECK(hipGetLastError());
+}
+
 void transpose_out(Ctx& ctx, const u64* colmajor, u64* rowmajor, size_t h, size_t w, bool bitrev_rows) {
   if (h * w == 0) return;
   hipLaunchKernelGGL(transpose_out_k, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, ctx.stream, colmajor, rowmajor, h,

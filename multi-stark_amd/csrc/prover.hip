@@ -9,7 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 
 #include "host.h"
 
@@ -504,6 +508,137 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
   return w;
 }
 
+// ------------------------------------------------------------------ narrowing a host trace before its upload
+namespace {
+// values[i] -> `pb`-byte little-endian words; returns the OR of everything read (the caller checks the bits above 8 pb)
+u64 narrow_range(const u64* in, uint8_t* out, unsigned pb, size_t n) {
+  u64 acc = 0;
+  if (pb == 1) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      const u64 a0 = in[i], a1 = in[i + 1], a2 = in[i + 2], a3 = in[i + 3], a4 = in[i + 4], a5 = in[i + 5], a6 = in[i + 6], a7 = in[i + 7];
+      acc |= a0 | a1 | a2 | a3 | a4 | a5 | a6 | a7;
+      const u64 w = (a0 & 0xff) | (a1 & 0xff) << 8 | (a2 & 0xff) << 16 | (a3 & 0xff) << 24 | (a4 & 0xff) << 32 | (a5 & 0xff) << 40 |
+                    (a6 & 0xff) << 48 | (a7 & 0xff) << 56;
+      memcpy(out + i, &w, 8);
+    }
+    for (; i < n; i++) {
+      acc |= in[i];
+      out[i] = (uint8_t)in[i];
+    }
+  } else if (pb == 2) {
+    uint16_t* o = reinterpret_cast<uint16_t*>(out);
+    for (size_t i = 0; i < n; i++) {
+      acc |= in[i];
+      o[i] = (uint16_t)in[i];
+    }
+  } else {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    for (size_t i = 0; i < n; i++) {
+      acc |= in[i];
+      o[i] = (uint32_t)in[i];
+    }
+  }
+  return acc;
+}
+
+// A handful of persistent host threads (MSAMD_PACK_THREADS, default 8; the process keeps them for its lifetime). One job at
+// a time: the element range is cut into chunks, every chunk into one piece per worker; pieces are claimed in order, so
+// the chunks complete in order and the caller uploads chunk k while the workers narrow chunk k + 1.
+class PackPool {
+ public:
+  static PackPool* get() {
+    static PackPool* pool = []() -> PackPool* {
+      int n = 8;
+      if (const char* e = getenv("MSAMD_PACK_THREADS")) n = atoi(e);
+      if (n <= 0) return nullptr;
+      if (n > 64) n = 64;
+      return new PackPool(n);  // never destroyed: the threads end with the process
+    }();
+    return pool;
+  }
+  static constexpr size_t MAX_CHUNKS = 64;
+  size_t n_chunks = 0;
+  // starts narrowing in[0 .. cnt) into out; chunk k covers elements [chunk_begin(k), chunk_begin(k + 1))
+  void start(const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks) {
+    job_mu_.lock();  // one job at a time (contexts on other threads wait here); released by finish()
+    std::unique_lock<std::mutex> lk(mu_);
+    in_ = in, out_ = out, pb_ = pb, cnt_ = cnt;
+    n_chunks = std::max<size_t>(1, std::min(chunks, MAX_CHUNKS));
+    per_chunk_ = ((cnt + n_chunks - 1) / n_chunks + 63) & ~size_t(63);
+    n_chunks = (cnt + per_chunk_ - 1) / per_chunk_;
+    next_.store(0);
+    acc_.store(0);
+    for (size_t k = 0; k < n_chunks; k++) left_[k].store((int)threads_.size());
+    busy_ = (int)threads_.size();
+    gen_++;
+    cv_.notify_all();
+  }
+  size_t chunk_begin(size_t k) const { return std::min(cnt_, k * per_chunk_); }
+  // waits until chunk k is complete; false = some value read so far does not fit `pb` bytes
+  bool wait_chunk(size_t k) {
+    while (left_[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    return (acc_.load() >> (8 * pb_)) == 0;
+  }
+  // every worker has left the job (its buffers may be reused or freed)
+  void finish() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      done_cv_.wait(lk, [&] { return busy_ == 0; });
+    }
+    job_mu_.unlock();
+  }
+  struct Job {  // start ... finish, also when an error unwinds the caller
+    PackPool& p;
+    Job(PackPool& pool, const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks) : p(pool) { p.start(in, out, pb, cnt, chunks); }
+    ~Job() { p.finish(); }
+  };
+
+ private:
+  explicit PackPool(int n) {
+    for (int i = 0; i < n; i++) threads_.emplace_back([this]() { run(); });
+    for (auto& t : threads_) t.detach();
+  }
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+      }
+      const size_t nsub = threads_.size(), items = n_chunks * nsub;
+      for (;;) {
+        const size_t it = next_.fetch_add(1);
+        if (it >= items) break;
+        const size_t k = it / nsub, sub = it % nsub;
+        const size_t b = chunk_begin(k), e = chunk_begin(k + 1);
+        const size_t piece = (((e - b) + nsub - 1) / nsub + 7) & ~size_t(7);
+        const size_t lo = std::min(e, b + sub * piece), hi = std::min(e, lo + piece);
+        if (hi > lo) acc_.fetch_or(narrow_range(in_ + lo, out_ + lo * pb_, pb_, hi - lo));
+        left_[k].fetch_sub(1, std::memory_order_release);
+      }
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (--busy_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_, job_mu_;
+  std::condition_variable cv_, done_cv_;
+  uint64_t gen_ = 0;
+  int busy_ = 0;
+  const u64* in_ = nullptr;
+  uint8_t* out_ = nullptr;
+  unsigned pb_ = 1;
+  size_t cnt_ = 0, per_chunk_ = 0;
+  std::atomic<size_t> next_{0};
+  std::atomic<u64> acc_{0};
+  std::atomic<int> left_[MAX_CHUNKS];
+};
+}  // namespace
+
 // ------------------------------------------------------------------ host-resident SystemWitness
 // The reference's prove() is handed a witness that lives in host memory (benches/multi_stark.rs:292-296,
 // src/prover.rs:290-295). Nothing is uploaded here: the caller's buffers are page-locked so that the per-proof uploads
@@ -528,6 +663,9 @@ HWitness::~HWitness() {
     for (auto& e : st.ev)
       if (e) (void)hipEventDestroy(e);
   for (void* p : registered) (void)hipHostUnregister(p);
+  for (uint8_t* p : h_packed)
+    if (p) (void)hipHostFree(p);
+  (void)hipGetLastError();  // (a range the caller has already freed or re-registered: nothing to report, nothing to leave behind)
 }
 
 std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* traces, const u64* heights, size_t n_claims,
@@ -543,6 +681,11 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
   w->h_traces.assign(C, nullptr);
   w->h_mult.resize(C);
   w->h_args.resize(C);
+  w->pack_bytes.assign(C, 0);
+  w->h_packed.assign(C, nullptr);
+  size_t pack_min = size_t(4) << 20;  // below this the plain upload takes less than waking the threads
+  if (const char* e = getenv("MSAMD_PACK_MIN_BYTES")) pack_min = (size_t)atoll(e);
+  const bool may_pack = !getenv("MSAMD_NO_PACK") && PackPool::get() != nullptr;
   for (size_t ci = 0; ci < C; ci++) {
     const HCircuit& c = sys.circuits[ci];
     const size_t h = heights[ci];
@@ -557,10 +700,23 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
       continue;
     }
     const size_t cnt = h * c.main_width;
-    for (size_t i = 0; i < cnt; i++)
+    u64 seen = 0;
+    for (size_t i = 0; i < cnt; i++) {
       if (traces[ci][i] >= GL_P) throw std::runtime_error("non-canonical trace value");
+      seen |= traces[ci][i];
+    }
     w->h_traces[ci] = traces[ci];
     w->pin(traces[ci], cnt * 8);
+    if (may_pack && cnt * 8 >= pack_min && (seen >> 32) == 0) {
+      const unsigned pb = (seen >> 8) == 0 ? 1 : (seen >> 16) == 0 ? 2 : 4;
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, cnt * pb, hipHostMallocDefault) == hipSuccess) {
+        w->pack_bytes[ci] = pb;
+        w->h_packed[ci] = (uint8_t*)hp;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     DLookups& lk = w->lookups[ci];
     lk.height = h;
     lk.num_lookups = c.num_lookups;
@@ -621,14 +777,37 @@ struct HostUpload {
     // buffers first: pool blocks handed out here may still be in use by kernels queued earlier on ctx.stream
     HIP_CHECK(hipEventRecord(ctx.copy_ev[3], ctx.stream));
     HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[3], 0));
+    std::vector<DBuf<uint8_t>> narrow(C);  // released when the proof's uploads have been waited for (the destructor's sync)
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
       if (!h || !w.h_traces[ci]) continue;  // inactive, or computed by another rank
-      st.traces[ci] = DBuf<u64>(ctx, h * c.main_width);
-      HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], h * c.main_width * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+      const size_t cnt = h * c.main_width;
+      st.traces[ci] = DBuf<u64>(ctx, cnt);
+      const unsigned pb = w.pack_bytes[ci];
+      PackPool* pool = pb && !w.prefetch ? PackPool::get() : nullptr;  // (a prefetch already travels behind the running proof)
+      bool sent = false;
+      if (pool) {
+        // the host threads narrow chunk k + 1 while chunk k crosses the link; the device widens the whole trace afterwards
+        narrow[ci] = DBuf<uint8_t>(ctx, cnt * pb);
+        {
+          PackPool::Job job(*pool, w.h_traces[ci], w.h_packed[ci], pb, cnt, 16);
+          sent = true;
+          for (size_t k = 0; k < pool->n_chunks; k++) {
+            if (!pool->wait_chunk(k)) {  // a value outgrew the width found at creation: the plain path below
+              sent = false;
+              break;
+            }
+            const size_t b = pool->chunk_begin(k), e = pool->chunk_begin(k + 1);
+            HIP_CHECK(hipMemcpyAsync(narrow[ci].p + b * pb, w.h_packed[ci] + b * pb, (e - b) * pb, hipMemcpyHostToDevice, ctx.copy_stream));
+          }
+        }
+        if (sent) widen_words(narrow[ci].p, pb, cnt, st.traces[ci].p, ctx.copy_stream);
+      }
+      if (!sent) HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], cnt * 8, hipMemcpyHostToDevice, ctx.copy_stream));
     }
     HIP_CHECK(hipEventRecord(st.ev[0], ctx.copy_stream));
+    st.narrow = std::move(narrow);
     st.has_host_lookups = false;
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
@@ -700,6 +879,7 @@ struct HostUpload {
     // this proof's copies may still be in flight when it is abandoned: wait before the blocks return to the pool (a
     // prefetch queued behind them is then complete as well, which costs nothing: it is shorter than the proof)
     (void)hipStreamSynchronize(ctx.copy_stream);
+    w.stage[w.cur].narrow.clear();
     for (auto& t : w.traces) t.reset();
     for (auto& lk : w.lookups) {
       lk.mult.reset();

@@ -201,6 +201,48 @@ def test_host_resident_witness(pkg, ctx, oracle, fe, case):
             g.host_witness(bad, packed)
 
 
+# The narrow upload of a host-resident witness (traces whose values fit 1 / 2 / 4 bytes are narrowed on host threads,
+# uploaded chunk by chunk and widened on the device): forced on small systems (MSAMD_PACK_MIN_BYTES=0) for every width
+# class, against the plain upload (MSAMD_NO_PACK) and the oracle; a value that outgrows the width found at creation
+# (the caller may rewrite its buffers between proofs) must send the proof down the plain path, not corrupt it
+@pytest.mark.parametrize("case", ["bytes", "u16", "u32", "wide", "bench12"])
+def test_host_resident_witness_narrow_upload(pkg, ctx, oracle, fe, case, monkeypatch):
+    monkeypatch.setenv("MSAMD_PACK_MIN_BYTES", "0")
+    if case == "bench12":
+        traces, claims = fe.u32_add_bench_witness(1 << 12)
+        inputs, params = fe.u32_add_system_inputs(), fe.bench_params()
+    else:
+        # the Pythagorean circuit a^2 + b^2 = c^2 takes any field elements: rows scaled to the width class under test
+        top = {"bytes": 1 << 8, "u16": 1 << 16, "u32": 1 << 32, "wide": 1 << 63}[case]
+        t = fe.pythagorean_trace(64).copy()
+        assert int(t.max()) < 256
+        if case != "bytes":
+            # (3k, 4k, 5k) stays a Pythagorean triple: scale one row so that the largest value lands in the class
+            k = (top - 1) // int(t[1].max())
+            t[1] = t[1] * np.uint64(k)
+        traces, claims, inputs, params = [np.ascontiguousarray(t, dtype=np.uint64)], [], fe.pythagorean_inputs(), fe.test_params()
+    g = pkg.System.new(ctx, params, inputs)
+    packed = fe.pack_claims(claims)
+    want = oracle.System(g.blob).prove(traces, packed)
+    hw = g.host_witness(traces, packed)
+    for _ in range(3):
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+    monkeypatch.setenv("MSAMD_NO_PACK", "1")
+    plain = g.host_witness(traces, packed)
+    assert g.prove_multiple_claims(plain).to_bytes() == want
+    monkeypatch.delenv("MSAMD_NO_PACK")
+    if case in ("bytes", "u16", "u32"):
+        # the caller rewrites its buffer between proofs: a wider value, then back
+        kept = hw.keep[0]
+        old = kept[5].copy()
+        kept[5] = old * np.uint64(1 << 40)   # still a Pythagorean triple, far outside the width class
+        t2 = [kept.copy()]
+        got = g.prove_multiple_claims(hw).to_bytes()
+        assert got == oracle.System(g.blob).prove(t2, packed)
+        kept[5] = old
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+
+
 # ms_witness_prefetch: each proof of a host-resident witness also uploads the inputs of the next one; same bytes, also
 # across switching it on and off, interleaved with other witnesses, and after an injected mid-proof failure
 def test_host_witness_prefetch(pkg, ctx, oracle, fe):
