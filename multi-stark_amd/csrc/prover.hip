@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -542,18 +546,56 @@ u64 narrow_range(const u64* in, uint8_t* out, unsigned pb, size_t n) {
   return acc;
 }
 
-// A handful of persistent host threads (MSAMD_PACK_THREADS, default 8; the process keeps them for its lifetime). One job at
+// A handful of persistent host threads (MSAMD_PACK_THREADS, default 16; the process keeps them for its lifetime). One job at
 // a time: the element range is cut into chunks, every chunk into one piece per worker; pieces are claimed in order, so
 // the chunks complete in order and the caller uploads chunk k while the workers narrow chunk k + 1.
+// the CPUs of the NUMA node that holds the page at `addr`, intersected with what this process may run on (empty: unknown)
+std::vector<int> cpus_near(const void* addr) {
+  std::vector<int> out;
+  int node = -1;
+#if defined(SYS_get_mempolicy)
+  if (!addr || syscall(SYS_get_mempolicy, &node, nullptr, 0UL, const_cast<void*>(addr), 3UL /* MPOL_F_NODE | MPOL_F_ADDR */) != 0) node = -1;
+#endif
+  if (node < 0) return out;
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return out;
+  char buf[4096];
+  const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+  fclose(f);
+  buf[got] = 0;
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+  for (char* p = buf; *p;) {  // "0-63,128-191"
+    char* e = nullptr;
+    long a = strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    if (*e == '-') {
+      p = e + 1;
+      b = strtol(p, &e, 10);
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (CPU_ISSET((int)c, &allowed)) out.push_back((int)c);
+    p = *e == ',' ? e + 1 : e;
+    if (*e != ',') break;
+  }
+  return out;
+}
+
 class PackPool {
  public:
-  static PackPool* get() {
-    static PackPool* pool = []() -> PackPool* {
-      int n = 8;
+  // `near`: an address inside the first trace that will be narrowed. The workers are kept on the NUMA node that holds it
+  // (a box with two sockets otherwise schedules half of them a socket away from the data: slower and erratic)
+  static PackPool* get(const void* near = nullptr) {
+    static PackPool* pool = [near]() -> PackPool* {
+      int n = 16;
       if (const char* e = getenv("MSAMD_PACK_THREADS")) n = atoi(e);
       if (n <= 0) return nullptr;
       if (n > 64) n = 64;
-      return new PackPool(n);  // never destroyed: the threads end with the process
+      return new PackPool(n, getenv("MSAMD_PACK_NO_AFFINITY") ? std::vector<int>() : cpus_near(near));  // never destroyed
     }();
     return pool;
   }
@@ -595,8 +637,14 @@ class PackPool {
   };
 
  private:
-  explicit PackPool(int n) {
+  PackPool(int n, const std::vector<int>& cpus) {
     for (int i = 0; i < n; i++) threads_.emplace_back([this]() { run(); });
+    if ((int)cpus.size() >= n) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      for (int c : cpus) CPU_SET(c, &set);
+      for (auto& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);  // best effort
+    }
     for (auto& t : threads_) t.detach();
   }
   void run() {
@@ -685,7 +733,10 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
   w->h_packed.assign(C, nullptr);
   size_t pack_min = size_t(4) << 20;  // below this the plain upload takes less than waking the threads
   if (const char* e = getenv("MSAMD_PACK_MIN_BYTES")) pack_min = (size_t)atoll(e);
-  const bool may_pack = !getenv("MSAMD_NO_PACK") && PackPool::get() != nullptr;
+  const void* first_trace = nullptr;  // the tallest one
+  for (size_t ci = 0, best = 0; ci < C; ci++)
+    if (heights[ci] > best && traces[ci]) first_trace = traces[ci], best = heights[ci];
+  const bool may_pack = !getenv("MSAMD_NO_PACK") && PackPool::get(first_trace) != nullptr;
   for (size_t ci = 0; ci < C; ci++) {
     const HCircuit& c = sys.circuits[ci];
     const size_t h = heights[ci];
@@ -791,18 +842,21 @@ struct HostUpload {
         // the host threads narrow chunk k + 1 while chunk k crosses the link; the device widens the whole trace afterwards
         narrow[ci] = DBuf<uint8_t>(ctx, cnt * pb);
         {
-          PackPool::Job job(*pool, w.h_traces[ci], w.h_packed[ci], pb, cnt, 16);
+          static const size_t n_chunks = getenv("MSAMD_PACK_CHUNKS") ? (size_t)atoi(getenv("MSAMD_PACK_CHUNKS")) : 8;
+          PackPool::Job job(*pool, w.h_traces[ci], w.h_packed[ci], pb, cnt, n_chunks);
           sent = true;
           for (size_t k = 0; k < pool->n_chunks; k++) {
             if (!pool->wait_chunk(k)) {  // a value outgrew the width found at creation: the plain path below
               sent = false;
               break;
             }
+            if (k == 0) g_probes.mark("narrow upload: first chunk ready");
             const size_t b = pool->chunk_begin(k), e = pool->chunk_begin(k + 1);
             HIP_CHECK(hipMemcpyAsync(narrow[ci].p + b * pb, w.h_packed[ci] + b * pb, (e - b) * pb, hipMemcpyHostToDevice, ctx.copy_stream));
+            widen_words(narrow[ci].p + b * pb, pb, e - b, st.traces[ci].p + b, ctx.copy_stream);  // behind its chunk: only the last one is exposed
           }
+          g_probes.mark("narrow upload: last chunk queued");
         }
-        if (sent) widen_words(narrow[ci].p, pb, cnt, st.traces[ci].p, ctx.copy_stream);
       }
       if (!sent) HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], cnt * 8, hipMemcpyHostToDevice, ctx.copy_stream));
     }
