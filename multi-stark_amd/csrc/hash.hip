@@ -39,7 +39,10 @@ struct RowIter {
       cur = g[mi].d + row;
       w = g[mi].w;
     }
-    u64 v = *cur;
+    // the matrix pointers come out of a descriptor in memory, so the compiler only knows them as generic pointers and
+    // would emit flat loads (which also count against the LDS counter); they are device allocations: say so
+    typedef const u64 __attribute__((address_space(1))) * GlobalPtr;
+    u64 v = *(GlobalPtr)cur;
     cur += H;
     c++;
     return v;

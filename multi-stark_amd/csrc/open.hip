@@ -192,13 +192,17 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
     accs_init(a01);
     accs_init(a10);
     accs_init(a11);
+    // (the matrix pointer comes out of a descriptor in memory: tell the compiler it is a device allocation, or it emits
+    // flat loads, which also count against the LDS counter)
+    typedef unsigned long long Pair __attribute__((ext_vector_type(2)));
+    typedef const Pair __attribute__((address_space(1))) * GlobalPair;
     const u64* __restrict__ md = dm.d + i;
     const u32 mw = dm.w;
     u32 c = 0;
     for (; c + 8 <= mw; c += 8) {  // eight 16-byte loads in flight per lane before the first use
-      ulonglong2 v[8];
+      Pair v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const ulonglong2*>(md + size_t(c + u) * p.height);
+      for (int u = 0; u < 8; u++) v[u] = *(GlobalPair)(md + size_t(c + u) * p.height);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const E2 a = apow[c + u];
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
       }
     }
     for (; c < mw; c++) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(md + size_t(c) * p.height);
+      const Pair v = *(GlobalPair)(md + size_t(c) * p.height);
       const E2 a = apow[c];
       accs_mad(a00, a.c0, v.x);
       accs_mad(a01, a.c1, v.x);
