@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmstark_hip.so")
 SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "prover.hip", "verifier.hip", "witness_gen.hip", "capi.hip",
-           "comm_rccl.hip", "bb_kernels.hip", "bb_prover.hip"]
+           "comm_rccl.hip", "bb_kernels.hip", "bb_prover.hip", "pack_host.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -31,13 +31,14 @@ def build(force=False, verbose=False):
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_mtime):
             jobs.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        flags = [f for f in FLAGS if not f.startswith("--offload-arch")] if src.endswith(".cpp") else FLAGS  # plain host C++
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-6000:]))
@@ -47,7 +48,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if jobs or force or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -513,39 +513,10 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
 }
 
 // ------------------------------------------------------------------ narrowing a host trace before its upload
+// values[i] -> `pb`-byte little-endian words; returns the OR of everything read (the caller checks the bits above 8 pb);
+// pack_host.cpp (plain host C++: AVX-512 where the CPU has it)
+u64 narrow_range(const u64* in, uint8_t* out, unsigned pb, size_t n);
 namespace {
-// values[i] -> `pb`-byte little-endian words; returns the OR of everything read (the caller checks the bits above 8 pb)
-u64 narrow_range(const u64* in, uint8_t* out, unsigned pb, size_t n) {
-  u64 acc = 0;
-  if (pb == 1) {
-    size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-      const u64 a0 = in[i], a1 = in[i + 1], a2 = in[i + 2], a3 = in[i + 3], a4 = in[i + 4], a5 = in[i + 5], a6 = in[i + 6], a7 = in[i + 7];
-      acc |= a0 | a1 | a2 | a3 | a4 | a5 | a6 | a7;
-      const u64 w = (a0 & 0xff) | (a1 & 0xff) << 8 | (a2 & 0xff) << 16 | (a3 & 0xff) << 24 | (a4 & 0xff) << 32 | (a5 & 0xff) << 40 |
-                    (a6 & 0xff) << 48 | (a7 & 0xff) << 56;
-      memcpy(out + i, &w, 8);
-    }
-    for (; i < n; i++) {
-      acc |= in[i];
-      out[i] = (uint8_t)in[i];
-    }
-  } else if (pb == 2) {
-    uint16_t* o = reinterpret_cast<uint16_t*>(out);
-    for (size_t i = 0; i < n; i++) {
-      acc |= in[i];
-      o[i] = (uint16_t)in[i];
-    }
-  } else {
-    uint32_t* o = reinterpret_cast<uint32_t*>(out);
-    for (size_t i = 0; i < n; i++) {
-      acc |= in[i];
-      o[i] = (uint32_t)in[i];
-    }
-  }
-  return acc;
-}
-
 // A handful of persistent host threads (MSAMD_PACK_THREADS, default 16; the process keeps them for its lifetime). One job at
 // a time: the element range is cut into chunks, every chunk into one piece per worker; pieces are claimed in order, so
 // the chunks complete in order and the caller uploads chunk k while the workers narrow chunk k + 1.
