@@ -146,6 +146,48 @@ __global__ __launch_bounds__(256) void leaf_hash_k(const MatRef* __restrict__ g,
   store_digest(out + row, cv);
 }
 
+// The tallest group of a commitment is almost always ONE matrix of at most 128 columns (one BLAKE3 chunk per row). The
+// general kernel above walks descriptor lists with data-dependent loops around every load, which leaves the compiler no
+// room: the loads sit under branches and everything outstanding is waited for in front of each compression. Here the
+// column pointer is a kernel argument, every load is unconditional (the last block re-reads the last column and masks
+// it) and the loads of block b + 1 are issued in front of the compression of block b.
+__global__ __launch_bounds__(256) void leaf_hash_single_k(const u64* __restrict__ d, size_t H, u32 w, Digest* __restrict__ out) {
+  const size_t row = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (row >= H) return;
+  const u64* __restrict__ p = d + row;
+  const u32 nblocks = (w + 7) >> 3, last_c = w - 1;
+  u32 cv[8];
+  b3_iv(cv);
+  u64 cur[8], nxt[8];
+#pragma unroll
+  for (u32 j = 0; j < 8; j++) cur[j] = p[size_t(j < last_c ? j : last_c) * H];
+  for (u32 b = 0; b + 1 < nblocks; b++) {  // full blocks with more input behind them
+    const u32 c0 = 8 * (b + 1);
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) nxt[j] = p[size_t(c0 + j < last_c ? c0 + j : last_c) * H];
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the rounds
+    u32 m[16];
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+      m[2 * j] = (u32)cur[j];
+      m[2 * j + 1] = (u32)(cur[j] >> 32);
+    }
+    b3_compress(cv, m, 0, 64, b == 0 ? B3_CHUNK_START : 0);
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) cur[j] = nxt[j];
+  }
+  const u32 nvalid = w - 8 * (nblocks - 1);
+  u32 m[16];
+#pragma unroll
+  for (u32 j = 0; j < 8; j++) {
+    const u64 v = j < nvalid ? cur[j] : 0;
+    m[2 * j] = (u32)v;
+    m[2 * j + 1] = (u32)(v >> 32);
+  }
+  b3_compress(cv, m, 0, nvalid * 8, (nblocks == 1 ? B3_CHUNK_START : 0) | B3_CHUNK_END | B3_ROOT);
+  store_digest(out + row, cv);
+}
+
 // next[i] = compress(prev[2i], prev[2i+1]); with an injected group: compress(that, hash(rows i))
 template <bool INJECT, bool MULTI>
 __global__ __launch_bounds__(256) void compress_layer_k(const Digest* __restrict__ prev, Digest* __restrict__ next, size_t n,
@@ -831,7 +873,9 @@ void merkle_build(Ctx& ctx, DTree& t) {
     // descriptor list must end at the group's end: RowIter walks by widths, total_w bounds it
     dim3 grid((unsigned)((maxh + 255) / 256));
     hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
-    if (tw <= 128)
+    if (tw <= 128 && count == 1 && !getenv("MSAMD_GENERIC_LEAF_HASH"))
+      hipLaunchKernelGGL(leaf_hash_single_k, grid, dim3(256), 0, ctx.stream, t.mat_d[order[first]], maxh, tw, t.base());
+    else if (tw <= 128)
       hipLaunchKernelGGL(leaf_hash_k<false>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.base());
     else
       hipLaunchKernelGGL(leaf_hash_k<true>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.base());
