@@ -582,15 +582,18 @@ class PackPool {
     n_chunks = (cnt + per_chunk_ - 1) / per_chunk_;
     next_.store(0);
     acc_.store(0);
-    for (size_t k = 0; k < n_chunks; k++) left_[k].store((int)threads_.size());
+    nsub_ = 2 * threads_.size();  // pieces per chunk
+    for (size_t k = 0; k < n_chunks; k++) left_[k].store((int)nsub_);
     busy_ = (int)threads_.size();
     gen_++;
     cv_.notify_all();
   }
   size_t chunk_begin(size_t k) const { return std::min(cnt_, k * per_chunk_); }
   // waits until chunk k is complete; false = some value read so far does not fit `pb` bytes
+  // (the caller narrows pieces itself while it waits: it is awake, the workers may still be waking up)
   bool wait_chunk(size_t k) {
-    while (left_[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    while (left_[k].load(std::memory_order_acquire) != 0)
+      if (!take_piece()) std::this_thread::yield();
     return (acc_.load() >> (8 * pb_)) == 0;
   }
   // every worker has left the job (its buffers may be reused or freed)
@@ -618,6 +621,18 @@ class PackPool {
     }
     for (auto& t : threads_) t.detach();
   }
+  // claims the next piece of the job and narrows it; false = every piece has been claimed
+  bool take_piece() {
+    const size_t it = next_.fetch_add(1);
+    if (it >= n_chunks * nsub_) return false;
+    const size_t k = it / nsub_, sub = it % nsub_;
+    const size_t b = chunk_begin(k), e = chunk_begin(k + 1);
+    const size_t piece = (((e - b) + nsub_ - 1) / nsub_ + 7) & ~size_t(7);
+    const size_t lo = std::min(e, b + sub * piece), hi = std::min(e, lo + piece);
+    if (hi > lo) acc_.fetch_or(narrow_range(in_ + lo, out_ + lo * pb_, pb_, hi - lo));
+    left_[k].fetch_sub(1, std::memory_order_release);
+    return true;
+  }
   void run() {
     uint64_t seen = 0;
     for (;;) {
@@ -626,16 +641,7 @@ class PackPool {
         cv_.wait(lk, [&] { return gen_ != seen; });
         seen = gen_;
       }
-      const size_t nsub = threads_.size(), items = n_chunks * nsub;
-      for (;;) {
-        const size_t it = next_.fetch_add(1);
-        if (it >= items) break;
-        const size_t k = it / nsub, sub = it % nsub;
-        const size_t b = chunk_begin(k), e = chunk_begin(k + 1);
-        const size_t piece = (((e - b) + nsub - 1) / nsub + 7) & ~size_t(7);
-        const size_t lo = std::min(e, b + sub * piece), hi = std::min(e, lo + piece);
-        if (hi > lo) acc_.fetch_or(narrow_range(in_ + lo, out_ + lo * pb_, pb_, hi - lo));
-        left_[k].fetch_sub(1, std::memory_order_release);
+      while (take_piece()) {
       }
       {
         std::unique_lock<std::mutex> lk(mu_);
@@ -651,7 +657,7 @@ class PackPool {
   const u64* in_ = nullptr;
   uint8_t* out_ = nullptr;
   unsigned pb_ = 1;
-  size_t cnt_ = 0, per_chunk_ = 0;
+  size_t cnt_ = 0, per_chunk_ = 0, nsub_ = 1;
   std::atomic<size_t> next_{0};
   std::atomic<u64> acc_{0};
   std::atomic<int> left_[MAX_CHUNKS];
