@@ -169,6 +169,7 @@ struct DeepParams {
   DeepPoints pts;
   E2* ro;
   size_t height;
+  Digest* leaves;  // when set: digest of FRI row i / 2 = (ro[i], ro[i + 1]), the leaf layer of the first commit-phase round
 };
 // ro[i] = sum_q den_q[i] * (K_q - sum_m coeff_{m,q} * s_m[i]),  s_m[i] = sum_c alpha^c m[i][c]
 // (= sum over matrices and points of coeff * (red_z - s_m[i]) / (z_q - x_i), regrouped by point so that the
@@ -253,6 +254,27 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
   }
   p.ro[i] = r0;
   p.ro[i + 1] = r1;
+  if (p.leaves) {
+    // the pair this thread has just produced is one row of FRI's first committed matrix: hash it here (the pass waits on
+    // memory, the 680 instructions ride along) instead of reading the vector back in a launch of its own
+    u32 m[16];
+    m[0] = (u32)r0.c0;
+    m[1] = (u32)(r0.c0 >> 32);
+    m[2] = (u32)r0.c1;
+    m[3] = (u32)(r0.c1 >> 32);
+    m[4] = (u32)r1.c0;
+    m[5] = (u32)(r1.c0 >> 32);
+    m[6] = (u32)r1.c1;
+    m[7] = (u32)(r1.c1 >> 32);
+#pragma unroll
+    for (int k = 8; k < 16; k++) m[k] = 0;
+    u32 cv[8];
+    b3_iv(cv);
+    b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+    uint4* q = reinterpret_cast<uint4*>(p.leaves + (i >> 1));
+    q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+  }
 }
 
 // out[i] = (1/2 + pw) lo + (1/2 - pw) hi, pw = (beta/2) w_{2R}^{-bitrev(i)}; optional roll-in out[i] += f * in[i]
@@ -668,7 +690,7 @@ void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npo
 }
 
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* apow_dev, E2* ro,
-                 const E2* apow_host) {
+                 const E2* apow_host, Digest* fri_leaves) {
   if (pts.n > 2) throw std::runtime_error("deep_reduce: more than two opening points at one height");
   for (auto& m : mats)
     for (u32 k = 0; k < m.npoints; k++)
@@ -679,7 +701,7 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
   if (!apow_dev) throw std::runtime_error("deep_reduce: alpha powers missing");
   DBuf<DeepMat> dm(ctx, mats.size());
   ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
-  DeepParams p{dm.p, (u32)mats.size(), apow_dev, pts, ro, height};
+  DeepParams p{dm.p, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves};
   double bytes = 16.0 * height * (1 + pts.n);
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);

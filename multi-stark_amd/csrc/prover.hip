@@ -1032,7 +1032,7 @@ struct FriHead {
 };
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
                size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr,
-               const FriHead* head = nullptr);
+               const FriHead* head = nullptr, DTree* round0 = nullptr);
 
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
 void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes) {
@@ -1198,16 +1198,23 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     }
   }
   std::vector<DBuf<E2>> inputs;  // descending height
+  DTree fri_round0;              // the tallest vector is FRI's first committed matrix: its leaf layer is hashed where it is produced
   if (use_side) ctx.side_fork();  // behind the upload of the alpha powers
   for (int lh = 32; lh >= 0; lh--) {
     if (!present[lh]) continue;
     size_t h = size_t(1) << lh;
     SideScope sc(ctx, use_side && h <= short_h);
     DBuf<E2> ro(ctx, h);
-    if (lists[lh].empty())
+    if (lists[lh].empty()) {
       HIP_CHECK(hipMemsetAsync(ro.p, 0, h * sizeof(E2), ctx.stream));
-    else
-      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p, apow.data());
+    } else {
+      Digest* leaves = nullptr;
+      if (inputs.empty() && h >= 8192 && !getenv("MSAMD_NO_DEEP_LEAVES")) {
+        merkle_alloc(ctx, fri_round0, h / 2);
+        leaves = fri_round0.base();
+      }
+      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p, apow.data(), leaves);
+    }
     inputs.push_back(std::move(ro));
   }
   ctx.side_join();  // the short reduced openings read the tall points' denominators, released next
@@ -1232,7 +1239,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     shape.widths.push_back(std::move(widths));
     shape.nsib.push_back(t.cap_layer());
   }
-  fri_prove(sys, ch, inputs, log_gmax, segs, out_off, shape, nullptr, fri_bytes, tr);
+  fri_prove(sys, ch, inputs, log_gmax, segs, out_off, shape, nullptr, fri_bytes, tr, nullptr, &fri_round0);
 }
 
 // prove_fri (commit phase, final polynomial, query proof of work, query openings) over the reduced openings
@@ -1241,7 +1248,8 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
 // every matrix row, then the sibling digests bottom-up) or, when the committed data is spread over ranks, by
 // `remote`, called with the sampled indices and filling the same layout.
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
-               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr, const FriHead* head) {
+               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr, const FriHead* head,
+               DTree* round0) {
   Ctx& ctx = *sys.ctx;
   const unsigned head_rounds = head ? head->n_rounds : 0;
   if (head && !remote) throw std::runtime_error("FRI: head rounds need the remote gather");
@@ -1292,6 +1300,12 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     size_t r = 0;
     bool leaves_done = false;  // the fold of the previous round already hashed this round's leaves
     bool tree_done = false;    // the previous round's fused launch already built this round's tree and ran its challenger step
+    if (round0 && round0->digests.p && folded.n > stop && !(use_tail && folded.n <= 2048)) {
+      // the first round's leaf layer was hashed by the pass that produced the vector (deep_reduce_k)
+      round0->cap_height = 0;
+      trees.push_back(std::move(*round0));
+      leaves_done = true;
+    }
     while (folded.n > stop) {
       if (use_tail && folded.n <= 2048) {
         const uint32_t len0 = (uint32_t)folded.n;
@@ -1381,10 +1395,14 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   }
   while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, or MSAMD_HOST_FRI)
     size_t rows = folded.n / 2;
-    trees.emplace_back();
+    const bool prehashed = round0 && round0->digests.p && trees.empty() && layers.empty() && round0->layer_len[0] == rows;
+    if (prehashed)
+      trees.push_back(std::move(*round0));
+    else
+      trees.emplace_back();
     DTree& t = trees.back();
     t.cap_height = (unsigned)prm.cap_height;
-    fri_tree_build(ctx, t, folded.p, rows);
+    fri_tree_build(ctx, t, prehashed ? nullptr : folded.p, rows);
     bool found = false;
     u64 wit = 0;
     std::vector<Digest> cap = cap_and_grind(ctx, t, ch.input, (unsigned)prm.commit_pow_bits, &found, &wit);
