@@ -197,6 +197,8 @@ def single_gpu(args, pkg, fe, ctx, torch):
     dom = ctx.kernel_stats()[dominant]
     ctx.set_profile([])
     stage = system.prove_multiple_claims(witness, want_times=True).stage_ms
+    verdict = system.verify_multiple_claims(packed, proof.to_bytes())  # untimed: System::verify_multiple_claims on the bytes
+    assert verdict == 0, "the library's own verifier rejects the proof (code %d)" % verdict
     # the same proof from a witness that already sits in HBM (round-1 definition of the step): context, never `value`
     hbm_ms = None
     if not args.hbm_resident:
@@ -251,6 +253,7 @@ def single_gpu(args, pkg, fe, ctx, torch):
         "workload": WORKLOAD % (args.log_adds, "proof", "witness resident in HBM" if args.hbm_resident else HOST_RESIDENT),
         "rows_per_proof": rows,
         "proof_bytes": len(proof.to_bytes()),
+        "verified": True,
         "parallelism": "single GPU",
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
         "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows / (elapsed / args.steps) / 1e9,
@@ -317,6 +320,7 @@ def babybear(args, pkg, fe, ctx, torch):
                     "witness resident in HBM, proof bytes returned to host" % args.log_adds,
         "rows_per_proof": rows,
         "proof_bytes": len(proof.to_bytes()),
+        "verified": True,
         "parallelism": "single GPU",
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
     }
@@ -475,6 +479,11 @@ def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
     moved = comm.bytes_moved // (args.steps + max(args.warmup, 1))
     stage = system.prove_sharded(witness, comm, owners, want_times=True).stage_ms
     sha = hashlib.sha256(proof.to_bytes()).hexdigest()
+    # untimed: the joint proof must be accepted by the library's verifier (System::verify_multiple_claims on the bytes); a
+    # wrong exchange on first contact with several GPUs must not pass as a measurement
+    verdict = system.verify_multiple_claims(packed, proof.to_bytes()) if rank == 0 else 0
+    if rank == 0:
+        log("joint proof: verifier verdict %d (0 = accepted)" % verdict)
     if rank == 0:
         log("joint proof: %.3f ms per proof, %d rows, transport %s, sha256 %s" % (1e3 * elapsed / args.steps, rows, transport, sha[:16]))
     info = {
@@ -483,7 +492,10 @@ def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
         "value": rows * args.steps / elapsed, "unit": "rows/s", "ms_per_step": 1e3 * elapsed / args.steps,
         "rows_per_proof": rows, "proof_bytes": len(proof.to_bytes()), "proof_sha256": sha, "transport": transport,
         "bytes_exchanged_per_rank_per_proof": moved, "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+        "verified": verdict == 0,
     }
+    if verdict != 0:
+        info["error"] = "the joint proof is REJECTED by the verifier (code %d): the figures of this leg are void" % verdict
     return info, dominant, dom, rows
 
 
@@ -531,6 +543,9 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
         result["config"]["stage_ms"] = info["stage_ms"]
         result["config"]["bytes_exchanged_per_rank_per_proof"] = info["bytes_exchanged_per_rank_per_proof"]
         result["config"]["proof_sha256"] = info["proof_sha256"]
+        result["config"]["verified"] = info["verified"]
+        if "error" in info:
+            result["error"] = info["error"]
     result["roofline"] = roofline_of(dominant, dom)
     if joint_primary and "replicas" in done:
         result["replicas"] = done["replicas"][0]
@@ -588,6 +603,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if result.get("error"):
+        sys.exit(4)  # a rejected proof is a failed run, whatever was timed
 
 
 def measured_traffic(kernel):
