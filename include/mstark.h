@@ -171,6 +171,14 @@ typedef struct ms_comm {
   int32_t (*all_to_all_start)(void* user, const void* send_dev, size_t send_stride, void* recv_dev, size_t recv_stride,
                               size_t bytes_per_peer);
   int32_t (*all_to_all_wait)(void* user);
+  /* Optional (NULL = not offered; needs all_to_all_wait): the same non-blocking exchange read STRAIGHT OUT OF a column-major
+   * matrix, so that no send buffer has to be packed first. For every rank k, `ncols` segments of seg_bytes bytes each way:
+   * segment c for rank k is read at send_dev + k * send_peer_stride + c * send_col_stride (rows [k h / N, (k + 1) h / N)
+   * of column c of this rank's LDE), and segment c coming from rank k is written at recv_dev + k * recv_peer_stride +
+   * c * recv_col_stride (block k of this rank's receive buffer, column c). Segments of one peer travel in column order on
+   * both sides; the rank's own segments (k = rank) are copied on the device. Completed by all_to_all_wait. */
+  int32_t (*all_to_all_cols_start)(void* user, const void* send_dev, size_t send_peer_stride, size_t send_col_stride, void* recv_dev,
+                                   size_t recv_peer_stride, size_t recv_col_stride, size_t ncols, size_t seg_bytes);
 } ms_comm;
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms);

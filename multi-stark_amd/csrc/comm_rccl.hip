@@ -97,6 +97,24 @@ struct ms_comm_rccl {
     // this rank's own block never leaves the device
     HIP_CHECK(hipMemcpyAsync(recv + (size_t)rank * recv_stride, send + (size_t)rank * send_stride, n, hipMemcpyDeviceToDevice, stream));
   }
+  // the exchange read straight out of a column-major matrix (ms_comm.all_to_all_cols_start): one ncclSend / ncclRecv per
+  // peer and column in ONE group (4 MB segments at the bench size); this rank's own rows are a strided device copy
+  void exchange_cols(const uint8_t* send, size_t sps, size_t scs, uint8_t* recv, size_t rps, size_t rcs, size_t ncols, size_t seg) {
+    bytes_moved += seg * ncols * (size_t)world;
+    if (seg == 0 || ncols == 0) return;
+    if (world > 1) {
+      nccl_check(rccl().GroupStart(), "ncclGroupStart");
+      for (int k = 0; k < world; k++) {
+        if (k == rank) continue;
+        for (size_t c = 0; c < ncols; c++) {
+          nccl_check(rccl().Send(send + (size_t)k * sps + c * scs, seg, ncclUint8, k, comm, stream), "ncclSend");
+          nccl_check(rccl().Recv(recv + (size_t)k * rps + c * rcs, seg, ncclUint8, k, comm, stream), "ncclRecv");
+        }
+      }
+      nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    }
+    HIP_CHECK(hipMemcpy2DAsync(recv + (size_t)rank * rps, rcs, send + (size_t)rank * sps, scs, seg, ncols, hipMemcpyDeviceToDevice, stream));
+  }
   void gather(const void* send, void* recv, size_t n) {
     bytes_moved += n * (size_t)world;
     if (n == 0) return;
@@ -136,6 +154,10 @@ int32_t cb_all_gather(void* user, const void* send, void* recv, size_t bytes) {
 int32_t cb_start(void* user, const void* send, size_t send_stride, void* recv, size_t recv_stride, size_t per_peer) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
   return guarded(c, [&] { c->exchange((const uint8_t*)send, send_stride, (uint8_t*)recv, recv_stride, per_peer); });
+}
+int32_t cb_cols_start(void* user, const void* send, size_t sps, size_t scs, void* recv, size_t rps, size_t rcs, size_t ncols, size_t seg) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] { c->exchange_cols((const uint8_t*)send, sps, scs, (uint8_t*)recv, rps, rcs, ncols, seg); });
 }
 int32_t cb_wait(void* user) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
@@ -183,6 +205,7 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
     c->table.all_gather = cb_all_gather;
     c->table.all_to_all_start = cb_start;
     c->table.all_to_all_wait = cb_wait;
+    c->table.all_to_all_cols_start = cb_cols_start;
     c->owner = ctx;
     ctx_retain(ctx);
     *out = c;

@@ -11,11 +11,12 @@ import ctypes as C
 _CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 _START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t)
 _WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+_COLS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t)
 
 
 class MsComm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB),
-                ("all_to_all_start", _START), ("all_to_all_wait", _WAIT)]
+                ("all_to_all_start", _START), ("all_to_all_wait", _WAIT), ("all_to_all_cols_start", _COLS)]
 
 
 class _DevBytes:
@@ -42,8 +43,9 @@ class TorchComm:
         self._ag = _CB(self._all_gather)
         self._start = _START(self._all_to_all_start)
         self._wait = _WAIT(self._all_to_all_wait)
+        self._cols = _COLS(self._all_to_all_cols_start)
         self._pending = []
-        self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag, self._start, self._wait)
+        self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag, self._start, self._wait, self._cols)
 
     def _view(self, ptr, nbytes):
         return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
@@ -94,6 +96,41 @@ class TorchComm:
                 dist.all_gather(parts, mine, group=self.group)
                 for k in range(self.world):
                     outs[k].copy_(parts[k][self.rank * per_peer:(self.rank + 1) * per_peer])
+                torch.cuda.synchronize(self.device)
+
+        return self._guard(run)
+
+    def _all_to_all_cols_start(self, _user, send, sps, scs, recv, rps, rcs, ncols, seg):
+        """the exchange read straight out of a column-major matrix: for rank k, segment c is sent from send + k * sps + c * scs
+        and the segment c coming from rank k is written at recv + k * rps + c * rcs"""
+
+        def run():
+            self.bytes_moved += seg * ncols * self.world
+            ins = [[self._view(send + k * sps + c * scs, seg) for c in range(ncols)] for k in range(self.world)]
+            outs = [[self._view(recv + k * rps + c * rcs, seg) for c in range(ncols)] for k in range(self.world)]
+            for c in range(ncols):  # this rank's own rows never leave the device
+                outs[self.rank][c].copy_(ins[self.rank][c])
+            if self.direct:
+                ops = []
+                for k in range(self.world):
+                    if k == self.rank:
+                        continue
+                    for c in range(ncols):
+                        ops.append(dist.P2POp(dist.isend, ins[k][c], k, self.group))
+                        ops.append(dist.P2POp(dist.irecv, outs[k][c], k, self.group))
+                if ops:
+                    self._pending.extend(dist.batch_isend_irecv(ops))
+            else:  # staged transports have nothing to overlap with: exchange now (every rank takes its block of each)
+                mine = torch.cat([t.cpu() for k in range(self.world) for t in ins[k]])
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                per = seg * ncols
+                for k in range(self.world):
+                    if k == self.rank:
+                        continue
+                    blk = parts[k][self.rank * per:(self.rank + 1) * per]
+                    for c in range(ncols):
+                        outs[k][c].copy_(blk[c * seg:(c + 1) * seg])
                 torch.cuda.synchronize(self.device)
 
         return self._guard(run)

@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, log_adds, variant, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4", OMP_WAIT_POLICY="passive")
+        if variant == "pack":  # the exchange through a packed send buffer (what a transport without all_to_all_cols_start gets)
+            os.environ["MSAMD_SHARDED_PACK"] = "1"
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import importlib
@@ -174,9 +176,9 @@ def test_sharded_random_systems(world, seed):
 
 # 2^8 additions: the adders' LDE is as tall as the byte table's (same leaf group); 2^10: the byte table is injected
 @pytest.mark.parametrize("world,log_adds,variant", [(1, 9, "bench"), (2, 8, "bench"), (2, 10, "bad-owners"), (4, 10, "bench"),
-                                                    (2, 9, "cap1")])
+                                                    (2, 9, "cap1"), (2, 9, "pack"), (4, 8, "pack")])
 def test_sharded_proof_equals_single_gpu_proof(world, log_adds, variant):
-    port = 29600 + (os.getpid() % 1000) + 7 * world + log_adds + (3 if variant == "cap1" else 0)
+    port = 29600 + (os.getpid() % 1000) + 7 * world + log_adds + (3 if variant == "cap1" else 50 if variant == "pack" else 0)
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     procs = [mpc.Process(target=_worker, args=(r, world, port, log_adds, variant, q)) for r in range(world)]
