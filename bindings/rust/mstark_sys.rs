@@ -46,6 +46,7 @@ pub struct ms_comm {
     pub all_to_all_cols_start: Option<unsafe extern "C" fn(user: *mut c_void, send_dev: *const c_void, send_peer_stride: usize, send_col_stride: usize,
                                                            recv_dev: *mut c_void, recv_peer_stride: usize, recv_col_stride: usize, ncols: usize,
                                                            seg_bytes: usize) -> i32>,
+    pub set_stream_ordered: Option<unsafe extern "C" fn(user: *mut c_void, hip_stream: *mut c_void) -> i32>,
 }
 
 extern "C" {

@@ -81,6 +81,22 @@ struct ms_comm_rccl {
   int rank = 0, world = 1;
   uint64_t bytes_moved = 0;
   ms_comm table;
+  // stream-ordered mode (ms_comm.set_stream_ordered): `peer` is the caller's stream; events order the two streams
+  hipStream_t peer = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  void begin() {  // the exchange that follows runs behind everything queued on the caller's stream so far
+    if (!peer) return;
+    HIP_CHECK(hipEventRecord(ev_in, peer));
+    HIP_CHECK(hipStreamWaitEvent(stream, ev_in, 0));
+  }
+  void complete() {  // what the caller queues next runs behind every exchange given to this transport so far
+    if (peer) {
+      HIP_CHECK(hipEventRecord(ev_out, stream));
+      HIP_CHECK(hipStreamWaitEvent(peer, ev_out, 0));
+    } else {
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
 
   void exchange(const uint8_t* send, size_t send_stride, uint8_t* recv, size_t recv_stride, size_t n) {
     bytes_moved += n * (size_t)world;
@@ -140,28 +156,47 @@ int32_t guarded(ms_comm_rccl* c, F f) {
 int32_t cb_all_to_all(void* user, const void* send, void* recv, size_t per_peer) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
   return guarded(c, [&] {
+    c->begin();
     c->exchange((const uint8_t*)send, per_peer, (uint8_t*)recv, per_peer, per_peer);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->complete();
   });
 }
 int32_t cb_all_gather(void* user, const void* send, void* recv, size_t bytes) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
   return guarded(c, [&] {
+    c->begin();
     c->gather(send, recv, bytes);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->complete();
   });
 }
 int32_t cb_start(void* user, const void* send, size_t send_stride, void* recv, size_t recv_stride, size_t per_peer) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
-  return guarded(c, [&] { c->exchange((const uint8_t*)send, send_stride, (uint8_t*)recv, recv_stride, per_peer); });
+  return guarded(c, [&] {
+    c->begin();
+    c->exchange((const uint8_t*)send, send_stride, (uint8_t*)recv, recv_stride, per_peer);
+  });
 }
 int32_t cb_cols_start(void* user, const void* send, size_t sps, size_t scs, void* recv, size_t rps, size_t rcs, size_t ncols, size_t seg) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
-  return guarded(c, [&] { c->exchange_cols((const uint8_t*)send, sps, scs, (uint8_t*)recv, rps, rcs, ncols, seg); });
+  return guarded(c, [&] {
+    c->begin();
+    c->exchange_cols((const uint8_t*)send, sps, scs, (uint8_t*)recv, rps, rcs, ncols, seg);
+  });
 }
 int32_t cb_wait(void* user) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
-  return guarded(c, [&] { HIP_CHECK(hipStreamSynchronize(c->stream)); });
+  return guarded(c, [&] { c->complete(); });
+}
+int32_t cb_set_stream_ordered(void* user, void* hip_stream) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] {
+    if (!hip_stream && c->peer) HIP_CHECK(hipStreamSynchronize(c->stream));  // leaving the mode: nothing of ours stays in flight
+    if (hip_stream && !c->ev_in) {
+      HIP_CHECK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    }
+    c->peer = (hipStream_t)hip_stream;
+  });
 }
 }  // namespace
 
@@ -206,6 +241,7 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
     c->table.all_to_all_start = cb_start;
     c->table.all_to_all_wait = cb_wait;
     c->table.all_to_all_cols_start = cb_cols_start;
+    c->table.set_stream_ordered = cb_set_stream_ordered;
     c->owner = ctx;
     ctx_retain(ctx);
     *out = c;
@@ -228,6 +264,8 @@ void ms_comm_rccl_destroy(ms_comm_rccl* c) {
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)rccl().CommDestroy(c->comm);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   (void)hipStreamDestroy(c->stream);
   ms_ctx* o = c->owner;
   delete c;

@@ -197,18 +197,30 @@ def test_sharded_proof_equals_single_gpu_proof(world, log_adds, variant):
 # The library's own RCCL transport (ms_comm_rccl_*, csrc/comm_rccl.hip). One GPU on the test box allows world = 1 only
 # (RCCL refuses two ranks on one device): the call path, handle lifetimes and the proof bytes are checked here, the
 # multi-rank exchange pattern by the callback tests above, and 2 .. 8 real ranks by bench.py on the driver's node.
-def test_native_rccl_transport_world_1(pkg, ctx, oracle, fe):
+# Variants: the transport ordered with the prover's stream by events (the default: no host waits around the exchanges), by
+# the host (MSAMD_SHARDED_HOST_SYNC), and the exchange through a packed send buffer (MSAMD_SHARDED_PACK); at 2^12 and at 2^16
+# rows (column groups overlapping the transforms), from a device- and from a host-resident witness, several proofs in a row.
+@pytest.mark.parametrize("var", ["", "MSAMD_SHARDED_HOST_SYNC", "MSAMD_SHARDED_PACK"])
+@pytest.mark.parametrize("log_adds", [12, 16])
+def test_native_rccl_transport_world_1(pkg, ctx, oracle, fe, var, log_adds, monkeypatch):
     import importlib
 
+    if var:
+        monkeypatch.setenv(var, "1")
     sharded = importlib.import_module("multi_stark_amd.sharded")
     system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(1))
-    traces, claims = fe.multi_u32_add_witness(1, 1 << 12)
+    traces, claims = fe.multi_u32_add_witness(1, 1 << log_adds)
     packed = fe.pack_claims(claims)
     w = system.witness(traces, packed)
     want = system.prove_multiple_claims(w).to_bytes()
     comm = sharded.RcclComm(ctx, None, 0, 1)
     got = system.prove_sharded(w, comm, sharded.u32_add_owners(1)).to_bytes()
     assert got == want
+    hw = system.host_witness(traces, packed)
+    for _ in range(3):
+        assert system.prove_sharded(hw, comm, sharded.u32_add_owners(1)).to_bytes() == want
+        assert system.prove_sharded(w, comm, sharded.u32_add_owners(1)).to_bytes() == want
+    assert system.prove_multiple_claims(w).to_bytes() == want   # the plain prover on the same context afterwards
     assert comm.bytes_moved > 0
     assert oracle.System(system.blob).verify(packed, got) == 0
     comm.close()
