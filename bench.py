@@ -121,10 +121,38 @@ def profile_first_step(ctx, step, rank):
     return proof, dominant
 
 
-def roofline_of(dominant, dom):
+VALU_FILE = "r02_valu.json"
+VALU_PEAK_TOPS = 39.4  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one integer VALU instruction per lane and clock
+
+
+def measured_valu(kernel):
+    """VALU lane-operations per launch of `kernel` from the committed SQ_INSTS_VALU pass (tools/valu_from_pmc.py)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", VALU_FILE)))[kernel]["valu_lane_ops_per_launch"]
+    except Exception:
+        return None
+
+
+def roofline_of(dominant, dom, full_size=True):
     avg_ms = dom["ms"] / max(dom["launches"], 1)
     bytes_per_launch = dom["alg_bytes"] / max(dom["launches"], 1)
     achieved = bytes_per_launch / max(avg_ms, 1e-12) / 1e6  # GB/s
+    line = _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved)
+    ops = measured_valu(dominant) if full_size else None
+    if ops:
+        # the bound that binds: these kernels are integer arithmetic (no 64-bit multiplier on gfx950; DESIGN section 4), the
+        # vector ALU issues at its peak long before HBM is busy. Counted instructions (every instruction as ONE issue slot,
+        # although a v_mad_u64_u32 takes about two) against the issue peak.
+        tops = ops / max(avg_ms, 1e-12) / 1e9
+        line["valu"] = {
+            "what": "VALU lane-operations per launch (SQ_INSTS_VALU x 64 of the committed counter pass profiles/%s, same workload) "
+                    "/ this run's average launch time, against the integer issue peak" % VALU_FILE,
+            "lane_ops_per_launch": ops, "achieved_Tops": tops, "peak_Tops": VALU_PEAK_TOPS, "frac": tops / VALU_PEAK_TOPS,
+        }
+    return line
+
+
+def _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved):
     return {
         "kernel": dominant,
         "bound": "hbm",
@@ -268,7 +296,7 @@ def single_gpu(args, pkg, fe, ctx, torch):
             "plain_upload_ms_per_proof": plain_ms,
         },
     }
-    result["roofline"] = roofline_of(dominant, dom)
+    result["roofline"] = roofline_of(dominant, dom, full_size=(args.log_adds == 20))  # (the committed counter pass is of 2^20 additions)
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(fe, system.blob, args.cpu_log_adds)
     return result
@@ -324,7 +352,7 @@ def babybear(args, pkg, fe, ctx, torch):
         "parallelism": "single GPU",
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
     }
-    rl = roofline_of(dominant, dom)
+    rl = roofline_of(dominant, dom, full_size=False)
     rl["traffic"], rl["traffic_source"] = None, "not collected for this configuration"
     if dom.get("units"):
         perms_per_s = dom["units"] / max(dom["ms"], 1e-12) * 1e3
@@ -546,7 +574,7 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
         result["config"]["verified"] = info["verified"]
         if "error" in info:
             result["error"] = info["error"]
-    result["roofline"] = roofline_of(dominant, dom)
+    result["roofline"] = roofline_of(dominant, dom, full_size=False)
     if joint_primary and "replicas" in done:
         result["replicas"] = done["replicas"][0]
     if not joint_primary and "joint" in done:
