@@ -103,11 +103,10 @@ int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const u
  * runs SystemWitness::from_stage_1 (src/system.rs:244-328) on the device and frees the device copies again, so its
  * wall time is the reference's timed region: witness in host memory at the start, proof bytes in host memory at the end.
  * Narrow upload: a trace of at least 4 MB whose values all fit 1 / 2 / 4 bytes (seen by the validation pass here) is not
- * sent as 64-bit words: every ms_prove narrows it on a pool of host threads (16 by default, kept on the NUMA node of the
- * trace), checking the range again, uploads the narrowed chunks as they complete and widens them on the device - at the
+ * sent as 64-bit words: every ms_prove narrows it on a pool of host threads (16 by default), checking the range again, uploads the narrowed chunks as they complete and widens them on the device - at the
  * bench size 15 MB instead of 117 MB cross PCIe, in 0.5 ms instead of 2.1. A value that no longer fits sends that proof
  * down the plain path. Environment: MSAMD_NO_PACK=1 (read here) never narrows; MSAMD_PACK_THREADS=n (0: off),
- * MSAMD_PACK_MIN_BYTES, MSAMD_PACK_CHUNKS, MSAMD_PACK_NO_AFFINITY=1 tune it. */
+ * MSAMD_PACK_MIN_BYTES, MSAMD_PACK_CHUNKS, MSAMD_PACK_AFFINITY=1 (workers confined to the NUMA node of the trace) tune it. */
 int32_t ms_witness_create_host(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, size_t n_claims,
                                const uint64_t* claim_offsets, const uint64_t* claim_data, int32_t* pinned /* nullable */,
                                ms_witness** out);
