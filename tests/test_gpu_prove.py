@@ -498,8 +498,13 @@ def test_error_paths_return_codes_not_crashes(pkg, ctx, fe):
 
 # An error in the middle of a proof (here: an injected allocation failure at every allocation in turn) must return an
 # error code, drop the read-backs it had queued into locals that no longer exist, and leave the library usable.
+# (side = "9": the byte table's launches go to the side stream beside the adder's - failures then also unwind out of side
+# scopes, with blocks of the side pool live and releases deferred)
+@pytest.mark.parametrize("side", ["", "9"])
 @pytest.mark.parametrize("host", [False, True])
-def test_mid_proof_failure_leaves_the_library_usable(pkg, ctx, fe, host):
+def test_mid_proof_failure_leaves_the_library_usable(pkg, ctx, fe, host, side, monkeypatch):
+    if side:
+        monkeypatch.setenv("MSAMD_SIDE_MAX_LOG", side)
     traces, claims = fe.u32_add_bench_witness(1 << 11)   # claims hashed on the device: read-backs are queued mid-proof
     g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
     packed = fe.pack_claims(claims)
