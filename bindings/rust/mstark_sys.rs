@@ -15,6 +15,8 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct ms_mmcs { _p: [u8; 0] }
 #[repr(C)] pub struct ms_challenger { _p: [u8; 0] }
 #[repr(C)] pub struct ms_comm_rccl { _p: [u8; 0] }
+#[repr(C)] pub struct ms_comm_local_group { _p: [u8; 0] }
+#[repr(C)] pub struct ms_comm_local { _p: [u8; 0] }
 #[repr(C)] pub struct ms_trace { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_system { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_witness { _p: [u8; 0] }
@@ -86,6 +88,13 @@ extern "C" {
     pub fn ms_comm_rccl_table(c: *mut ms_comm_rccl) -> *const ms_comm;
     pub fn ms_comm_rccl_bytes_moved(c: *mut ms_comm_rccl) -> u64;
     pub fn ms_comm_rccl_destroy(c: *mut ms_comm_rccl);
+    pub fn ms_comm_local_group_create(world: i32, out: *mut *mut ms_comm_local_group) -> i32;
+    pub fn ms_comm_local_group_abort(g: *mut ms_comm_local_group);
+    pub fn ms_comm_local_group_destroy(g: *mut ms_comm_local_group);
+    pub fn ms_comm_local_create(g: *mut ms_comm_local_group, ctx: *mut ms_ctx, rank: i32, out: *mut *mut ms_comm_local) -> i32;
+    pub fn ms_comm_local_table(c: *mut ms_comm_local) -> *const ms_comm;
+    pub fn ms_comm_local_bytes_moved(c: *mut ms_comm_local) -> u64;
+    pub fn ms_comm_local_destroy(c: *mut ms_comm_local);
     pub fn ms_dft_batch(ctx: *mut ms_ctx, input: *const u64, h: usize, w: usize, inverse: i32, out: *mut u64) -> i32;
     pub fn ms_coset_lde_batch(ctx: *mut ms_ctx, input: *const u64, h: usize, w: usize, log_blowup: u32, out: *mut u64) -> i32;
     pub fn ms_quotient_lde(ctx: *mut ms_ctx, input: *const u64, log_n: u32, log_q: u32, log_blowup: u32, d: usize, out: *mut u64) -> i32;

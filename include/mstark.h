@@ -20,6 +20,7 @@
  *   ms_verify      System::verify_multiple_claims               src/verifier.rs:208-532
  *   ms_prove_sharded   the same proof computed by several GPUs  src/prover.rs:290-603 (commit/open calls :350,419,526,580)
  *   ms_comm_rccl_*     its transport on RCCL (the reference has no collectives: Cargo.toml has no MPI / NCCL crate)
+ *   ms_comm_local_*    its transport between threads of one process (peer copies; the reference's own process model)
  *   ms_dft_batch   Radix2DitParallel::dft_batch                 src/prover.rs:650,716 (type fixed at :440)
  *   ms_coset_lde_batch  the LDE inside Pcs::commit              src/prover.rs:350,419; layout pinned by :975-999
  *   ms_quotient_lde     shifted_quotient_slices + lde_from_shifted_coefficients   src/prover.rs:631-717
@@ -202,6 +203,25 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
 const ms_comm* ms_comm_rccl_table(ms_comm_rccl* c);
 uint64_t ms_comm_rccl_bytes_moved(ms_comm_rccl* c); /* bytes this rank has put through the two exchanges so far */
 void ms_comm_rccl_destroy(ms_comm_rccl* c);
+
+/* ---- In-process transport for ms_prove_sharded (csrc/comm_local.hip): the ranks are THREADS of one process, each with its
+ * own ms_ctx (one device each, or several contexts on one device), and the exchanges are device-to-device copies pulled by the
+ * receiving rank, ordered between the ranks' streams by HIP events - peer copies over xGMI when the contexts sit on
+ * different GPUs. For a host that drives a whole node from one process (the reference's prover is one process with a thread
+ * pool, Cargo.toml:45) and for tests: RCCL refuses two ranks on one device, thread ranks do not, so BASELINE config 3 runs at
+ * world 8 on a one-GPU box. Create the group once, then one handle per rank (any thread); every rank's thread passes
+ * ms_comm_local_table() to ms_prove_sharded. A rank that fails or never arrives does not hang the others: the rendezvous times
+ * out (MSAMD_LOCAL_TIMEOUT_S, default 120) and ms_comm_local_group_abort wakes every waiting rank with an error. Handles and
+ * group may be destroyed in any order. */
+typedef struct ms_comm_local_group ms_comm_local_group;
+typedef struct ms_comm_local ms_comm_local;
+int32_t ms_comm_local_group_create(int32_t world, ms_comm_local_group** out);
+void ms_comm_local_group_abort(ms_comm_local_group* g);
+void ms_comm_local_group_destroy(ms_comm_local_group* g);
+int32_t ms_comm_local_create(ms_comm_local_group* g, ms_ctx* ctx, int32_t rank, ms_comm_local** out);
+const ms_comm* ms_comm_local_table(ms_comm_local* c);
+uint64_t ms_comm_local_bytes_moved(ms_comm_local* c);
+void ms_comm_local_destroy(ms_comm_local* c);
 
 /* ---- PCS-level entry points (host buffers in, host buffers out) */
 /* out[k] = sum_j in[j] w_h^{jk} per column (inverse != 0: the inverse transform incl. 1/h); natural order both sides */

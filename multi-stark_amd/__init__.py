@@ -45,7 +45,8 @@ def exported_symbols():
             "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_witness_prefetch",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
-            "ms_comm_rccl_table", "ms_comm_rccl_bytes_moved", "ms_comm_rccl_destroy", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
+            "ms_comm_rccl_table", "ms_comm_rccl_bytes_moved", "ms_comm_rccl_destroy", "ms_comm_local_group_create", "ms_comm_local_group_abort",
+            "ms_comm_local_group_destroy", "ms_comm_local_create", "ms_comm_local_table", "ms_comm_local_bytes_moved", "ms_comm_local_destroy", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_pcs_commit", "ms_pcs_open", "ms_pcs_verify", "ms_challenger_create",
             "ms_challenger_destroy", "ms_challenger_observe", "ms_challenger_observe_digests", "ms_challenger_sample_ext",
             "ms_challenger_sample_bits", "ms_stage2_trace", "ms_claims_accumulator",

@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <mutex>
 #include <string>
 
 #include "../../include/mstark.h"
@@ -28,6 +30,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -37,18 +40,24 @@ struct RcclApi {
 };
 RcclApi g_api;
 
-// one copy of RCCL per process: if the host has already loaded one (torch ships its own), use that one
+// one copy of RCCL per process: if the host has already loaded one (torch ships its own), use that one; otherwise the
+// library MSAMD_RCCL_LIB names (and only that one), otherwise the usual names
 const RcclApi& rccl() {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   if (g_api.lib) return g_api;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
   for (const char* n : names)
     if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-  if (const char* env = getenv("MSAMD_RCCL_LIB"))
-    if (!h) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  const char* env = getenv("MSAMD_RCCL_LIB");
+  if (!h && env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
   for (const char* n : names)
-    if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-  if (!h) throw std::runtime_error(std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"));
+    if (!h && !(env && *env)) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    const char* why = dlerror();  // (one call: dlerror() clears the message it returns)
+    throw std::runtime_error(std::string("cannot load librccl: ") + (why ? why : "not found"));
+  }
   RcclApi a;
   a.lib = h;
 #define MS_SYM(field, name)                                                       \
@@ -64,12 +73,41 @@ const RcclApi& rccl() {
   MS_SYM(AllGather, "ncclAllGather");
   MS_SYM(GetErrorString, "ncclGetErrorString");
 #undef MS_SYM
+  a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
   g_api = a;
   return g_api;
 }
 
 void nccl_check(ncclResult_t r, const char* what) {
   if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL ") + what + ": " + rccl().GetErrorString(r));
+}
+// ncclGroupStart ... ncclGroupEnd that is closed on every path: an exception between the two would otherwise leave the
+// thread inside an open group, and every later RCCL call of that thread - the next proof's all_gather - would be queued
+// into it and never launched (the peers hang instead of failing). end() reports the group's own result; the destructor
+// only closes.
+struct GroupGuard {
+  bool open = false;
+  GroupGuard() {
+    nccl_check(rccl().GroupStart(), "ncclGroupStart");
+    open = true;
+  }
+  void end() {
+    open = false;
+    nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+  }
+  ~GroupGuard() {
+    if (open) (void)rccl().GroupEnd();
+  }
+};
+// most point-to-point operations in one group (MSAMD_RCCL_GROUP_OPS): the column exchange issues one send and one receive
+// per peer and column, and splits its columns over several groups above this count
+size_t max_group_ops() {
+  static const size_t n = [] {
+    const char* e = getenv("MSAMD_RCCL_GROUP_OPS");
+    const long v = e ? atol(e) : 0;
+    return (size_t)(v > 0 ? v : 128);
+  }();
+  return n;
 }
 }  // namespace
 
@@ -84,7 +122,24 @@ struct ms_comm_rccl {
   // stream-ordered mode (ms_comm.set_stream_ordered): `peer` is the caller's stream; events order the two streams
   hipStream_t peer = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  uint64_t groups_issued = 0;
+  bool failed = false;
+  // An RCCL call of this rank has failed: the peers are waiting for operations that will never be issued. Abort the
+  // communicator so that they get an error instead of a hang, and refuse further use of this transport.
+  void fail() {
+    if (failed) return;
+    failed = true;
+    peer = nullptr;
+    if (comm && rccl().CommAbort) {
+      (void)rccl().CommAbort(comm);
+      comm = nullptr;
+    }
+  }
+  void usable() const {
+    if (failed) throw std::runtime_error("RCCL transport: an earlier exchange failed and the communicator was aborted; create a new transport");
+  }
   void begin() {  // the exchange that follows runs behind everything queued on the caller's stream so far
+    usable();
     if (!peer) return;
     HIP_CHECK(hipEventRecord(ev_in, peer));
     HIP_CHECK(hipStreamWaitEvent(stream, ev_in, 0));
@@ -102,13 +157,18 @@ struct ms_comm_rccl {
     bytes_moved += n * (size_t)world;
     if (n == 0) return;
     if (world > 1) {
-      nccl_check(rccl().GroupStart(), "ncclGroupStart");
-      for (int k = 0; k < world; k++) {
-        if (k == rank) continue;
-        nccl_check(rccl().Send(send + (size_t)k * send_stride, n, ncclUint8, k, comm, stream), "ncclSend");
-        nccl_check(rccl().Recv(recv + (size_t)k * recv_stride, n, ncclUint8, k, comm, stream), "ncclRecv");
+      try {
+        GroupGuard grp;
+        for (int k = 0; k < world; k++) {
+          if (k == rank) continue;
+          nccl_check(rccl().Send(send + (size_t)k * send_stride, n, ncclUint8, k, comm, stream), "ncclSend");
+          nccl_check(rccl().Recv(recv + (size_t)k * recv_stride, n, ncclUint8, k, comm, stream), "ncclRecv");
+        }
+        grp.end();
+      } catch (...) {
+        fail();
+        throw;
       }
-      nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
     }
     // this rank's own block never leaves the device
     HIP_CHECK(hipMemcpyAsync(recv + (size_t)rank * recv_stride, send + (size_t)rank * send_stride, n, hipMemcpyDeviceToDevice, stream));
@@ -119,24 +179,43 @@ struct ms_comm_rccl {
     bytes_moved += seg * ncols * (size_t)world;
     if (seg == 0 || ncols == 0) return;
     if (world > 1) {
-      nccl_check(rccl().GroupStart(), "ncclGroupStart");
-      for (int k = 0; k < world; k++) {
-        if (k == rank) continue;
-        for (size_t c = 0; c < ncols; c++) {
-          nccl_check(rccl().Send(send + (size_t)k * sps + c * scs, seg, ncclUint8, k, comm, stream), "ncclSend");
-          nccl_check(rccl().Recv(recv + (size_t)k * rps + c * rcs, seg, ncclUint8, k, comm, stream), "ncclRecv");
+      // every rank cuts the columns into the same groups, and inside a group every send has its receive on the peer: the
+      // groups complete one after the other on all ranks. Group size bounded (7 peers x 7 columns x 2 = 98 operations for a
+      // quarter of the stage-2 LDE at world 8; wider circuits would otherwise grow the group without limit).
+      const size_t per_col = 2 * (size_t)(world - 1);
+      const size_t cols_per_group = std::max<size_t>(1, max_group_ops() / per_col);
+      try {
+        for (size_t c0 = 0; c0 < ncols; c0 += cols_per_group) {
+          const size_t c1 = std::min(ncols, c0 + cols_per_group);
+          GroupGuard grp;
+          for (int k = 0; k < world; k++) {
+            if (k == rank) continue;
+            for (size_t c = c0; c < c1; c++) {
+              nccl_check(rccl().Send(send + (size_t)k * sps + c * scs, seg, ncclUint8, k, comm, stream), "ncclSend");
+              nccl_check(rccl().Recv(recv + (size_t)k * rps + c * rcs, seg, ncclUint8, k, comm, stream), "ncclRecv");
+            }
+          }
+          grp.end();
+          groups_issued++;
         }
+      } catch (...) {
+        fail();
+        throw;
       }
-      nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
     }
     HIP_CHECK(hipMemcpy2DAsync(recv + (size_t)rank * rps, rcs, send + (size_t)rank * sps, scs, seg, ncols, hipMemcpyDeviceToDevice, stream));
   }
   void gather(const void* send, void* recv, size_t n) {
     bytes_moved += n * (size_t)world;
     if (n == 0) return;
-    if (world > 1)
-      nccl_check(rccl().AllGather(send, recv, n, ncclUint8, comm, stream), "ncclAllGather");
-    else
+    if (world > 1) {
+      try {
+        nccl_check(rccl().AllGather(send, recv, n, ncclUint8, comm, stream), "ncclAllGather");
+      } catch (...) {
+        fail();
+        throw;
+      }
+    } else
       HIP_CHECK(hipMemcpyAsync(recv, send, n, hipMemcpyDeviceToDevice, stream));
   }
 };

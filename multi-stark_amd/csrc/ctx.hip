@@ -1,5 +1,8 @@
 // Device context: stream, twiddle tables, pooled memory, event-based per-kernel timing.
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include <cstdlib>
 #include <mutex>
@@ -55,6 +58,27 @@ void RoctxRange::next(const char* name) {
   }
 }
 
+// MSAMD_ABORT_TRACE=1 (diagnostics): a native backtrace on SIGABRT - the runtime's own assertions and std::terminate say
+// nothing about where they were raised
+namespace {
+void abort_trace(int) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  static const char msg[] = "[msamd] SIGABRT, native backtrace of the aborting thread:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(SIGABRT, SIG_DFL);
+  raise(SIGABRT);
+}
+void install_abort_trace() {
+  static const bool once = [] {
+    if (getenv("MSAMD_ABORT_TRACE")) signal(SIGABRT, abort_trace);
+    return true;
+  }();
+  (void)once;
+}
+}  // namespace
+
 void abandon_pending() {
   Ctx* c = tl_pending_ctx;
   tl_pending_ctx = nullptr;
@@ -107,6 +131,7 @@ void field_op(Ctx& ctx, int op, const u64* a, const u64* b, size_t n, u64* out) 
 }
 
 Ctx::Ctx(int dev) : device(dev) {
+  install_abort_trace();
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live.insert(this);

@@ -1,5 +1,6 @@
 """Transports for `System.prove_sharded` (ms_prove_sharded): the two exchanges the library asks for, on torch.distributed
-(`TorchComm`) or on the library's own RCCL transport (`RcclComm`, csrc/comm_rccl.hip - no torch involved).
+(`TorchComm`), on the library's own RCCL transport (`RcclComm`, csrc/comm_rccl.hip - no torch involved) or between threads
+of one process (`LocalGroup` / `LocalComm`, csrc/comm_local.hip - device copies, no collective library at all).
 
 `TorchComm` builds the `ms_comm` callback table of include/mstark.h. With backend "nccl" (= RCCL on ROCm) the device
 buffers the library hands over are wrapped as torch tensors in place (`__cuda_array_interface__`) and exchanged by
@@ -203,6 +204,95 @@ class RcclComm:
     def close(self):
         if getattr(self, "h", None):
             self._lib.ms_comm_rccl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LocalGroup:
+    """The rendezvous of the library's in-process transport (ms_comm_local_*, csrc/comm_local.hip): the ranks are threads of
+    this process, each with its own Context; the exchanges are device copies ordered by HIP events. `run(fn)` starts one
+    thread per rank, calls fn(rank, group) on each and returns the results in rank order; a rank that raises aborts the
+    group, so that the others return with an error instead of waiting for it."""
+
+    def __init__(self, world: int):
+        from . import lib, _check
+
+        self._lib = lib()
+        self.world = world
+        self.h = C.c_void_p()
+        _check(self._lib.ms_comm_local_group_create(C.c_int32(world), C.byref(self.h)))
+
+    def comm(self, ctx, rank: int):
+        return LocalComm(self, ctx, rank)
+
+    def abort(self):
+        if getattr(self, "h", None):
+            self._lib.ms_comm_local_group_abort(self.h)
+
+    def run(self, fn):
+        import threading
+
+        results, errors = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                results[r] = fn(r, self)
+            except BaseException as e:  # noqa: BLE001 - reported by the caller's thread
+                errors[r] = e
+                self.abort()
+
+        threads = [threading.Thread(target=body, args=(r,), name="ms-rank-%d" % r) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = [e for e in errors if e is not None and "local transport aborted" not in str(e)] or [e for e in errors if e is not None]
+        if first:
+            raise first[0]
+        return results
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.ms_comm_local_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LocalComm:
+    """One rank's handle of the in-process transport; `struct` is the ms_comm table ms_prove_sharded takes."""
+
+    def __init__(self, group: LocalGroup, ctx, rank: int):
+        from . import lib, _check
+
+        self._lib = lib()
+        self.group, self.ctx = group, ctx
+        self.rank, self.world = rank, group.world
+        self.h = C.c_void_p()
+        _check(self._lib.ms_comm_local_create(group.h, ctx.h, C.c_int32(rank), C.byref(self.h)))
+        self._lib.ms_comm_local_table.restype = C.c_void_p
+        self._lib.ms_comm_local_bytes_moved.restype = C.c_uint64
+        self.struct = MsComm.from_address(self._lib.ms_comm_local_table(self.h))
+
+    @property
+    def bytes_moved(self):
+        return int(self._lib.ms_comm_local_bytes_moved(self.h))
+
+    def reraise(self):
+        pass  # errors of this transport come back as the library's error codes
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.ms_comm_local_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,6 +1,9 @@
-"""GPU parity of the multi-rank prover (ms_prove_sharded): `world` processes (gloo transport, the ranks share the one
-GPU of the test box) prove the system [ByteTable, U32Add x world] together; every rank must return exactly the bytes
-the single-GPU prover produces for the same system and witness, and the oracle verifier must accept them."""
+"""GPU parity of the multi-rank prover (ms_prove_sharded): `world` ranks prove the system [ByteTable, U32Add x world]
+together; every rank must return exactly the bytes the single-GPU prover produces for the same system and witness, and the
+oracle verifier must accept them. The ranks share the one GPU of the test box, in two forms: processes over gloo
+(`TorchComm`, world <= 4: the box allows six processes on its card) and threads of the test process over the library's
+in-process transport (`LocalGroup`, csrc/comm_local.hip: world 8 = BASELINE config 3 as specified, and the same
+stream-ordered, non-blocking column exchange the RCCL transport offers, here with real peers)."""
 import hashlib
 import os
 import sys
@@ -234,3 +237,194 @@ def test_native_rccl_unique_id(pkg):
     sharded = importlib.import_module("multi_stark_amd.sharded")
     a, b = sharded.RcclComm.unique_id(), sharded.RcclComm.unique_id()
     assert len(a) == 128 and a != b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Thread ranks over the library's in-process transport: world 8 (BASELINE config 3: [ByteTable, U32Add x 8], one adder per
+# rank, benches/multi_stark.rs:260-267 x 8) on the one GPU, in ONE process (eight processes on the card would trip the box's
+# process guard; RCCL refuses two ranks on one device). log2 N = 3 head rounds of FRI, cap_height up to 3, 7-peer exchanges.
+def _params_for(fe, variant):
+    if variant.startswith("cap"):  # commitments are 2^k-digest caps, 4-coefficient final polynomial, host-driven FRI rounds
+        return fe.Params(log_blowup=2, cap_height=int(variant[3:]), log_final_poly_len=2, num_queries=20, commit_proof_of_work_bits=3,
+                         query_proof_of_work_bits=5)
+    return fe.bench_params()
+
+
+def _thread_rank(pkg, fe, sharded, oracle, rank, group, log_adds, variant, shared):
+    world = group.world
+    ctx = pkg.Context(0)
+    system = pkg.System.new(ctx, _params_for(fe, variant), fe.multi_u32_add_system_inputs(world))
+    traces, packed = shared["traces"], shared["packed"]
+    owners = sharded.u32_add_owners(world)
+    # (a rank's buffers are its own, as they would be in a process of its own: the host-resident witness page-locks them)
+    mine = [t.copy() if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+    remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+    w = system.witness(mine, packed, remote_heights=remote)
+    comm = group.comm(ctx, rank)
+    try:
+        proof = system.prove_sharded(w, comm, owners).to_bytes()
+        hw = system.host_witness(mine, packed, remote_heights=remote)  # traces + this rank's claim slice uploaded inside the proof
+        for _ in range(2):
+            assert system.prove_sharded(hw, comm, owners).to_bytes() == proof, "host-resident sharded proof differs"
+        del hw
+        again = system.prove_sharded(w, comm, owners, want_times=True)
+        assert again.to_bytes() == proof and again.stage_ms["total"] > 0
+        if rank == 0:
+            full = system.witness(traces, packed)
+            want = system.prove_multiple_claims(full).to_bytes()
+            assert proof == want, "sharded proof differs from the single-GPU proof"
+            osys = oracle.System(system.blob)
+            assert osys.verify(packed, proof) == 0
+            if log_adds <= 9:
+                assert osys.prove(traces, packed) == proof, "sharded proof differs from the oracle's proof"
+            assert system.verify_multiple_claims(packed, proof) == 0
+        assert world == 1 or comm.bytes_moved > 0
+        return hashlib.sha256(proof).hexdigest()
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world,log_adds,variant", [
+    (8, 8, "bench"), (8, 10, "bench"), (8, 8, "cap3"), (8, 10, "cap3"), (8, 9, "cap1"), (8, 9, "pack"), (8, 9, "host-sync"),
+    (8, 9, "no-overlap"), (8, 9, "full-fri"), (2, 9, "bench"), (4, 10, "bench"), (4, 9, "pack"), (1, 9, "bench")])
+def test_thread_ranks_proof_equals_single_gpu_proof(pkg, fe, oracle, world, log_adds, variant, monkeypatch):
+    import importlib
+
+    env = {"pack": "MSAMD_SHARDED_PACK", "host-sync": "MSAMD_SHARDED_HOST_SYNC", "no-overlap": "MSAMD_SHARDED_NO_OVERLAP",
+           "full-fri": "MSAMD_SHARDED_FULL_FRI"}.get(variant)
+    if env:
+        monkeypatch.setenv(env, "1")
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
+    shared = {"traces": traces, "packed": fe.pack_claims(claims)}
+    group = sharded.LocalGroup(world)
+    try:
+        res = group.run(lambda rank, g: _thread_rank(pkg, fe, sharded, oracle, rank, g, log_adds, variant, shared))
+    finally:
+        group.close()
+    assert len(set(res)) == 1, res  # every rank holds the same proof bytes
+
+
+def test_thread_ranks_failure_does_not_hang(pkg, fe, monkeypatch):
+    """a rank that fails in the middle of a joint proof (injected allocation failure) makes every rank return an error -
+    nobody waits for it forever - and the same contexts prove again afterwards"""
+    import importlib
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    monkeypatch.setenv("MSAMD_LOCAL_TIMEOUT_S", "20")
+    world = 4
+    traces, claims = fe.multi_u32_add_witness(world, 1 << 9)
+    packed = fe.pack_claims(claims)
+    owners = sharded.u32_add_owners(world)
+    ctxs = [pkg.Context(0) for _ in range(world)]
+    systems = [pkg.System.new(c, fe.bench_params(), fe.multi_u32_add_system_inputs(world)) for c in ctxs]
+    wits = []
+    for r in range(world):
+        mine = [t if owners[i] in (-1, r) else None for i, t in enumerate(traces)]
+        remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, r)}
+        wits.append(systems[r].witness(mine, packed, remote_heights=remote))
+
+    def attempt(fail_rank, nth):
+        group = sharded.LocalGroup(world)
+
+        def body(rank, g):
+            comm = g.comm(ctxs[rank], rank)
+            try:
+                if rank == fail_rank:
+                    ctxs[rank].debug_fail_alloc(nth)
+                return systems[rank].prove_sharded(wits[rank], comm, owners).to_bytes()
+            finally:
+                ctxs[rank].debug_fail_alloc(0)
+                comm.close()
+
+        try:
+            return group.run(body)
+        finally:
+            group.close()
+
+    good = attempt(-1, 0)
+    assert len(set(good)) == 1
+    for nth in (3, 25, 60):
+        with pytest.raises(pkg.MstarkError):
+            attempt(2, nth)
+        assert attempt(-1, 0) == good
+
+
+def _thread_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
+    """the random systems of _random_worker on thread ranks (same generator, same stream on every rank)"""
+    world = group.world
+    ctx = pkg.Context(0)
+    comm = group.comm(ctx, rank)
+    try:
+        master = np.random.default_rng(seed)
+        done = 0
+        for case in range(n_cases):
+            rng = np.random.default_rng(master.integers(0, 1 << 62))
+            lb = int(rng.integers(1, 3))
+            lw = world.bit_length() - 1
+            params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 1)), log_final_poly_len=0,
+                               num_queries=int(rng.integers(1, 12)), commit_proof_of_work_bits=int(rng.integers(0, 5)),
+                               query_proof_of_work_bits=int(rng.integers(0, 5)))
+            shard_ci, shard_w, fixed_h = fz.random_circuit(rng, fe, lb)
+            shard_h = fixed_h if fixed_h else 1 << int(rng.integers(3, 10))
+            if shard_h < world:
+                continue
+            circuits, traces, owners = [], [], []
+            n_rep = int(rng.integers(0, 3))
+            rep_positions = sorted(int(x) for x in rng.integers(0, world + 1, n_rep))
+            k = 0
+            for slot in range(world + 1):
+                for _ in range(rep_positions.count(slot)):
+                    ci, w, fh = fz.random_circuit(rng, fe, lb)
+                    h = fh if fh else 1 << int(rng.integers(3, 10))
+                    circuits.append(ci)
+                    traces.append(fz.rand_field(rng, (h, w)))
+                    owners.append(-1)
+                if slot < world:
+                    circuits.append(shard_ci)
+                    traces.append(fz.rand_field(rng, (shard_h, shard_w)))
+                    owners.append(k)
+                    k += 1
+            if any(t.shape[0] < world for t in traces):
+                continue
+            claims = [[int(x) for x in fz.rand_field(rng, int(rng.integers(0, 5)))] for _ in range(int(rng.integers(0, 4)))]
+            packed = fe.pack_claims(claims)
+            try:
+                compiled = [fe.compile_circuit(c) for c in circuits]
+            except fe.CompileError:
+                continue
+            try:
+                system = pkg.System(ctx, fe.system_blob(params, compiled), len(compiled))
+            except pkg.MstarkError:
+                continue  # e.g. a random constraint above the degree bound: every rank skips alike
+            mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+            remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+            proof = system.prove_sharded(system.witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+            if rank == case % world:  # the single-GPU proof of the same system, checked by a different rank every case
+                want = system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
+                assert proof == want, "random case %d: sharded proof differs from the single-GPU proof" % case
+            done += 1
+        return done
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world,seed", [(8, 11), (4, 12)])
+def test_thread_ranks_random_systems(pkg, fe, world, seed, monkeypatch):
+    import importlib
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as fz
+
+    monkeypatch.setenv("MSAMD_NO_JIT", "1")
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    n_cases = int(os.environ.get("MSAMD_SHARDED_FUZZ_CASES", "30"))
+    group = sharded.LocalGroup(world)
+    try:
+        res = group.run(lambda rank, g: _thread_random_rank(pkg, fe, fz, np, rank, g, seed, n_cases))
+    finally:
+        group.close()
+    assert len(set(res)) == 1 and res[0] >= 10, res
+    print("thread ranks, random systems:", res[0], "cases, world", world)
