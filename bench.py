@@ -37,7 +37,7 @@ from __graft_entry__ import load_package, load_oracle  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ALG_BYTES_PER_ROW = 5512
-TRAFFIC_FILE = "r02_traffic.json"
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 WORKLOAD = ("U32-add + byte-table lookup (benches/multi_stark.rs), 2^%d additions per %s, bench_config(): log_blowup 2, "
             "100 queries, 10+10 PoW bits, GoldilocksBlake3Config; %s, proof bytes returned to host")
 HOST_RESIDENT = ("witness (traces + claims, 64-bit words) in pinned host memory at step start: upload, from_stage_1 on the device "
@@ -80,19 +80,33 @@ class Watchdog:
     the others blocked forever, and a hang must not be recorded as a success. Whatever rank 0 has measured so far is
     printed first, with the error recorded."""
 
-    def __init__(self, rank, what, seconds, partial):
+    def __init__(self, rank, what, seconds, partial, ctx=None):
         self.done = threading.Event()
-        self.rank, self.what, self.seconds, self.partial = rank, what, seconds, partial
+        self.rank, self.what, self.seconds, self.partial, self.ctx = rank, what, seconds, partial, ctx
+        self.leg = "setup"
         threading.Thread(target=self._run, daemon=True).start()
+
+    def where(self):
+        """which collective this rank is in (the library records every call into the transport: ms_ctx_comm_progress)"""
+        if self.ctx is None:
+            return "leg '%s'" % self.leg
+        try:
+            text, seq, inside = self.ctx.comm_progress()
+        except Exception as e:  # noqa: BLE001
+            return "leg '%s' (no progress record: %s)" % (self.leg, e)
+        if not seq:
+            return "leg '%s', no exchange of the joint prover entered yet" % self.leg
+        return "leg '%s', %s exchange #%d of this process: %s" % (self.leg, "INSIDE" if inside else "after", seq, text)
 
     def _run(self):
         if self.done.wait(self.seconds):
             return
-        log("[rank %d] %s did not finish within %.0f s: exiting with status 3" % (self.rank, self.what, self.seconds))
+        where = self.where()
+        log("[rank %d] %s did not finish within %.0f s (%s): exiting with status 3" % (self.rank, self.what, self.seconds, where))
         if self.rank == 0:
             line = self.partial()
             if line is not None:
-                line["error"] = "%s timed out after %.0f s (collective hang or a failed rank)" % (self.what, self.seconds)
+                line["error"] = "%s timed out after %.0f s (collective hang or a failed rank); rank 0 was in %s" % (self.what, self.seconds, where)
                 print(json.dumps(line), flush=True)
         os._exit(3)
 
@@ -109,10 +123,7 @@ def profile_first_step(ctx, step, rank):
     table = ctx.kernel_stats()
     ctx.set_profile([])
     ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
-    dominant = ranked[0][0] if ranked and ranked[0][1]["ms"] > 0 else "ntt12_dif"
-    # the two transform passes take the same time to within a per cent: keep the pick stable from run to run
-    if dominant != "ntt12_dif" and ranked and table.get("ntt12_dif", {}).get("ms", 0) >= 0.97 * ranked[0][1]["ms"]:
-        dominant = "ntt12_dif"
+    dominant = ranked[0][0] if ranked and ranked[0][1]["ms"] > 0 else "ntt12_dif"  # the class that really took the most time
     if rank == 0:
         log("per-kernel-class device time of one proof (HIP events, profiled warmup step):")
         for n, s in ranked:
@@ -121,24 +132,38 @@ def profile_first_step(ctx, step, rank):
     return proof, dominant
 
 
-VALU_FILE = "r02_valu.json"
+VALU_FILES = ("r03_valu.json", "r02_valu.json")
 VALU_PEAK_TOPS = 39.4  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one integer VALU instruction per lane and clock
 
 
-def measured_valu(kernel):
-    """VALU lane-operations per launch of `kernel` from the committed SQ_INSTS_VALU pass (tools/valu_from_pmc.py)."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", VALU_FILE)))[kernel]["valu_lane_ops_per_launch"]
-    except Exception:
-        return None
+# algorithmic bytes per launch of the transform classes in the committed counter pass (config 2: 42 columns x 2^22 rows x 16 B
+# in 3 launches per pass); files written by this round's tools carry the figure themselves (alg_bytes_per_launch)
+PROFILE_ALG_BYTES = {"ntt12_dif": 939524096.0, "ntt8s_dif": 939524096.0}
+
+
+def measured_valu(kernel, bytes_per_launch=None):
+    """VALU lane-operations per launch of `kernel` from the committed SQ_INSTS_VALU pass (tools/valu_from_pmc.py). The pass
+    is of config 2's launches; a launch of another size (the joint prover transforms its columns in four groups) is priced by
+    the class's lane-operations per algorithmic byte, which does not depend on the launch size."""
+    for name in VALU_FILES:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]
+        except Exception:
+            continue
+        ops = rec["valu_lane_ops_per_launch"]
+        ref = rec.get("alg_bytes_per_launch") or PROFILE_ALG_BYTES.get(kernel)
+        if bytes_per_launch and ref:
+            return ops * bytes_per_launch / ref, name
+        return (ops, name) if not bytes_per_launch else (None, name)
+    return None, None
 
 
 def roofline_of(dominant, dom, full_size=True):
     avg_ms = dom["ms"] / max(dom["launches"], 1)
     bytes_per_launch = dom["alg_bytes"] / max(dom["launches"], 1)
     achieved = bytes_per_launch / max(avg_ms, 1e-12) / 1e6  # GB/s
-    line = _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved)
-    ops = measured_valu(dominant) if full_size else None
+    line = _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved, full_size)
+    ops, valu_file = measured_valu(dominant, None if full_size else bytes_per_launch)
     if ops:
         # the bound that binds: these kernels are integer arithmetic (no 64-bit multiplier on gfx950; DESIGN section 4), the
         # vector ALU issues at its peak long before HBM is busy. Counted instructions (every instruction as ONE issue slot,
@@ -146,13 +171,20 @@ def roofline_of(dominant, dom, full_size=True):
         tops = ops / max(avg_ms, 1e-12) / 1e9
         line["valu"] = {
             "what": "VALU lane-operations per launch (SQ_INSTS_VALU x 64 of the committed counter pass profiles/%s, same workload) "
-                    "/ this run's average launch time, against the integer issue peak" % VALU_FILE,
+                    "%s/ this run's average launch time, against the integer issue peak" % (
+                        valu_file, "" if full_size else "scaled by algorithmic bytes to this run's launch size "),
             "lane_ops_per_launch": ops, "achieved_Tops": tops, "peak_Tops": VALU_PEAK_TOPS, "frac": tops / VALU_PEAK_TOPS,
         }
     return line
 
 
-def _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved):
+def _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved, full_size=True):
+    traffic, tfile = measured_traffic(dominant)
+    note = "rocprofv3 --pmc passes of this command, committed; not re-measured in this run"
+    ref = PROFILE_ALG_BYTES.get(dominant)
+    if traffic is not None and not full_size:
+        # the committed pass is of config 2's launches: another launch size is priced by the measured traffic per algorithmic byte
+        traffic, note = (traffic * bytes_per_launch / ref, note + "; scaled by algorithmic bytes to this run's launch size") if ref else (None, note)
     return {
         "kernel": dominant,
         "bound": "hbm",
@@ -160,8 +192,8 @@ def _roofline_hbm(dominant, dom, avg_ms, bytes_per_launch, achieved):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": measured_traffic(dominant),
-        "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % TRAFFIC_FILE,
+        "traffic": traffic,
+        "traffic_source": "profiles/%s (%s)" % (tfile, note),
         "avg_launch_ms": avg_ms,
         "alg_bytes_per_launch": bytes_per_launch,
         "launches": dom["launches"],
@@ -466,7 +498,58 @@ def replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces
     }, dominant, dom, rows
 
 
-def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims):
+def joint_preflight(args, pkg, fe, ctx, torch, dist, sharded, system, comm, owners, rank, world, dev, wd):
+    """Before anything is timed: the joint proof of the SAME system at 2^12 additions per rank must have exactly the bytes of
+    the single-GPU proof of the full system (System::prove_multiple_claims on rank 0, which holds every trace at this size)
+    and be accepted by the verifier. First contact with several GPUs then fails HERE, with a reason, instead of as a
+    rejected proof after the measurement or as a hang in the middle of it."""
+    if wd is not None:
+        wd.leg = "joint proof, pre-flight at 2^12 additions per rank"
+    k = min(args.log_adds, 12)
+    traces, claims = fe.multi_u32_add_witness(world, 1 << k)  # deterministic: every rank builds the same small witness
+    packed = fe.pack_claims(claims)
+    mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+    remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+    got = system.prove_sharded(system.host_witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+    again = system.prove_sharded(system.witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+    ok, why = 1, ""
+    if again != got:
+        ok, why = 0, "rank %d: the joint proof from a device-resident witness differs from the host-resident one" % rank
+    if rank == 0 and ok:
+        want = system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
+        if got != want:
+            first = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), min(len(got), len(want)))
+            ok, why = 0, "joint proof (%d bytes) differs from the single-GPU proof (%d bytes) of the same system from byte %d" % (len(got), len(want), first)
+        elif system.verify_multiple_claims(packed, got) != 0:
+            ok, why = 0, "the verifier rejects the pre-flight proof"
+    # every rank must hold the same bytes; every rank learns the verdict
+    digest = np.frombuffer(hashlib.sha256(got).digest(), dtype=np.uint8).astype(np.int64)
+    flags = torch.tensor(np.concatenate([[ok], digest]), dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(flags) for _ in range(world)]
+    dist.all_gather(parts, flags)
+    parts = [p.cpu().numpy() for p in parts]
+    all_ok = all(int(p[0]) == 1 for p in parts)
+    same = all((p[1:] == parts[0][1:]).all() for p in parts)
+    info = {"log_adds": k, "ok": bool(all_ok and same), "proof_bytes": len(got), "proof_sha256": hashlib.sha256(got).hexdigest(),
+            "what": "joint proof of [ByteTable, U32Add x %d] at 2^%d additions per rank == System::prove_multiple_claims of the full system "
+                    "on rank 0, byte for byte; same bytes on every rank; verifier accepts" % (world, k)}
+    if not all_ok or not same:
+        info["error"] = why or ("the ranks hold different proof bytes" if not same else "another rank reported a mismatch")
+    if rank == 0:
+        log("pre-flight: joint proof at 2^%d additions per rank %s the single-GPU proof of the same system (%d bytes, sha256 %s)" % (
+            k, "==" if info["ok"] else "DIFFERS FROM", len(got), info["proof_sha256"][:16]))
+    if not info["ok"]:
+        raise PreflightFailed(info)
+    return info
+
+
+class PreflightFailed(RuntimeError):
+    def __init__(self, info):
+        super().__init__(info.get("error", "pre-flight failed"))
+        self.info = info
+
+
+def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims, wd=None):
     """ONE proof of [ByteTable, U32Add x N] by all ranks per step (ms_prove_sharded); setup (untimed, like criterion's setup
     closure): the byte table's multiplicities are the sum over ranks (plain integer counts) and every rank holds all
     claims, which the transcript absorbs in order"""
@@ -497,11 +580,16 @@ def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
     else:
         comm = sharded.TorchComm(local_rank)
     rows = 256 + world * traces[1].shape[0]
+    preflight = joint_preflight(args, pkg, fe, ctx, torch, dist, sharded, system, comm, owners, rank, world, dev, wd)
 
     def step():
         return system.prove_sharded(witness, comm, owners)
 
+    if wd is not None:
+        wd.leg = "joint proof, first full-size proof (fills the pool, opens the transport's channels)"
     proof = step()  # fills the pool, opens the RCCL channels
+    if wd is not None:
+        wd.leg = "joint proof, warm-up and timed steps"
     comm.bytes_moved = 0
     proof, elapsed, dominant, dom = timed_steps(args, ctx, torch, dist, step, lambda: None, dev)
     moved = comm.bytes_moved // (args.steps + max(args.warmup, 1))
@@ -520,7 +608,7 @@ def joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
         "value": rows * args.steps / elapsed, "unit": "rows/s", "ms_per_step": 1e3 * elapsed / args.steps,
         "rows_per_proof": rows, "proof_bytes": len(proof.to_bytes()), "proof_sha256": sha, "transport": transport,
         "bytes_exchanged_per_rank_per_proof": moved, "stage_ms": {k: round(v, 3) for k, v in stage.items()},
-        "verified": verdict == 0,
+        "verified": verdict == 0, "preflight": preflight,
     }
     if verdict != 0:
         info["error"] = "the joint proof is REJECTED by the verifier (code %d): the figures of this leg are void" % verdict
@@ -547,12 +635,21 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
             return line
         return base_line(args, n_gpus, None, None)
 
-    wd = Watchdog(rank, "the multi-GPU bench", args.primary_timeout, partial)
+    wd = Watchdog(rank, "the multi-GPU bench", args.primary_timeout, partial, ctx)
     joint_primary = not args.replicas_primary
     if not args.no_replicas_leg or not joint_primary:
+        wd.leg = "replicas (one independent proof per rank)"
         done["replicas"] = replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces, claims)
     if joint_primary or not args.no_joint_leg:
-        done["joint"] = joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims)
+        try:
+            done["joint"] = joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims, wd)
+        except PreflightFailed as e:
+            # nothing of the joint leg is timed on a prover whose bytes are wrong: report what there is, with the reason
+            wd.finish()
+            line = partial()
+            line["error"] = "joint proof pre-flight failed: %s" % e
+            line["preflight"] = e.info
+            return line
     wd.finish()
     prim = done["joint"] if joint_primary else done["replicas"]
     info, dominant, dom, rows = prim
@@ -575,6 +672,15 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
         if "error" in info:
             result["error"] = info["error"]
     result["roofline"] = roofline_of(dominant, dom, full_size=False)
+    if joint_primary:
+        result["config"]["preflight"] = info.get("preflight")
+    if not args.no_cpu_baseline and rank == 0:
+        # the same CPU leg as at N = 1 (one [ByteTable, U32Add] proof at 2^cpu-log-adds additions on this box's host cores): rows/s of
+        # the restatement does not depend on how many adders the system holds. The other ranks wait at the closing barrier.
+        one = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+        result["cpu_baseline"] = cpu_baseline(fe, one.blob, args.cpu_log_adds)
+        result["cpu_baseline"]["sample"] += "; measured on rank 0's host cores while the other ranks idle"
+        del one
     if joint_primary and "replicas" in done:
         result["replicas"] = done["replicas"][0]
     if not joint_primary and "joint" in done:
@@ -638,12 +744,12 @@ def main():
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, corrected as MI355X_MICROARCH.md prescribes; tools/traffic_from_pmc.py)."""
-    for name in (TRAFFIC_FILE, "r01_traffic.json"):
+    for name in TRAFFIC_FILES:
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]["hbm_bytes_per_launch"]
+            return json.load(open(os.path.join(ROOT, "profiles", name)))[kernel]["hbm_bytes_per_launch"], name
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def cpu_baseline(fe, blob, log_adds):

@@ -83,6 +83,7 @@ extern "C" {
                      proof_len: usize, verdict: *mut i32) -> i32;
     pub fn ms_prove_sharded(sys: *mut ms_system, w: *mut ms_witness, comm: *const ms_comm, owners: *const i32, proof_out: *mut u8,
                             cap: usize, proof_len: *mut usize, stage_ms: *mut f64) -> i32;
+    pub fn ms_ctx_comm_progress(ctx: *mut ms_ctx, out: *mut c_char, cap: usize, seq: *mut u64, in_flight: *mut i32) -> i32;
     pub fn ms_comm_rccl_unique_id(out: *mut u8) -> i32;
     pub fn ms_comm_rccl_create(ctx: *mut ms_ctx, unique_id: *const u8, rank: i32, world: i32, out: *mut *mut ms_comm_rccl) -> i32;
     pub fn ms_comm_rccl_table(c: *mut ms_comm_rccl) -> *const ms_comm;

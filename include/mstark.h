@@ -190,6 +190,13 @@ typedef struct ms_comm {
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms);
 
+/* Where a joint proof is: the library records every call it makes into the transport - the prover's phase, the collective,
+ * its size, the rank ("stage-2 commit: all_to_all_cols_start (29360128 bytes, part 3) on rank 5 of 8"). `out` receives the
+ * text of the LAST call entered through this context, *seq how many have been entered since the context was created and
+ * *in_flight whether that call has not returned yet. Callable from any thread while ms_prove_sharded runs on another (it is
+ * what a watchdog prints when a peer never joins a collective: which exchange, on which rank). */
+int32_t ms_ctx_comm_progress(ms_ctx* ctx, char* out, size_t cap, uint64_t* seq, int32_t* in_flight);
+
 /* ---- Native transport for ms_prove_sharded: RCCL over xGMI (csrc/comm_rccl.hip; librccl is loaded at run time). The host
  * needs no Python: rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever channel the
  * host already has (a file, MPI, a TCP store); every rank then creates its transport on its own context (collective:

@@ -44,7 +44,7 @@ def exported_symbols():
     return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_witness_prefetch",
-            "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
+            "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_ctx_comm_progress", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
             "ms_comm_rccl_table", "ms_comm_rccl_bytes_moved", "ms_comm_rccl_destroy", "ms_comm_local_group_create", "ms_comm_local_group_abort",
             "ms_comm_local_group_destroy", "ms_comm_local_create", "ms_comm_local_table", "ms_comm_local_bytes_moved", "ms_comm_local_destroy", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
             "ms_mmcs_open", "ms_mmcs_destroy", "ms_blake3", "ms_pcs_commit", "ms_pcs_open", "ms_pcs_verify", "ms_challenger_create",
@@ -97,6 +97,14 @@ class Context:
 
     def trim(self):
         _check(lib().ms_ctx_trim(self.h))
+
+    def comm_progress(self):
+        """(text of the last transport call ms_prove_sharded entered through this context, calls entered so far, still inside?) -
+        readable from another thread while the proof runs"""
+        buf = C.create_string_buffer(256)
+        seq, fl = C.c_uint64(), C.c_int32()
+        _check(lib().ms_ctx_comm_progress(self.h, buf, C.c_size_t(256), C.byref(seq), C.byref(fl)))
+        return buf.value.decode(), int(seq.value), bool(fl.value)
 
     def debug_fail_alloc(self, nth):
         """diagnostics: the nth device allocation from now raises (0 = off)"""

@@ -104,6 +104,8 @@ Ctx* ctx_of(ms_ctx* c) {
   if (!c) throw std::runtime_error("null context");
   return &c->ctx;
 }
+std::string last_error_text() { return g_err; }
+void clear_last_error() { g_err.clear(); }
 void ctx_retain(ms_ctx* c) { c->refs++; }
 void ctx_release(ms_ctx* c) { ctx_unref(c); }
 }  // namespace msamd
@@ -268,6 +270,7 @@ int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, con
   MS_TRY StageMs st;
   if (!comm || !owners || !comm->all_to_all || !comm->all_gather) throw std::runtime_error("ms_prove_sharded: incomplete ms_comm");
   if (comm->rank < 0 || comm->rank >= comm->world) throw std::runtime_error("ms_prove_sharded: rank out of range");
+  g_err.clear();  // (a failing transport callback leaves its reason here; prove_sharded quotes it)
   std::vector<uint8_t> bytes = prove_sharded(*sys->sys, *w->w, comm, owners, stage_ms ? &st : nullptr);
   if (stage_ms) memcpy(stage_ms, st.v, sizeof(st.v));
   *proof_len = bytes.size();
@@ -275,6 +278,19 @@ int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, con
   memcpy(proof_out, bytes.data(), bytes.size());
   return MS_OK;
   MS_CATCH
+}
+
+int32_t ms_ctx_comm_progress(ms_ctx* ctx, char* out, size_t cap, uint64_t* seq, int32_t* in_flight) {
+  if (!ctx) return MS_ERR;
+  std::lock_guard<std::mutex> lk(ctx->ctx.comm_mu);
+  if (out && cap) {
+    const size_t n = std::min(cap - 1, ctx->ctx.comm_what.size());
+    memcpy(out, ctx->ctx.comm_what.data(), n);
+    out[n] = 0;
+  }
+  if (seq) *seq = ctx->ctx.comm_seq;
+  if (in_flight) *in_flight = ctx->ctx.comm_in_flight ? 1 : 0;
+  return MS_OK;
 }
 
 int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets, const uint64_t* claim_data, const uint8_t* proof,

@@ -14,6 +14,7 @@ namespace msamd {
 
 // ---- BLAKE3 on the host (challenger, grinding)
 void blake3_host(const uint8_t* in, size_t len, uint8_t out[32]);
+std::string last_error_text();  // the calling thread's ms_last_error() text (capi.hip)
 
 // DeterministicPow<SerializingChallenger64<Goldilocks, HashChallenger<u8, Blake3, 32>>>, src/types.rs:28-81
 struct Challenger {

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -122,6 +123,14 @@ struct Ctx {
   std::vector<Pending> prof_pending;
   std::vector<hipEvent_t> event_pool;
   KernelStat stats[K_COUNT];
+
+  // Progress of the multi-rank prover's exchanges (prover_sharded.inc): which collective this rank entered last, how many
+  // it has entered, and whether it has returned from it. Read by another thread (ms_ctx_comm_progress: a watchdog that must
+  // say WHERE a joint proof hangs when a peer never arrives).
+  std::mutex comm_mu;
+  std::string comm_what;
+  uint64_t comm_seq = 0;
+  bool comm_in_flight = false;
 
   explicit Ctx(int dev);
   ~Ctx();

@@ -22,7 +22,16 @@ class _R:
         self.o += 8
         return v
 
+    def cnt(self):
+        """a length prefix: never more items than bytes left (a foreign or corrupted layout must fail, not loop)"""
+        v = self.u64()
+        if v > len(self.b) - self.o:
+            raise ValueError("proof layout: a length prefix of %d at byte %d exceeds the %d bytes left" % (v, self.o - 8, len(self.b) - self.o))
+        return v
+
     def fe(self):
+        if self.o + _ELEM > len(self.b):
+            raise ValueError("proof layout: truncated at byte %d" % self.o)
         v = int.from_bytes(self.b[self.o:self.o + _ELEM], "little")
         self.o += _ELEM
         return v
@@ -36,10 +45,10 @@ class _R:
         return [self.fe() for _ in range(_DEG)]
 
     def cap(self):
-        return [self.raw(32) for _ in range(self.u64())]
+        return [self.raw(32) for _ in range(self.cnt())]
 
     def round(self):
-        return [[[self.ext() for _ in range(self.u64())] for _ in range(self.u64())] for _ in range(self.u64())]
+        return [[[self.ext() for _ in range(self.cnt())] for _ in range(self.cnt())] for _ in range(self.cnt())]
 
 
 class _W:
@@ -77,24 +86,24 @@ def parse(b, elem_bytes=8, ext_degree=2):
     global _ELEM, _DEG
     _ELEM, _DEG = elem_bytes, ext_degree
     r = _R(b)
-    p = {"active": [r.u8() for _ in range(r.u64())]}
+    p = {"active": [r.u8() for _ in range(r.cnt())]}
     p["stage_1_commit"], p["stage_2_commit"], p["quotient_commit"] = r.cap(), r.cap(), r.cap()
-    p["intermediate_accumulators"] = [r.ext() for _ in range(r.u64())]
-    p["log_degrees"] = [r.u8() for _ in range(r.u64())]
-    fri = {"commit_phase_commits": [r.cap() for _ in range(r.u64())], "commit_pow_witnesses": [r.fe() for _ in range(r.u64())]}
+    p["intermediate_accumulators"] = [r.ext() for _ in range(r.cnt())]
+    p["log_degrees"] = [r.u8() for _ in range(r.cnt())]
+    fri = {"commit_phase_commits": [r.cap() for _ in range(r.cnt())], "commit_pow_witnesses": [r.fe() for _ in range(r.cnt())]}
     qs = []
-    for _ in range(r.u64()):
+    for _ in range(r.cnt()):
         q = {"input_proof": [], "commit_phase_openings": []}
-        for _ in range(r.u64()):
-            rows = [[r.fe() for _ in range(r.u64())] for _ in range(r.u64())]
-            q["input_proof"].append({"opened_values": rows, "proof": [r.raw(32) for _ in range(r.u64())]})
-        for _ in range(r.u64()):
+        for _ in range(r.cnt()):
+            rows = [[r.fe() for _ in range(r.cnt())] for _ in range(r.cnt())]
+            q["input_proof"].append({"opened_values": rows, "proof": [r.raw(32) for _ in range(r.cnt())]})
+        for _ in range(r.cnt()):
             la = r.u8()
-            sib = [r.ext() for _ in range(r.u64())]
-            q["commit_phase_openings"].append({"log_arity": la, "sibling_values": sib, "proof": [r.raw(32) for _ in range(r.u64())]})
+            sib = [r.ext() for _ in range(r.cnt())]
+            q["commit_phase_openings"].append({"log_arity": la, "sibling_values": sib, "proof": [r.raw(32) for _ in range(r.cnt())]})
         qs.append(q)
     fri["query_proofs"] = qs
-    fri["final_poly"] = [r.ext() for _ in range(r.u64())]
+    fri["final_poly"] = [r.ext() for _ in range(r.cnt())]
     fri["query_pow_witness"] = r.fe()
     p["opening_proof"] = fri
     p["quotient_opened_values"] = r.round()
