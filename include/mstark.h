@@ -186,7 +186,14 @@ typedef struct ms_comm {
    * twenty times less often this way. set_stream_ordered(user, NULL) restores the blocking contract; ms_prove_sharded
    * switches the mode on for its own duration when the transport offers it (MSAMD_SHARDED_HOST_SYNC=1: never). */
   int32_t (*set_stream_ordered)(void* user, void* hip_stream);
+  /* Optional (NULL = not offered): all_to_all_cols_start with flags. MS_COMM_SKIP_SELF: the rank's own segments (k = rank) are
+   * NOT copied - the library hashes and reduces its own rows where they are, inside its LDE, so that block of the receive buffer
+   * is never read (at world 1 the exchange then moves nothing at all). Without this member the library calls
+   * all_to_all_cols_start; the self-copy is then made and ignored. */
+  int32_t (*all_to_all_cols_start2)(void* user, const void* send_dev, size_t send_peer_stride, size_t send_col_stride, void* recv_dev,
+                                    size_t recv_peer_stride, size_t recv_col_stride, size_t ncols, size_t seg_bytes, uint32_t flags);
 } ms_comm;
+#define MS_COMM_SKIP_SELF 1u
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms);
 

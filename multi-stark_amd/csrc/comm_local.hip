@@ -114,9 +114,9 @@ struct ms_comm_local {
     }
   }
   // steps 1-4 of the protocol; `recv*` describe where block k (from rank k) lands on this rank
-  void collective(const Offer& mine, uint8_t* recv, size_t recv_peer_stride, size_t recv_col_stride, const char* what) {
+  void collective(const Offer& mine, uint8_t* recv, size_t recv_peer_stride, size_t recv_col_stride, const char* what, bool skip_self = false) {
     const int N = g->world;
-    bytes_moved += mine.seg * mine.ncols * (size_t)N;
+    bytes_moved += mine.seg * mine.ncols * (size_t)(skip_self ? N - 1 : N);
     try {
       g->offers[rank] = mine;
       HIP_CHECK(hipEventRecord(g->ready[rank], stream));
@@ -131,6 +131,7 @@ struct ms_comm_local {
       if (mine.seg && mine.ncols) {
         for (int k = 0; k < N; k++) {
           const Offer& o = g->offers[k];
+          if (k == rank && skip_self) continue;
           if (k != rank) HIP_CHECK(hipStreamWaitEvent(stream, g->ready[k], 0));
           const uint8_t* src = mine.kind == OP_GATHER ? o.send : o.send + (size_t)rank * o.send_peer_stride;
           uint8_t* dst = recv + (size_t)k * recv_peer_stride;
@@ -212,6 +213,21 @@ int32_t cb_cols_start(void* user, const void* send, size_t sps, size_t scs, void
     o.seg = seg;
     c->begin();
     c->collective(o, (uint8_t*)recv, rps, rcs, "all_to_all_cols_start");
+  });
+}
+int32_t cb_cols_start2(void* user, const void* send, size_t sps, size_t scs, void* recv, size_t rps, size_t rcs, size_t ncols, size_t seg,
+                       uint32_t flags) {
+  ms_comm_local* c = (ms_comm_local*)user;
+  return guarded(c, [&] {
+    Offer o;
+    o.kind = OP_COLS;
+    o.send = (const uint8_t*)send;
+    o.send_peer_stride = sps;
+    o.send_col_stride = scs;
+    o.ncols = ncols;
+    o.seg = seg;
+    c->begin();
+    c->collective(o, (uint8_t*)recv, rps, rcs, "all_to_all_cols_start", (flags & MS_COMM_SKIP_SELF) != 0);
   });
 }
 int32_t cb_wait(void* user) {
@@ -315,6 +331,7 @@ int32_t ms_comm_local_create(ms_comm_local_group* g, ms_ctx* ctx, int32_t rank, 
     c->table.all_to_all_wait = cb_wait;
     c->table.all_to_all_cols_start = cb_cols_start;
     c->table.set_stream_ordered = cb_set_stream_ordered;
+    c->table.all_to_all_cols_start2 = cb_cols_start2;
     c->owner = ctx;
     ctx_retain(ctx);
     *out = c;

@@ -175,8 +175,9 @@ struct ms_comm_rccl {
   }
   // the exchange read straight out of a column-major matrix (ms_comm.all_to_all_cols_start): one ncclSend / ncclRecv per
   // peer and column in ONE group (4 MB segments at the bench size); this rank's own rows are a strided device copy
-  void exchange_cols(const uint8_t* send, size_t sps, size_t scs, uint8_t* recv, size_t rps, size_t rcs, size_t ncols, size_t seg) {
-    bytes_moved += seg * ncols * (size_t)world;
+  void exchange_cols(const uint8_t* send, size_t sps, size_t scs, uint8_t* recv, size_t rps, size_t rcs, size_t ncols, size_t seg,
+                     bool skip_self = false) {
+    bytes_moved += seg * ncols * (size_t)(skip_self ? world - 1 : world);
     if (seg == 0 || ncols == 0) return;
     if (world > 1) {
       // every rank cuts the columns into the same groups, and inside a group every send has its receive on the peer: the
@@ -203,7 +204,8 @@ struct ms_comm_rccl {
         throw;
       }
     }
-    HIP_CHECK(hipMemcpy2DAsync(recv + (size_t)rank * rps, rcs, send + (size_t)rank * sps, scs, seg, ncols, hipMemcpyDeviceToDevice, stream));
+    if (!skip_self)
+      HIP_CHECK(hipMemcpy2DAsync(recv + (size_t)rank * rps, rcs, send + (size_t)rank * sps, scs, seg, ncols, hipMemcpyDeviceToDevice, stream));
   }
   void gather(const void* send, void* recv, size_t n) {
     bytes_moved += n * (size_t)world;
@@ -260,6 +262,14 @@ int32_t cb_cols_start(void* user, const void* send, size_t sps, size_t scs, void
   return guarded(c, [&] {
     c->begin();
     c->exchange_cols((const uint8_t*)send, sps, scs, (uint8_t*)recv, rps, rcs, ncols, seg);
+  });
+}
+int32_t cb_cols_start2(void* user, const void* send, size_t sps, size_t scs, void* recv, size_t rps, size_t rcs, size_t ncols, size_t seg,
+                       uint32_t flags) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] {
+    c->begin();
+    c->exchange_cols((const uint8_t*)send, sps, scs, (uint8_t*)recv, rps, rcs, ncols, seg, (flags & MS_COMM_SKIP_SELF) != 0);
   });
 }
 int32_t cb_wait(void* user) {
@@ -321,6 +331,7 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
     c->table.all_to_all_wait = cb_wait;
     c->table.all_to_all_cols_start = cb_cols_start;
     c->table.set_stream_ordered = cb_set_stream_ordered;
+    c->table.all_to_all_cols_start2 = cb_cols_start2;
     c->owner = ctx;
     ctx_retain(ctx);
     *out = c;

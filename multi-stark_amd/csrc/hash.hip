@@ -28,9 +28,11 @@ struct RowIter {
   u32 c;
   const u64* cur;  // column c of matrix mi at this row
   u32 w;           // width of matrix mi
+  size_t stride;   // its column stride (H unless the rows are a window of a taller matrix)
   __device__ __forceinline__ void init() {
     cur = g[0].d + row;
     w = g[0].w;
+    stride = g[0].stride;
   }
   __device__ __forceinline__ u64 next() {
     while (c == w) {  // next matrix of the group (never taken for a single-matrix group)
@@ -38,12 +40,13 @@ struct RowIter {
       c = 0;
       cur = g[mi].d + row;
       w = g[mi].w;
+      stride = g[mi].stride;
     }
     // the matrix pointers come out of a descriptor in memory, so the compiler only knows them as generic pointers and
     // would emit flat loads (which also count against the LDS counter); they are device allocations: say so
     typedef const u64 __attribute__((address_space(1))) * GlobalPtr;
     u64 v = *(GlobalPtr)cur;
-    cur += H;
+    cur += stride;
     c++;
     return v;
   }
@@ -63,7 +66,7 @@ __device__ __forceinline__ void parent_cv(const u32 l[8], const u32 r[8], u32 fl
 // BLAKE3 of the serialised row (total_w elements, 8 bytes each). MULTI: rows longer than one 1024-byte chunk.
 template <bool MULTI>
 __device__ __forceinline__ void hash_row(const MatRef* g, size_t H, size_t row, u32 total_w, u32 out[8]) {
-  RowIter it{g, H, row, 0, 0, nullptr, 0};
+  RowIter it{g, H, row, 0, 0, nullptr, 0, 0};
   it.init();
   u32 cv[8];
   b3_iv(cv);
@@ -151,9 +154,10 @@ __global__ __launch_bounds__(256) void leaf_hash_k(const MatRef* __restrict__ g,
 // room: the loads sit under branches and everything outstanding is waited for in front of each compression. Here the
 // column pointer is a kernel argument, every load is unconditional (the last block re-reads the last column and masks
 // it) and the loads of block b + 1 are issued in front of the compression of block b.
-__global__ __launch_bounds__(256) void leaf_hash_single_k(const u64* __restrict__ d, size_t H, u32 w, Digest* __restrict__ out) {
+__global__ __launch_bounds__(256) void leaf_hash_single_k(const u64* __restrict__ d, size_t rows, size_t H /* column stride */, u32 w,
+                                                          Digest* __restrict__ out) {
   const size_t row = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (row >= H) return;
+  if (row >= rows) return;
   const u64* __restrict__ p = d + row;
   const u32 nblocks = (w + 7) >> 3, last_c = w - 1;
   u32 cv[8];
@@ -852,7 +856,12 @@ void merkle_build(Ctx& ctx, DTree& t) {
   merkle_alloc(ctx, t, maxh);
   // group descriptors, sorted order
   std::vector<MatRef> refs(nm);
-  for (size_t k = 0; k < nm; k++) refs[k] = MatRef{t.mat_d[order[k]], (uint32_t)t.mat_w[order[k]], 0};
+  if (!t.mat_stride.empty() && t.mat_stride.size() != nm) throw std::runtime_error("merkle_build: one column stride per matrix expected");
+  auto stride_of = [&](size_t i) { return t.mat_stride.empty() ? t.mat_h[i] : t.mat_stride[i]; };
+  for (size_t k = 0; k < nm; k++) {
+    if (stride_of(order[k]) < t.mat_h[order[k]]) throw std::runtime_error("merkle_build: column stride below the matrix height");
+    refs[k] = MatRef{t.mat_d[order[k]], (uint32_t)t.mat_w[order[k]], 0, (uint64_t)stride_of(order[k])};
+  }
   DBuf<MatRef> drefs(ctx, nm);
   ctx.h2d(drefs.p, refs.data(), nm * sizeof(MatRef));
   size_t pos = 0;
@@ -874,7 +883,7 @@ void merkle_build(Ctx& ctx, DTree& t) {
     dim3 grid((unsigned)((maxh + 255) / 256));
     hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
     if (tw <= 128 && count == 1 && !getenv("MSAMD_GENERIC_LEAF_HASH"))
-      hipLaunchKernelGGL(leaf_hash_single_k, grid, dim3(256), 0, ctx.stream, t.mat_d[order[first]], maxh, tw, t.base());
+      hipLaunchKernelGGL(leaf_hash_single_k, grid, dim3(256), 0, ctx.stream, t.mat_d[order[first]], maxh, stride_of(order[first]), tw, t.base());
     else if (tw <= 128)
       hipLaunchKernelGGL(leaf_hash_k<false>, grid, dim3(256), 0, ctx.stream, drefs.p + first, maxh, tw, t.base());
     else

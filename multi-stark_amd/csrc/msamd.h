@@ -248,11 +248,13 @@ struct MatRef {
   const u64* d;
   uint32_t w;
   uint32_t pad;
+  uint64_t stride;  // elements between consecutive columns (= the matrix height unless the rows are a window of a taller matrix)
 };
 // Merkle tree over column-major matrices (heights powers of two), p3 MerkleTreeMmcs semantics
 struct DTree {
   std::vector<const u64*> mat_d;   // matrices in input order (not owned)
   std::vector<size_t> mat_h, mat_w;
+  std::vector<size_t> mat_stride;  // optional: column stride of each matrix when it is not its height (a row range read in place)
   DBuf<Digest> digests;            // all layers back to back, leaf layer first
   Digest* ext = nullptr;           // layers living in someone else's buffer (FRI tail rounds); overrides `digests`
   Digest* base() const { return ext ? ext : digests.p; }
@@ -366,6 +368,7 @@ struct DeepMat {
   uint32_t pt[2];       // which of the launch's points each opening uses
   E2 coeff[2];          // alpha^{offset_p}
   uint64_t coeff7[2];   // 7 * coeff.c1 (X^2 = 7), for the lazy product with the column sums
+  uint64_t stride;      // column stride in elements; 0 = the launch's height (the rows are the whole matrix)
 };
 struct DeepPoints {
   uint32_t n;           // opening points at this height (at most two: zeta and zeta * g)

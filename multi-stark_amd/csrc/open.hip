@@ -199,11 +199,12 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
     typedef const Pair __attribute__((address_space(1))) * GlobalPair;
     const u64* __restrict__ md = dm.d + i;
     const u32 mw = dm.w;
+    const size_t mstride = dm.stride ? (size_t)dm.stride : p.height;
     u32 c = 0;
     for (; c + 8 <= mw; c += 8) {  // eight 16-byte loads in flight per lane before the first use
       Pair v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = *(GlobalPair)(md + size_t(c + u) * p.height);
+      for (int u = 0; u < 8; u++) v[u] = *(GlobalPair)(md + size_t(c + u) * mstride);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const E2 a = apow[c + u];
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
       }
     }
     for (; c < mw; c++) {
-      const Pair v = *(GlobalPair)(md + size_t(c) * p.height);
+      const Pair v = *(GlobalPair)(md + size_t(c) * mstride);
       const E2 a = apow[c];
       accs_mad(a00, a.c0, v.x);
       accs_mad(a01, a.c1, v.x);

@@ -14,12 +14,14 @@ _START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, 
 _WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 _ORDERED = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
 _COLS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t)
+_COLS2 = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32)
 
 
 class MsComm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB),
                 ("all_to_all_start", _START), ("all_to_all_wait", _WAIT), ("all_to_all_cols_start", _COLS),
-                ("set_stream_ordered", _ORDERED)]  # (TorchComm leaves it NULL: its callbacks synchronise with the host)
+                ("set_stream_ordered", _ORDERED),  # (TorchComm leaves it NULL: its callbacks synchronise with the host)
+                ("all_to_all_cols_start2", _COLS2)]  # (NULL in TorchComm: the library then calls all_to_all_cols_start)
 
 
 class _DevBytes:
