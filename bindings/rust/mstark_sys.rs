@@ -148,6 +148,8 @@ extern "C" {
     pub fn msbb_system_circuit_info(sys: *const msbb_system, circuit: usize, out9: *mut u64) -> i32;
     pub fn msbb_witness_create(sys: *mut msbb_system, traces: *const *const u32, heights: *const u64, n_claims: usize,
                                claim_offsets: *const u64, claim_data: *const u32, out: *mut *mut msbb_witness) -> i32;
+    pub fn msbb_witness_create_host(sys: *mut msbb_system, traces: *const *const u32, heights: *const u64, n_claims: usize,
+                                    claim_offsets: *const u64, claim_data: *const u32, pinned: *mut i32, out: *mut *mut msbb_witness) -> i32;
     pub fn msbb_witness_destroy(w: *mut msbb_witness);
     pub fn msbb_prove(sys: *mut msbb_system, w: *mut msbb_witness, proof_out: *mut u8, cap: usize, proof_len: *mut usize,
                       stage_ms: *mut f64) -> i32;

@@ -150,8 +150,12 @@ int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets
  * Every rank creates the SAME system and a witness that holds: the traces of the circuits it computes (its own
  * "sharded" circuit and every replicated one; traces[i] = NULL with heights[i] > 0 marks a circuit computed elsewhere),
  * the heights of all circuits, and all claims. owners[i] = rank that computes circuit i, or -1 = replicated on every
- * rank (small tables). Exactly one sharded circuit per rank, all of one shape, the k-th of them owned by rank k; the
- * number of ranks is a power of two.
+ * rank (small tables). A rank may own any number of circuits (none included) of any shapes: the reference's multi-circuit
+ * systems (one wide circuit beside tables of other widths and heights, src/test_circuits/blake3.rs:2215-2613) split as they
+ * are. Limits: the number of ranks is a power of two; every committed LDE has at least as many rows as there are ranks;
+ * cap_height <= log2(ranks). When there is exactly one sharded circuit per rank, all of one shape, the k-th owned by rank k
+ * (BASELINE config 3) the row ranges travel by one symmetric all-to-all per column group; otherwise every sharded matrix is
+ * handed out by its owner (ms_comm.scatter_cols_start, which the transport must then offer).
  * The library calls back for the two exchanges it needs; both take DEVICE pointers of this context's device, are
  * called with the context's stream idle, and must have completed when they return (0 = ok):
  *   all_to_all: send/recv hold `world` blocks of bytes_per_peer bytes; block k of send goes to rank k, block k of recv
@@ -192,6 +196,14 @@ typedef struct ms_comm {
    * all_to_all_cols_start; the self-copy is then made and ignored. */
   int32_t (*all_to_all_cols_start2)(void* user, const void* send_dev, size_t send_peer_stride, size_t send_col_stride, void* recv_dev,
                                     size_t recv_peer_stride, size_t recv_col_stride, size_t ncols, size_t seg_bytes, uint32_t flags);
+  /* Optional (NULL = not offered; needs all_to_all_wait): ONE rank's matrix handed out by row ranges - what the library uses
+   * when the sharded circuits differ in shape or in number per rank. Rank `root` sends, to every OTHER rank k, ncols segments
+   * of seg_bytes read at send_dev + k * send_peer_stride + c * send_col_stride; every other rank receives its ncols
+   * segments at recv_dev + c * recv_col_stride. Nothing is copied for k = root (its rows stay where they are); send_dev is
+   * ignored on the other ranks, recv_dev on root. Non-blocking like all_to_all_start, completed by all_to_all_wait; every
+   * rank makes the same sequence of calls. */
+  int32_t (*scatter_cols_start)(void* user, int32_t root, const void* send_dev, size_t send_peer_stride, size_t send_col_stride,
+                                void* recv_dev, size_t recv_col_stride, size_t ncols, size_t seg_bytes);
 } ms_comm;
 #define MS_COMM_SKIP_SELF 1u
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,

@@ -44,6 +44,14 @@ int32_t msbb_system_circuit_info(const msbb_system* sys, size_t circuit, uint64_
  * claim_data. */
 int32_t msbb_witness_create(msbb_system* sys, const uint32_t* const* traces, const uint64_t* heights, size_t n_claims,
                             const uint64_t* claim_offsets, const uint32_t* claim_data, msbb_witness** out);
+/* A SystemWitness that STAYS in host memory - what the reference's prove() is handed (src/prover.rs:290-295; the setup closure
+ * of a criterion bench builds it). Values are validated and the caller's trace buffers page-locked here (*pinned = 1 when
+ * every range could be); they must stay valid and unchanged until msbb_witness_destroy. Every msbb_prove on such a witness
+ * uploads traces and claims, runs from_stage_1 on the device and releases the device copies: its wall time is the reference's
+ * timed region (witness in host memory at the start, proof bytes in host memory at the end). */
+int32_t msbb_witness_create_host(msbb_system* sys, const uint32_t* const* traces, const uint64_t* heights, size_t n_claims,
+                                 const uint64_t* claim_offsets, const uint32_t* claim_data, int32_t* pinned /* nullable */,
+                                 msbb_witness** out);
 void msbb_witness_destroy(msbb_witness* w);
 
 /* Writes Proof::to_bytes (src/prover.rs:241-248). stage_ms (optional, 6 doubles) as for ms_prove. */

@@ -18,7 +18,7 @@ P = frontend.BABYBEAR["P"]
 def exported_symbols():
     """Every entry point include/mstark_bb.h declares (used by the CPU-side ABI test)."""
     return ["msbb_system_create", "msbb_system_destroy", "msbb_system_preprocessed_commit", "msbb_system_circuit_info",
-            "msbb_witness_create", "msbb_witness_destroy", "msbb_prove", "msbb_verify", "msbb_set_poseidon2", "msbb_poseidon2_permute",
+            "msbb_witness_create", "msbb_witness_create_host", "msbb_witness_destroy", "msbb_prove", "msbb_verify", "msbb_set_poseidon2", "msbb_poseidon2_permute",
             "msbb_dft_batch", "msbb_coset_lde_batch", "msbb_mmcs_commit", "msbb_mmcs_open", "msbb_mmcs_destroy", "msbb_field_op"]
 
 
@@ -60,7 +60,9 @@ class Proof:
 
 
 class Witness:
-    def __init__(self, system, traces, claims_packed):
+    def __init__(self, system, traces, claims_packed, host_resident=False):
+        """host_resident: the witness stays in host memory (msbb_witness_create_host) and every proof uploads it - the
+        reference's timed region; the arrays are kept alive (and page-locked) by this object"""
         self.system = system
         offs, data = claims_packed
         trs = [_u32(t) for t in traces]
@@ -70,8 +72,14 @@ class Witness:
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         data = _u32(data)
         self.h = C.c_void_p()
-        _check(_lib().msbb_witness_create(system.h, ptrs, hs.ctypes.data_as(u64p), C.c_size_t(len(offs) - 1), offs.ctypes.data_as(u64p),
-                                          _p32(data), C.byref(self.h)))
+        if host_resident:
+            pinned = C.c_int32(0)
+            _check(_lib().msbb_witness_create_host(system.h, ptrs, hs.ctypes.data_as(u64p), C.c_size_t(len(offs) - 1), offs.ctypes.data_as(u64p),
+                                                   _p32(data), C.byref(pinned), C.byref(self.h)))
+            self.keep, self.pinned = trs, bool(pinned.value)
+        else:
+            _check(_lib().msbb_witness_create(system.h, ptrs, hs.ctypes.data_as(u64p), C.c_size_t(len(offs) - 1), offs.ctypes.data_as(u64p),
+                                              _p32(data), C.byref(self.h)))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -116,6 +124,10 @@ class System:
     def witness(self, traces, claims_packed):
         return Witness(self, traces, claims_packed)
 
+    def host_witness(self, traces, claims_packed):
+        """a SystemWitness that stays in host memory: every prove_multiple_claims uploads it (msbb_witness_create_host)"""
+        return Witness(self, traces, claims_packed, host_resident=True)
+
     def verify_multiple_claims(self, claims_packed, proof: bytes):
         """0 = accepted, otherwise the reference's VerificationError variant (MS_VERDICT_*)"""
         offs, data = claims_packed
@@ -130,15 +142,18 @@ class System:
     verify = verify_multiple_claims
 
     def prove_multiple_claims(self, witness, want_times=False):
-        cap = 1 << 22
         times = np.zeros(6, dtype=np.float64)
         while True:
-            out = np.zeros(cap, dtype=np.uint8)
+            # one output buffer per system, reused: a fresh multi-megabyte array per proof costs an mmap and its page faults
+            cap = getattr(self, "_proof_cap", 1 << 22)
+            out = getattr(self, "_proof_buf", None)
+            if out is None or out.size != cap:
+                out = self._proof_buf = np.zeros(cap, dtype=np.uint8)
             n = C.c_size_t()
             rc = _lib().msbb_prove(self.h, witness.h, out.ctypes.data_as(u8p), C.c_size_t(cap), C.byref(n),
-                                   times.ctypes.data_as(C.POINTER(C.c_double)))
+                                   times.ctypes.data_as(C.POINTER(C.c_double)) if want_times else None)
             if rc == -3:
-                cap = n.value
+                self._proof_cap = n.value
                 continue
             _check(rc)
             keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]

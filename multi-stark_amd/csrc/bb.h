@@ -43,6 +43,7 @@ struct BPcsData {
 
 // ---- layout / conversion
 void bb_upload_rows(Ctx& ctx, const u32* host_rowmajor_canonical, size_t h, size_t w, BMat& out);
+void bb_upload_rows_async(Ctx& ctx, const u32* host_rowmajor_canonical, size_t h, size_t w, BMat& out);  // queued, no synchronisation
 void bb_download_rows(Ctx& ctx, const BMat& m, bool bitrev_rows, u32* host_rowmajor_canonical);
 // ---- transforms (forward DIF: natural in, bit-reversed out, in place on every column)
 void bb_dif(Ctx& ctx, u32* data, size_t ld, unsigned log_n, size_t ncols);

@@ -51,6 +51,16 @@ void bb_upload_rows(Ctx& ctx, const u32* host, size_t h, size_t w, BMat& out) {
   upload_rows_k<<<blocks_for(h * w, 256), 256, 0, ctx.stream>>>(tmp.p, h, w, out.buf.p, out.ld);
   ctx.sync();
 }
+// the same without the final synchronisation, from (page-locked) caller memory: the copy and the conversion are queued on the
+// context's stream; the staging block returns to the pool at once (the pool is stream-ordered)
+void bb_upload_rows_async(Ctx& ctx, const u32* host, size_t h, size_t w, BMat& out) {
+  out = bmat(ctx, h, w);
+  if (!h || !w) return;
+  DBuf<u32> tmp(ctx, h * w);
+  HIP_CHECK(hipMemcpyAsync(tmp.p, host, h * w * 4, hipMemcpyHostToDevice, ctx.stream));
+  upload_rows_k<<<blocks_for(h * w, 256), 256, 0, ctx.stream>>>(tmp.p, h, w, out.buf.p, out.ld);
+  HIP_CHECK(hipGetLastError());
+}
 static unsigned log2_host(size_t n) {
   unsigned l = 0;
   while ((size_t(1) << l) < n) l++;

@@ -121,6 +121,17 @@ struct BWitness {
   std::vector<std::vector<u32>> claims;  // canonical (the transcript absorbs them on the host)
   DBuf<u32> d_claim_data;                // Montgomery form, concatenated
   DBuf<u64> d_claim_offs;
+  // host-resident form (msbb_witness_create_host): nothing lives in HBM between proofs; every prove() uploads the caller's
+  // (page-locked) trace buffers and the claims, and gives the device copies back when it is done
+  bool host_resident = false;
+  std::vector<const u32*> h_traces;
+  std::vector<void*> registered;
+  std::vector<u32> h_claims_monty;
+  std::vector<u64> h_claim_offs;
+  ~BWitness() {
+    for (void* p : registered) (void)hipHostUnregister(p);
+    if (!registered.empty()) (void)hipGetLastError();
+  }
 };
 
 static std::vector<Digest8> tree_cap(Ctx& ctx, const BTree& t) {
@@ -350,6 +361,81 @@ std::unique_ptr<BWitness> witness_create(BSystem& sys, const u32* const* traces,
   }
   return w;
 }
+
+// A SystemWitness that stays in host memory, which is what the reference's prove() is handed (src/prover.rs:290-295): values
+// validated and buffers page-locked here (setup), uploaded by every prove().
+std::unique_ptr<BWitness> witness_create_host(BSystem& sys, const u32* const* traces, const u64* heights, size_t n_claims,
+                                              const u64* claim_offsets, const u32* claim_data, bool* pinned) {
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  std::unique_ptr<BWitness> w(new BWitness());
+  w->sys = &sys;
+  w->host_resident = true;
+  bool all_pinned = true;
+  const size_t C = sys.circuits.size();
+  for (size_t ci = 0; ci < C; ci++) {
+    const BCircuit& c = sys.circuits[ci];
+    const size_t h = (size_t)heights[ci];
+    w->heights.push_back(h);
+    w->traces.emplace_back();
+    w->h_traces.push_back(nullptr);
+    if (h == 0) continue;
+    if (h & (h - 1)) throw std::runtime_error("trace height must be a power of two");
+    if (log2_strict(h) + log2_strict(c.quotient_degree()) + sys.params.log_blowup > BB_TWO_ADICITY)
+      throw std::runtime_error("trace too tall for the two-adicity of BabyBear");
+    if (c.pre_width && h != c.pre_height) throw std::runtime_error("main trace height must equal preprocessed trace height");
+    if (!traces[ci]) throw std::runtime_error("missing trace");
+    for (size_t i = 0; i < h * c.main_width; i++)
+      if (traces[ci][i] >= BB_P) throw std::runtime_error("non-canonical trace value");
+    w->h_traces[ci] = traces[ci];
+    hipError_t e = hipHostRegister(const_cast<u32*>(traces[ci]), h * c.main_width * 4, hipHostRegisterDefault);
+    if (e == hipSuccess) {
+      w->registered.push_back(const_cast<u32*>(traces[ci]));
+    } else {
+      (void)hipGetLastError();
+      if (e != hipErrorHostMemoryAlreadyRegistered) all_pinned = false;
+    }
+  }
+  w->h_claim_offs.assign(1, 0);
+  for (size_t i = 0; i < n_claims; i++) {
+    if (claim_offsets[i + 1] < claim_offsets[i]) throw std::runtime_error("claim offsets must not decrease");
+    w->claims.emplace_back(claim_data + claim_offsets[i], claim_data + claim_offsets[i + 1]);
+    for (u32 x : w->claims.back()) {
+      if (x >= BB_P) throw std::runtime_error("non-canonical claim value");
+      w->h_claims_monty.push_back(bb_to_monty(x));
+    }
+    w->h_claim_offs.push_back(claim_offsets[i + 1] - claim_offsets[0]);
+  }
+  if (pinned) *pinned = all_pinned;
+  return w;
+}
+
+namespace {
+// the per-proof upload of a host-resident witness: traces (converted to Montgomery form behind their copies) and claims
+struct BHostUpload {
+  BWitness& w;
+  Ctx& ctx;
+  BHostUpload(BWitness& wit, Ctx& c) : w(wit), ctx(c) {
+    if (!w.host_resident) return;
+    for (size_t ci = 0; ci < w.h_traces.size(); ci++)
+      if (w.h_traces[ci]) bb_upload_rows_async(ctx, w.h_traces[ci], w.heights[ci], w.sys->circuits[ci].main_width, w.traces[ci]);
+    const size_t n_claims = w.claims.size();
+    if (n_claims) {
+      w.d_claim_offs = DBuf<u64>(ctx, n_claims + 1);
+      w.d_claim_data = DBuf<u32>(ctx, std::max<size_t>(w.h_claims_monty.size(), 1));
+      ctx.h2d(w.d_claim_offs.p, w.h_claim_offs.data(), (n_claims + 1) * 8);
+      if (!w.h_claims_monty.empty()) ctx.h2d(w.d_claim_data.p, w.h_claims_monty.data(), w.h_claims_monty.size() * 4);
+    }
+  }
+  ~BHostUpload() {
+    if (!w.host_resident) return;
+    (void)hipStreamSynchronize(ctx.stream);  // an abandoned proof may still be reading the blocks
+    for (auto& t : w.traces) t = BMat();
+    w.d_claim_offs.reset();
+    w.d_claim_data.reset();
+  }
+};
+}  // namespace
 
 // ------------------------------------------------------------------ proof bytes (Proof::to_bytes, src/prover.rs:241-248)
 namespace {
@@ -737,6 +823,7 @@ std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
   unsigned lb = (unsigned)prm.log_blowup;
   size_t C = sys.circuits.size();
   if (wit.traces.size() != C) throw std::runtime_error("witness/circuit count mismatch");
+  BHostUpload upload(wit, ctx);  // host-resident witness: the uploads are queued now, in front of the transforms that read them
   Challenger ch(&sys.perm);
   for (u32 v : sys.seed) ch.observe(v);
   // System::observe_shape, src/system.rs:211-222
@@ -1574,6 +1661,20 @@ int32_t msbb_witness_create(msbb_system* sys, const uint32_t* const* traces, con
   if (!sys || !traces || !heights || !out) throw std::runtime_error("null argument");
   std::unique_ptr<msbb_witness> w(new msbb_witness());
   w->w = witness_create(*sys->sys, traces, heights, n_claims, claim_offsets, claim_data);
+  w->owner = sys;
+  sys->refs++;
+  *out = w.release();
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_witness_create_host(msbb_system* sys, const uint32_t* const* traces, const uint64_t* heights, size_t n_claims,
+                                 const uint64_t* claim_offsets, const uint32_t* claim_data, int32_t* pinned, msbb_witness** out) {
+  BB_TRY
+  if (!sys || !traces || !heights || !out) throw std::runtime_error("null argument");
+  std::unique_ptr<msbb_witness> w(new msbb_witness());
+  bool all = false;
+  w->w = witness_create_host(*sys->sys, traces, heights, n_claims, claim_offsets, claim_data, &all);
+  if (pinned) *pinned = all ? 1 : 0;
   w->owner = sys;
   sys->refs++;
   *out = w.release();

@@ -33,13 +33,16 @@ void ctx_release(ms_ctx* c);
 using namespace msamd;
 
 namespace {
-enum OpKind : int { OP_NONE = 0, OP_A2A, OP_COLS, OP_GATHER };
-const char* op_name(int k) { return k == OP_A2A ? "all_to_all" : k == OP_COLS ? "all_to_all_cols" : k == OP_GATHER ? "all_gather" : "none"; }
+enum OpKind : int { OP_NONE = 0, OP_A2A, OP_COLS, OP_GATHER, OP_SCATTER };
+const char* op_name(int k) {
+  return k == OP_A2A ? "all_to_all" : k == OP_COLS ? "all_to_all_cols" : k == OP_GATHER ? "all_gather" : k == OP_SCATTER ? "scatter_cols" : "none";
+}
 struct Offer {
   int kind = OP_NONE;
   const uint8_t* send = nullptr;
   size_t send_peer_stride = 0, send_col_stride = 0;
   size_t ncols = 0, seg = 0;  // a2a: ncols = 1, seg = bytes per peer; gather: seg = bytes
+  int root = -1;              // scatter: the rank that hands its matrix out
 };
 }  // namespace
 
@@ -54,8 +57,18 @@ struct ms_comm_local_group {
   double timeout_s = 120;
   int members = 0, refs = 1;  // handles created on this group; the group object lives until the last of them is gone
   std::vector<Offer> offers;
+  // One pair of events per rank, owned by the GROUP and destroyed with it: a rank that has returned from the last collective
+  // may destroy its handle while a slower peer is still ordering its stream behind that rank's `done` event.
   std::vector<hipEvent_t> ready, done;
   std::vector<int> devices;
+  std::vector<char> taken;
+  ~ms_comm_local_group() {
+    for (size_t k = 0; k < ready.size(); k++) {
+      if (devices[k] >= 0) (void)hipSetDevice(devices[k]);
+      if (ready[k]) (void)hipEventDestroy(ready[k]);
+      if (done[k]) (void)hipEventDestroy(done[k]);
+    }
+  }
 
   void abort(const std::string& why) {
     std::lock_guard<std::mutex> lk(mu);
@@ -123,12 +136,20 @@ struct ms_comm_local {
       g->barrier(rank, what);
       for (int k = 0; k < N; k++) {
         const Offer& o = g->offers[k];
-        if (o.kind != mine.kind || o.seg != mine.seg || o.ncols != mine.ncols)
+        if (o.kind != mine.kind || o.seg != mine.seg || o.ncols != mine.ncols || o.root != mine.root)
           throw std::runtime_error(std::string("local transport: rank ") + std::to_string(rank) + " entered " + op_name(mine.kind) + "(" +
                                    std::to_string(mine.ncols) + " x " + std::to_string(mine.seg) + " B) while rank " + std::to_string(k) +
                                    " entered " + op_name(o.kind) + "(" + std::to_string(o.ncols) + " x " + std::to_string(o.seg) + " B)");
       }
-      if (mine.seg && mine.ncols) {
+      if (mine.kind == OP_SCATTER) {
+        // only the root's offer carries data: every other rank pulls its row range out of the root's matrix
+        if (rank != mine.root && mine.seg && mine.ncols) {
+          const Offer& o = g->offers[mine.root];
+          HIP_CHECK(hipStreamWaitEvent(stream, g->ready[mine.root], 0));
+          HIP_CHECK(hipMemcpy2DAsync(recv, recv_col_stride, o.send + (size_t)rank * o.send_peer_stride, o.send_col_stride, mine.seg, mine.ncols,
+                                     hipMemcpyDeviceToDevice, stream));
+        }
+      } else if (mine.seg && mine.ncols) {
         for (int k = 0; k < N; k++) {
           const Offer& o = g->offers[k];
           if (k == rank && skip_self) continue;
@@ -230,6 +251,22 @@ int32_t cb_cols_start2(void* user, const void* send, size_t sps, size_t scs, voi
     c->collective(o, (uint8_t*)recv, rps, rcs, "all_to_all_cols_start", (flags & MS_COMM_SKIP_SELF) != 0);
   });
 }
+int32_t cb_scatter(void* user, int32_t root, const void* send, size_t sps, size_t scs, void* recv, size_t rcs, size_t ncols, size_t seg) {
+  ms_comm_local* c = (ms_comm_local*)user;
+  return guarded(c, [&] {
+    if (root < 0 || root >= c->g->world) throw std::runtime_error("scatter_cols_start: root out of range");
+    Offer o;
+    o.kind = OP_SCATTER;
+    o.root = root;
+    o.send = (const uint8_t*)send;
+    o.send_peer_stride = sps;
+    o.send_col_stride = scs;
+    o.ncols = ncols;
+    o.seg = seg;
+    c->begin();
+    c->collective(o, (uint8_t*)recv, 0, rcs, "scatter_cols_start", true);
+  });
+}
 int32_t cb_wait(void* user) {
   ms_comm_local* c = (ms_comm_local*)user;
   return guarded(c, [&] { c->complete(); });
@@ -267,6 +304,7 @@ int32_t ms_comm_local_group_create(int32_t world, ms_comm_local_group** out) {
     g->ready.assign(world, nullptr);
     g->done.assign(world, nullptr);
     g->devices.assign(world, -1);
+    g->taken.assign(world, 0);
     if (const char* e = getenv("MSAMD_LOCAL_TIMEOUT_S")) g->timeout_s = std::max(1.0, atof(e));
     *out = g;
     return MS_OK;
@@ -296,18 +334,21 @@ int32_t ms_comm_local_create(ms_comm_local_group* g, ms_ctx* ctx, int32_t rank, 
     c->rank = rank;
     HIP_CHECK(hipSetDevice(c->ctx->device));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    hipEvent_t ready = nullptr, done = nullptr;
-    HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
     {
       std::lock_guard<std::mutex> lk(g->mu);
-      if (g->ready[rank]) {
-        (void)hipEventDestroy(ready);
-        (void)hipEventDestroy(done);
-        throw std::runtime_error("ms_comm_local_create: this rank of the group is taken");
+      if (g->taken[rank]) throw std::runtime_error("ms_comm_local_create: this rank of the group is taken");
+      if (g->ready[rank] && g->devices[rank] != c->ctx->device) {  // the rank moves to another device: fresh events
+        (void)hipSetDevice(g->devices[rank]);
+        (void)hipEventDestroy(g->ready[rank]);
+        (void)hipEventDestroy(g->done[rank]);
+        g->ready[rank] = g->done[rank] = nullptr;
+        (void)hipSetDevice(c->ctx->device);
       }
-      g->ready[rank] = ready;
-      g->done[rank] = done;
+      if (!g->ready[rank]) {
+        HIP_CHECK(hipEventCreateWithFlags(&g->ready[rank], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming));
+      }
+      g->taken[rank] = 1;
       g->devices[rank] = c->ctx->device;
       g->members++;
       g->refs++;
@@ -332,6 +373,7 @@ int32_t ms_comm_local_create(ms_comm_local_group* g, ms_ctx* ctx, int32_t rank, 
     c->table.all_to_all_cols_start = cb_cols_start;
     c->table.set_stream_ordered = cb_set_stream_ordered;
     c->table.all_to_all_cols_start2 = cb_cols_start2;
+    c->table.scatter_cols_start = cb_scatter;
     c->owner = ctx;
     ctx_retain(ctx);
     *out = c;
@@ -356,10 +398,7 @@ void ms_comm_local_destroy(ms_comm_local* c) {
   ms_comm_local_group* g = c->g;
   {
     std::lock_guard<std::mutex> lk(g->mu);
-    if (g->ready[c->rank]) (void)hipEventDestroy(g->ready[c->rank]);
-    if (g->done[c->rank]) (void)hipEventDestroy(g->done[c->rank]);
-    g->ready[c->rank] = g->done[c->rank] = nullptr;
-    g->devices[c->rank] = -1;
+    g->taken[c->rank] = 0;  // (the rank's events stay with the group: a peer may still be waiting on them)
     g->members--;
   }
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);

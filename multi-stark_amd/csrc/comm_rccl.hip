@@ -207,6 +207,35 @@ struct ms_comm_rccl {
     if (!skip_self)
       HIP_CHECK(hipMemcpy2DAsync(recv + (size_t)rank * rps, rcs, send + (size_t)rank * sps, scs, seg, ncols, hipMemcpyDeviceToDevice, stream));
   }
+  // one rank's matrix handed out by row ranges (ms_comm.scatter_cols_start): the root sends ncols segments to every other
+  // rank, every other rank receives its ncols segments; groups bounded like the column exchange's
+  void scatter_cols(int root, const uint8_t* send, size_t sps, size_t scs, uint8_t* recv, size_t rcs, size_t ncols, size_t seg) {
+    if (root < 0 || root >= world) throw std::runtime_error("scatter_cols_start: root out of range");
+    bytes_moved += rank == root ? seg * ncols * (size_t)(world - 1) : seg * ncols;
+    if (seg == 0 || ncols == 0 || world == 1) return;
+    const size_t per_col = rank == root ? (size_t)(world - 1) : 1;
+    const size_t cols_per_group = std::max<size_t>(1, max_group_ops() / (size_t)(world - 1));  // the same cut on every rank
+    (void)per_col;
+    try {
+      for (size_t c0 = 0; c0 < ncols; c0 += cols_per_group) {
+        const size_t c1 = std::min(ncols, c0 + cols_per_group);
+        GroupGuard grp;
+        if (rank == root) {
+          for (int k = 0; k < world; k++) {
+            if (k == rank) continue;
+            for (size_t c = c0; c < c1; c++) nccl_check(rccl().Send(send + (size_t)k * sps + c * scs, seg, ncclUint8, k, comm, stream), "ncclSend");
+          }
+        } else {
+          for (size_t c = c0; c < c1; c++) nccl_check(rccl().Recv(recv + c * rcs, seg, ncclUint8, root, comm, stream), "ncclRecv");
+        }
+        grp.end();
+        groups_issued++;
+      }
+    } catch (...) {
+      fail();
+      throw;
+    }
+  }
   void gather(const void* send, void* recv, size_t n) {
     bytes_moved += n * (size_t)world;
     if (n == 0) return;
@@ -272,6 +301,13 @@ int32_t cb_cols_start2(void* user, const void* send, size_t sps, size_t scs, voi
     c->exchange_cols((const uint8_t*)send, sps, scs, (uint8_t*)recv, rps, rcs, ncols, seg, (flags & MS_COMM_SKIP_SELF) != 0);
   });
 }
+int32_t cb_scatter(void* user, int32_t root, const void* send, size_t sps, size_t scs, void* recv, size_t rcs, size_t ncols, size_t seg) {
+  ms_comm_rccl* c = (ms_comm_rccl*)user;
+  return guarded(c, [&] {
+    c->begin();
+    c->scatter_cols(root, (const uint8_t*)send, sps, scs, (uint8_t*)recv, rcs, ncols, seg);
+  });
+}
 int32_t cb_wait(void* user) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
   return guarded(c, [&] { c->complete(); });
@@ -332,6 +368,7 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
     c->table.all_to_all_cols_start = cb_cols_start;
     c->table.set_stream_ordered = cb_set_stream_ordered;
     c->table.all_to_all_cols_start2 = cb_cols_start2;
+    c->table.scatter_cols_start = cb_scatter;
     c->owner = ctx;
     ctx_retain(ctx);
     *out = c;

@@ -34,8 +34,12 @@ static constexpr u64 GL_EXT_W = 7;                        // X^2 = 7
 
 // On the device the modular add/sub/reduce are written as VCC carry chains in inline assembly: the compiler's own
 // lowering of the same C (64-bit compares into SGPR pairs + v_cndmask, register-pair shuffles for v_lshl_add_u64 and
-// the hazard s_nops between them) costs about twice the instructions. All sequences are pure VALU, keep every
-// intermediate in VGPRs and only clobber VCC; VALU->VALU carry-in needs no wait states on gfx950.
+// the hazard s_nops between them) costs about twice the instructions. Every intermediate stays in VGPRs. A carry or borrow
+// out of a 64-bit add / sub is folded back as +- (2^32 - 1) = "low limb -+ c, high limb +- (c xor the low limb's own
+// carry-out)": the two masks live in VCC and one SGPR pair, and their xor is ONE s_xor_b64 on the SCALAR unit instead of a
+// v_cndmask + a third vector add - these kernels are bound by vector-ALU issue, the scalar unit is idle (measured,
+// tools/micro/gl_sgpr.hip: mul 1.38 -> 1.53 T/s, add 4.74 -> 5.80, sub 6.46 -> 7.27, bit-identical on 4.2 M operand pairs).
+// The blocks clobber VCC and SCC (scalar logic writes SCC: the compiler keeps its loop conditions out of the way).
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ u64 gl_pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 #endif
@@ -43,15 +47,16 @@ __device__ __forceinline__ u64 gl_pack(u32 lo, u32 hi) { return ((u64)hi << 32) 
 GL_HD u64 gl_sub(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // d = a - b; on borrow add p, i.e. subtract 2^32 - 1 (mod 2^64)
-  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32), d0, d1, m;
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32), d0, d1;
+  u64 sm;
   asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
-      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(d0), "=&v"(d1), "=&v"(m)
+      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"   // borrow B
+      "v_addc_co_u32 %0, %2, 0, %0, vcc\n\t"     // + p = + 1 - 2^32: low += B (carry C2) ...
+      "s_xor_b64 %2, %2, vcc\n\t"                // ... high -= B and not C2
+      "v_subbrev_co_u32 %1, vcc, 0, %1, %2"
+      : "=&v"(d0), "=&v"(d1), "=&s"(sm)
       : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
-      : "vcc");
+      : "vcc", "scc");
   return gl_pack(d0, d1);
 #else
   u64 d = a - b;
@@ -61,18 +66,19 @@ GL_HD u64 gl_sub(u64 a, u64 b) {
 }
 GL_HD u64 gl_add(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  // a + b = a - (p - b); p - b = (1 - b0, 0xFFFFFFFF - b1 - borrow) needs no reduction (b = 0 gives p, still correct)
-  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32), d0, d1, m;
-  asm("v_sub_co_u32 %0, vcc, 1, %5\n\t"
-      "v_subb_co_u32 %1, vcc, -1, %6, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %3, %0\n\t"
-      "v_subb_co_u32 %1, vcc, %4, %1, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
-      : "=&v"(d0), "=&v"(d1), "=&v"(m)
+  // s = a + b (65 bits with the carry); s >= p <=> the carry, or s + (2^32 - 1) carries out; then the result is s - p
+  u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32), s0, s1, d0, d1;
+  u64 sc;
+  asm("v_add_co_u32 %0, vcc, %5, %7\n\t"
+      "v_addc_co_u32 %1, %4, %6, %8, vcc\n\t"    // carry C of a + b
+      "v_add_co_u32 %2, vcc, -1, %0\n\t"         // t = s + (2^32 - 1) = s - p (mod 2^64): carries out iff s >= p
+      "v_addc_co_u32 %3, vcc, 0, %1, vcc\n\t"
+      "s_or_b64 vcc, vcc, %4\n\t"                // a + b >= p: take t
+      "v_cndmask_b32 %2, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %1, %3, vcc"
+      : "=&v"(s0), "=&v"(s1), "=&v"(d0), "=&v"(d1), "=&s"(sc)
       : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
-      : "vcc");
+      : "vcc", "scc");
   return gl_pack(d0, d1);
 #else
   u64 s = a + b;
@@ -99,26 +105,27 @@ GL_HD u64 gl_reduce128(u64 lo, u64 hi) {
 // conditional subtraction of p.
 GL_HD u64 gl_reduce_limbs(u64 lo, u32 h0, u32 h1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, m, t0, t1;
+  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, t0, t1;
+  u64 sm;
   asm("v_sub_co_u32 %0, vcc, 0, %7\n\t"            // u = (h0 << 32) - h0
       "v_subbrev_co_u32 %1, vcc, 0, %7, vcc\n\t"
-      "v_add_co_u32 %0, vcc, %5, %0\n\t"            // A = lo + u
+      "v_add_co_u32 %0, vcc, %5, %0\n\t"            // A = lo + u, carry Cy
       "v_addc_co_u32 %1, vcc, %6, %1, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_add_co_u32 %0, vcc, %0, %2\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %8\n\t"            // C = A - h1
+      "v_subbrev_co_u32 %0, %4, 0, %0, vcc\n\t"     // + (2^32 - 1): low -= Cy (borrow b2), high += Cy and not b2
+      "s_xor_b64 %4, %4, vcc\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %8\n\t"            // C = A - h1, borrow Bw
       "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_add_co_u32 %3, vcc, -1, %0\n\t"            // C >= p  <=>  C + (2^32 - 1) carries out
-      "v_addc_co_u32 %4, vcc, 0, %1, vcc\n\t"
-      "v_cndmask_b32 %3, %0, %3, vcc\n\t"
-      "v_cndmask_b32 %4, %1, %4, vcc"
-      : "=&v"(r0), "=&v"(r1), "=&v"(m), "=&v"(t0), "=&v"(t1)
+      "v_addc_co_u32 %0, %4, 0, %0, vcc\n\t"        // - (2^32 - 1): low += Bw (carry c3), high -= Bw and not c3
+      "s_xor_b64 %4, %4, vcc\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_add_co_u32 %2, vcc, -1, %0\n\t"            // C >= p  <=>  C + (2^32 - 1) carries out
+      "v_addc_co_u32 %3, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %1, %3, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&s"(sm)
       : "v"(l0), "v"(l1), "v"(h0), "v"(h1)
-      : "vcc");
+      : "vcc", "scc");
   return gl_pack(t0, t1);
 #else
   return gl_reduce128(lo, ((u64)h1 << 32) | h0);
@@ -127,21 +134,22 @@ GL_HD u64 gl_reduce_limbs(u64 lo, u32 h0, u32 h1) {
 // the same with h1 = 0 (a 96-bit value), as produced by shifts of less than 32 bits
 GL_HD u64 gl_reduce_limbs96(u64 lo, u32 h0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, m, t0, t1;
+  u32 l0 = (u32)lo, l1 = (u32)(lo >> 32), r0, r1, t0, t1;
+  u64 sm;
   asm("v_sub_co_u32 %0, vcc, 0, %7\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %7, vcc\n\t"
       "v_add_co_u32 %0, vcc, %5, %0\n\t"
       "v_addc_co_u32 %1, vcc, %6, %1, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_add_co_u32 %0, vcc, %0, %2\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_add_co_u32 %3, vcc, -1, %0\n\t"
-      "v_addc_co_u32 %4, vcc, 0, %1, vcc\n\t"
-      "v_cndmask_b32 %3, %0, %3, vcc\n\t"
-      "v_cndmask_b32 %4, %1, %4, vcc"
-      : "=&v"(r0), "=&v"(r1), "=&v"(m), "=&v"(t0), "=&v"(t1)
+      "v_subbrev_co_u32 %0, %4, 0, %0, vcc\n\t"
+      "s_xor_b64 %4, %4, vcc\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_add_co_u32 %2, vcc, -1, %0\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %1, %3, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&s"(sm)
       : "v"(l0), "v"(l1), "v"(h0)
-      : "vcc");
+      : "vcc", "scc");
   return gl_pack(t0, t1);
 #else
   return gl_reduce128(lo, (u64)h0);
@@ -190,38 +198,85 @@ GL_HD u64 gl_mul(u64 a, u64 b) {
       : "vcc");
   u32 p00l = (u32)p00, p00h = (u32)(p00 >> 32), p01l = (u32)p01, p01h = (u32)(p01 >> 32);
   u32 p10l = (u32)p10, p10h = (u32)(p10 >> 32), p11l = (u32)p11, p11h = (u32)(p11 >> 32);
-  u32 r0, r1, m, t0, t1, h0, h1;
-  asm("v_add_co_u32 %3, vcc, %8, %9\n\t"          // l1 = p00h + p01l
-      "v_addc_co_u32 %5, vcc, %10, %12, vcc\n\t"  // h0 = p01h + p10h + c
-      "v_addc_co_u32 %6, vcc, 0, %14, vcc\n\t"    // h1 = p11h + c
-      "v_add_co_u32 %3, vcc, %3, %11\n\t"         // l1 += p10l
-      "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"   // h0 += p11l + c
-      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"     // h1 += c
-      "v_sub_co_u32 %0, vcc, 0, %5\n\t"           // u = (h0 << 32) - h0
+  u32 r0, r1, t0, t1, l1, h0, h1;
+  u64 sm;
+  asm("v_add_co_u32 %4, vcc, %9, %10\n\t"          // l1 = p00h + p01l
+      "v_addc_co_u32 %5, vcc, %11, %13, vcc\n\t"   // h0 = p01h + p10h + c
+      "v_addc_co_u32 %6, vcc, 0, %15, vcc\n\t"     // h1 = p11h + c
+      "v_add_co_u32 %4, vcc, %4, %12\n\t"          // l1 += p10l
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t"    // h0 += p11l + c
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"      // h1 += c
+      "v_sub_co_u32 %0, vcc, 0, %5\n\t"            // u = (h0 << 32) - h0
       "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
-      "v_add_co_u32 %0, vcc, %7, %0\n\t"          // A = (l1:l0) + u
-      "v_addc_co_u32 %1, vcc, %3, %1, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_add_co_u32 %0, vcc, %0, %2\n\t"
-      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %6\n\t"          // C = A - h1
+      "v_add_co_u32 %0, vcc, %8, %0\n\t"           // A = (l1:l0) + u, carry Cy
+      "v_addc_co_u32 %1, vcc, %4, %1, vcc\n\t"
+      "v_subbrev_co_u32 %0, %7, 0, %0, vcc\n\t"    // + (2^32 - 1): low -= Cy (borrow b2), high += Cy and not b2
+      "s_xor_b64 %7, %7, vcc\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %7\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %6\n\t"           // C = A - h1, borrow Bw
       "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
-      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
-      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
-      "v_add_co_u32 %3, vcc, -1, %0\n\t"          // C >= p  <=>  C + (2^32 - 1) carries out
-      "v_addc_co_u32 %4, vcc, 0, %1, vcc\n\t"
-      "v_cndmask_b32 %3, %0, %3, vcc\n\t"
-      "v_cndmask_b32 %4, %1, %4, vcc"
-      : "=&v"(r0), "=&v"(r1), "=&v"(m), "=&v"(t0), "=&v"(t1), "=&v"(h0), "=&v"(h1)
+      "v_addc_co_u32 %0, %7, 0, %0, vcc\n\t"       // - (2^32 - 1): low += Bw (carry c3), high -= Bw and not c3
+      "s_xor_b64 %7, %7, vcc\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, %7\n\t"
+      "v_add_co_u32 %2, vcc, -1, %0\n\t"           // C >= p  <=>  C + (2^32 - 1) carries out
+      "v_addc_co_u32 %3, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %1, %3, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1), "=&v"(l1), "=&v"(h0), "=&v"(h1), "=&s"(sm)
       : "v"(p00l), "v"(p00h), "v"(p01l), "v"(p01h), "v"(p10l), "v"(p10h), "v"(p11l), "v"(p11h)
-      : "vcc");
+      : "vcc", "scc");
   return gl_pack(t0, t1);
 #else
   unsigned __int128 x = (unsigned __int128)a * b;
   return gl_reduce128((u64)x, (u64)(x >> 64));
 #endif
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// x * 2^(64 + r), 0 <= r < 32, from the limbs (y2 : y1 : y0) of x << r:  y0 2^64 + y1 2^96 + y2 2^128 =
+// ((y0 << 32) - y0) - (y2 : y1). Both operands are canonical ((2^32 - 1)^2 < p; y2 < 2^31), so ONE modular
+// subtraction finishes it: 7 vector instructions where three chained subtractions took 17.
+__device__ __forceinline__ u64 gl_shift_hi(u32 y0, u32 y1, u32 y2) {
+  u32 t0, t1;
+  u64 sm;
+  asm("v_sub_co_u32 %0, vcc, 0, %3\n\t"             // T = (y0 << 32) - y0
+      "v_subbrev_co_u32 %1, vcc, 0, %3, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %4\n\t"            // T - (y2 : y1), borrow B
+      "v_subb_co_u32 %1, vcc, %1, %5, vcc\n\t"
+      "v_addc_co_u32 %0, %2, 0, %0, vcc\n\t"        // + p
+      "s_xor_b64 %2, %2, vcc\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, %2"
+      : "=&v"(t0), "=&v"(t1), "=&s"(sm)
+      : "v"(y0), "v"(y1), "v"(y2)
+      : "vcc", "scc");
+  return gl_pack(t0, t1);
+}
+// x * 2^(32 + r), 0 <= r < 32:  y0 2^32 + y1 2^64 + y2 2^96 = (y0 : 0) + ((y1 << 32) - y1) - y2. The sum of the first
+// two is below 2 p (one carry fold), y2 < 2^31 (one borrow fold), then the conditional subtraction of p.
+__device__ __forceinline__ u64 gl_shift_mid(u32 y0, u32 y1, u32 y2) {
+  u32 t0, t1, r0, r1;
+  u64 sm;
+  asm("v_sub_co_u32 %0, vcc, 0, %6\n\t"             // T = (y1 << 32) - y1
+      "v_subbrev_co_u32 %1, vcc, 0, %6, vcc\n\t"
+      "v_add_co_u32 %1, vcc, %1, %5\n\t"            // + (y0 : 0): the low limb is untouched; carry Cy
+      "v_subbrev_co_u32 %0, %4, 0, %0, vcc\n\t"     // + (2^32 - 1)
+      "s_xor_b64 %4, %4, vcc\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %7\n\t"            // - y2, borrow Bw
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_addc_co_u32 %0, %4, 0, %0, vcc\n\t"        // - (2^32 - 1)
+      "s_xor_b64 %4, %4, vcc\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_add_co_u32 %2, vcc, -1, %0\n\t"            // >= p ?
+      "v_addc_co_u32 %3, vcc, 0, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %0, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %1, %3, vcc"
+      : "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1), "=&s"(sm)
+      : "v"(y0), "v"(y1), "v"(y2)
+      : "vcc", "scc");
+  return gl_pack(r0, r1);
+}
+#endif
 
 // x * 2^k mod p for 0 <= k < 96 by shifts (2 has order 192 and 2^96 = -1: every root of unity of order <= 64 is a
 // signed power of two, so the innermost NTT stages need no multiplier). Meant for k known at compile time.
@@ -231,6 +286,15 @@ GL_HD u64 gl_mul_2exp(u64 x, unsigned k) {
     u64 lo = x << k, hi = x >> (64 - k);
     return gl_reduce_limbs96(lo, (u32)hi);
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    // x << r as three limbs (r = k mod 32, k > 32), then the limb arithmetic of the exponent's 32-bit block
+    const unsigned r = k & 31;
+    const u64 lo = x << r;
+    const u32 y2 = r ? ((u32)(x >> 32) >> (32 - r)) : 0u;
+    return k < 64 ? gl_shift_mid((u32)lo, (u32)(lo >> 32), y2) : gl_shift_hi((u32)lo, (u32)(lo >> 32), y2);
+  }
+#else
   if (k < 64) {
     u64 lo = x << k, hi = x >> (64 - k);
     return gl_reduce_limbs(lo, (u32)hi, (u32)(hi >> 32));
@@ -244,6 +308,7 @@ GL_HD u64 gl_mul_2exp(u64 x, unsigned k) {
   u64 t = gl_sub(((u64)l0 << 32), (u64)l0);   // (l0 << 32) - l0, both canonical
   t = gl_sub(t, (u64)l1);
   return gl_sub(t, hi << 32);
+#endif
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 

@@ -14,6 +14,7 @@ _START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, 
 _WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 _ORDERED = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
 _COLS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t)
+_SCATTER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t)
 _COLS2 = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32)
 
 
@@ -21,7 +22,8 @@ class MsComm(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB),
                 ("all_to_all_start", _START), ("all_to_all_wait", _WAIT), ("all_to_all_cols_start", _COLS),
                 ("set_stream_ordered", _ORDERED),  # (TorchComm leaves it NULL: its callbacks synchronise with the host)
-                ("all_to_all_cols_start2", _COLS2)]  # (NULL in TorchComm: the library then calls all_to_all_cols_start)
+                ("all_to_all_cols_start2", _COLS2),  # (NULL in TorchComm: the library then calls all_to_all_cols_start)
+                ("scatter_cols_start", _SCATTER)]
 
 
 class _DevBytes:
@@ -50,7 +52,9 @@ class TorchComm:
         self._wait = _WAIT(self._all_to_all_wait)
         self._cols = _COLS(self._all_to_all_cols_start)
         self._pending = []
+        self._scatter = _SCATTER(self._scatter_cols_start)
         self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag, self._start, self._wait, self._cols)
+        self.struct.scatter_cols_start = self._scatter
 
     def _view(self, ptr, nbytes):
         return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
@@ -137,6 +141,38 @@ class TorchComm:
                     for c in range(ncols):
                         outs[k][c].copy_(blk[c * seg:(c + 1) * seg])
                 torch.cuda.synchronize(self.device)
+
+        return self._guard(run)
+
+    def _scatter_cols_start(self, _user, root, send, sps, scs, recv, rcs, ncols, seg):
+        """one rank's matrix handed out by row ranges: root sends ncols segments to every other rank (general ownership)"""
+
+        def run():
+            if self.rank == root:
+                self.bytes_moved += seg * ncols * (self.world - 1)
+                ins = [[self._view(send + k * sps + c * scs, seg) for c in range(ncols)] for k in range(self.world)]
+            else:
+                self.bytes_moved += seg * ncols
+                outs = [self._view(recv + c * rcs, seg) for c in range(ncols)]
+            if self.direct:
+                ops = []
+                if self.rank == root:
+                    for k in range(self.world):
+                        if k != root:
+                            ops += [dist.P2POp(dist.isend, ins[k][c], k, self.group) for c in range(ncols)]
+                else:
+                    ops = [dist.P2POp(dist.irecv, outs[c], root, self.group) for c in range(ncols)]
+                if ops:
+                    self._pending.extend(dist.batch_isend_irecv(ops))
+            else:  # staged: the root's whole matrix is broadcast through the host, every rank takes its range
+                per = seg * ncols
+                buf = torch.cat([t.cpu() for k in range(self.world) for t in ins[k]]) if self.rank == root else torch.empty(per * self.world, dtype=torch.uint8)
+                dist.broadcast(buf, src=root, group=self.group)
+                if self.rank != root:
+                    blk = buf[self.rank * per:(self.rank + 1) * per]
+                    for c in range(ncols):
+                        outs[c].copy_(blk[c * seg:(c + 1) * seg])
+                    torch.cuda.synchronize(self.device)
 
         return self._guard(run)
 

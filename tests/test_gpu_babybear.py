@@ -114,6 +114,9 @@ def _prove_both(ctx, params, inputs, traces, claims):
     want = o.prove(traces, packed)
     assert len(got) == len(want)
     assert got == want, "proof bytes differ at byte %d" % next(i for i in range(len(got)) if got[i] != want[i])
+    # the same from a witness that stays in host memory (msbb_witness_create_host: upload inside every proof), twice
+    hw = g.host_witness(traces, packed)
+    assert g.prove_multiple_claims(hw).to_bytes() == want and g.prove_multiple_claims(hw).to_bytes() == want, "host-resident witness: proof differs"
     verdict = o.verify(packed, got)
     assert g.verify(packed, got) == verdict, "product verifier (msbb_verify) disagrees with the oracle's"
     return verdict, g, o, packed, got
@@ -269,3 +272,7 @@ def test_config4_full_size(ctx):
     print("config 4 (2^20 rows) stage ms:", {k: round(v, 1) for k, v in proof.stage_ms.items()})
     assert o.verify(packed, proof.to_bytes()) == 0
     assert o.prove([trace], packed) == proof.to_bytes()
+    hw = g.host_witness([trace], packed)
+    for _ in range(3):
+        assert g.prove_multiple_claims(hw).to_bytes() == proof.to_bytes()
+    assert g.prove_multiple_claims(w).to_bytes() == proof.to_bytes()  # and the device-resident one again on the same context

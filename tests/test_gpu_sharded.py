@@ -203,12 +203,16 @@ def test_sharded_proof_equals_single_gpu_proof(world, log_adds, variant):
 # Variants: the transport ordered with the prover's stream by events (the default: no host waits around the exchanges), by
 # the host (MSAMD_SHARDED_HOST_SYNC), and the exchange through a packed send buffer (MSAMD_SHARDED_PACK); at 2^12 and at 2^16
 # rows (column groups overlapping the transforms), from a device- and from a host-resident witness, several proofs in a row.
-@pytest.mark.parametrize("var", ["", "MSAMD_SHARDED_HOST_SYNC", "MSAMD_SHARDED_PACK"])
+@pytest.mark.parametrize("var", ["", "MSAMD_SHARDED_HOST_SYNC", "MSAMD_SHARDED_PACK", "bypass"])
 @pytest.mark.parametrize("log_adds", [12, 16])
 def test_native_rccl_transport_world_1(pkg, ctx, oracle, fe, var, log_adds, monkeypatch):
     import importlib
 
-    if var:
+    # a single rank normally never enters the transport (a gather from oneself is a copy on the prover's stream);
+    # MSAMD_SHARDED_WORLD1_TRANSPORT=1 sends every exchange through it, which is what this test is about
+    if var != "bypass":
+        monkeypatch.setenv("MSAMD_SHARDED_WORLD1_TRANSPORT", "1")
+    if var and var != "bypass":
         monkeypatch.setenv(var, "1")
     sharded = importlib.import_module("multi_stark_amd.sharded")
     system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(1))
@@ -224,7 +228,7 @@ def test_native_rccl_transport_world_1(pkg, ctx, oracle, fe, var, log_adds, monk
         assert system.prove_sharded(hw, comm, sharded.u32_add_owners(1)).to_bytes() == want
         assert system.prove_sharded(w, comm, sharded.u32_add_owners(1)).to_bytes() == want
     assert system.prove_multiple_claims(w).to_bytes() == want   # the plain prover on the same context afterwards
-    assert comm.bytes_moved > 0
+    assert (comm.bytes_moved > 0) == (var != "bypass")
     assert oracle.System(system.blob).verify(packed, got) == 0
     comm.close()
     with pytest.raises(pkg.MstarkError):
@@ -428,3 +432,245 @@ def test_thread_ranks_random_systems(pkg, fe, world, seed, monkeypatch):
         group.close()
     assert len(set(res)) == 1 and res[0] >= 10, res
     print("thread ranks, random systems:", res[0], "cases, world", world)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# General ownership (ms_comm.scatter_cols_start): any number of circuits per rank, any shapes, replicated tables.
+def _wide_and_tables(fe, np, W=96, H=64):
+    """the structure of the reference's largest scenario (src/test_circuits/blake3.rs:2215-2613: one wide circuit beside tables
+    of other widths and heights, linked by lookups), scaled down: a W-column product chain pushes two pairs that two tables of
+    other heights pull, next to a byte-range table and a second chain of another height"""
+    P = fe.P
+    rng = np.random.default_rng(177)
+
+    def chain(w, h, seed):
+        r = np.random.default_rng(seed)
+        m = np.zeros((h, w), dtype=object)
+        base = int(r.integers(1, 1 << 20))
+        m[:, 0] = [base + i for i in range(h)]
+        m[:, 1] = [int(x) for x in r.integers(1, 1 << 20, h)]
+        for i in range(2, w):
+            m[:, i] = (m[:, i - 2] * m[:, i - 1]) % P
+        return m.astype(np.uint64)
+
+    def chain_air(w, pushes):
+        def ev(b):
+            local, nxt = b.main()
+            for i in range(2, w):
+                b.assert_eq(local[i - 2] * local[i - 1], local[i])
+            b.when_transition().assert_eq(nxt[0], local[0] + fe.Expr.const(1))
+
+        return fe.lookup_air(w, ev, pushes)
+
+    var, one = fe.Expr.main, fe.Expr.const(1)
+    wide = chain(W, H, 1)
+    other = chain(12, 4 * H, 2)
+    wide_air = chain_air(W, [fe.Lookup.push(one, [var(0), var(1)]), fe.Lookup.push(one, [var(W - 2), var(W - 1)])])
+    other_air = chain_air(12, [fe.Lookup.push(one, [var(3), var(4)])])
+    t1 = np.stack([wide[:, 0], wide[:, 1]], axis=1)
+    t2 = np.zeros((2 * H, 3), dtype=np.uint64)
+    t2[:H, 0] = 1
+    t2[:H, 1] = wide[:, W - 2]
+    t2[:H, 2] = wide[:, W - 1]
+    t3 = np.stack([other[:, 3], other[:, 4]], axis=1)
+    a1 = fe.lookup_air(2, None, [fe.Lookup.pull(one, [var(0), var(1)])])
+    a2 = fe.lookup_air(3, lambda b: b.assert_bool(b.main()[0][0]), [fe.Lookup.pull(var(0), [var(1), var(2)])])
+    a3 = fe.lookup_air(2, None, [fe.Lookup.pull(one, [var(0), var(1)])])
+    del rng
+    return [a1, wide_air, a2, other_air, a3], [t1, wide, t2, other, t3]
+
+
+GENERAL_MAPS = {  # owners of [table1, wide, table2, other chain, table3]
+    2: [[-1, 0, -1, 1, -1], [1, 0, 1, 0, -1], [-1, 1, 1, 1, 0], [0, 0, 0, 0, 0]],
+    4: [[-1, 0, -1, 3, -1], [2, 0, 2, 1, 3], [-1, 1, -1, 1, -1]],
+    8: [[-1, 5, 2, 0, -1]],
+}
+
+
+def _general_rank(pkg, fe, sharded, oracle, np, rank, group, maps, shared):
+    ctx = pkg.Context(0)
+    comm = group.comm(ctx, rank)
+    inputs, traces = shared["inputs"], shared["traces"]
+    packed = fe.pack_claims([])
+    out = []
+    try:
+        for params in (fe.test_params(), fe.Params(log_blowup=2, cap_height=1, log_final_poly_len=1, num_queries=9, commit_proof_of_work_bits=2,
+                                                   query_proof_of_work_bits=3)):
+            system = pkg.System.new(ctx, params, inputs)
+            for owners in maps:
+                mine = [t.copy() if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+                remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+                proof = system.prove_sharded(system.witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+                hproof = system.prove_sharded(system.host_witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+                assert hproof == proof, "host-resident witness: joint proof differs"
+                if rank == 0:
+                    want = system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
+                    assert proof == want, "owners %s: joint proof differs from the single-GPU proof" % (owners,)
+                    osys = oracle.System(system.blob)
+                    assert osys.verify(packed, proof) == 0 and osys.prove(traces, packed) == proof
+                out.append(hashlib.sha256(proof).hexdigest())
+        return out
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_general_ownership_wide_circuit_and_tables(pkg, fe, oracle, world):
+    """circuits of different widths and heights, several (or none) per rank, replicated tables: every map gives the bytes of
+    the single-GPU proof and of the oracle's"""
+    import importlib
+
+    import numpy as np
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    inputs, traces = _wide_and_tables(fe, np)
+    shared = {"inputs": inputs, "traces": traces}
+    group = sharded.LocalGroup(world)
+    try:
+        res = group.run(lambda rank, g: _general_rank(pkg, fe, sharded, oracle, np, rank, g, GENERAL_MAPS[world], shared))
+    finally:
+        group.close()
+    assert all(r == res[0] for r in res), res
+    assert len(set(res[0])) == 2  # one proof per parameter set, whatever the map
+
+
+def test_general_pattern_on_the_uniform_system(pkg, fe, oracle, monkeypatch):
+    """BASELINE config 3's layout through the per-matrix hand-out (MSAMD_SHARDED_GENERAL=1): same bytes as the all-to-all"""
+    import importlib
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    world, log_adds = 4, 9
+    traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
+    shared = {"traces": traces, "packed": fe.pack_claims(claims)}
+    res = {}
+    for mode in ("uniform", "general"):
+        if mode == "general":
+            monkeypatch.setenv("MSAMD_SHARDED_GENERAL", "1")
+        group = sharded.LocalGroup(world)
+        try:
+            res[mode] = group.run(lambda rank, g: _thread_rank(pkg, fe, sharded, oracle, rank, g, log_adds, "bench", shared))
+        finally:
+            group.close()
+    assert set(res["uniform"]) == set(res["general"]) and len(set(res["general"])) == 1
+
+
+def _general_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
+    """random systems with random owner maps: 1-5 circuits of random shapes, each replicated or owned by a random rank"""
+    world = group.world
+    ctx = pkg.Context(0)
+    comm = group.comm(ctx, rank)
+    try:
+        master = np.random.default_rng(seed)
+        done = 0
+        for case in range(n_cases):
+            rng = np.random.default_rng(master.integers(0, 1 << 62))
+            lb = int(rng.integers(1, 3))
+            lw = world.bit_length() - 1
+            params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 1)), log_final_poly_len=0,
+                               num_queries=int(rng.integers(1, 12)), commit_proof_of_work_bits=int(rng.integers(0, 5)),
+                               query_proof_of_work_bits=int(rng.integers(0, 5)))
+            circuits, traces, owners = [], [], []
+            for _ in range(int(rng.integers(1, 6))):
+                ci, w, fh = fz.random_circuit(rng, fe, lb)
+                h = fh if fh else 1 << int(rng.integers(3, 10))
+                circuits.append(ci)
+                traces.append(fz.rand_field(rng, (h, w)))
+                owners.append(int(rng.integers(-1, world)))
+            if any(t.shape[0] < world for t in traces):
+                continue
+            claims = [[int(x) for x in fz.rand_field(rng, int(rng.integers(0, 5)))] for _ in range(int(rng.integers(0, 4)))]
+            packed = fe.pack_claims(claims)
+            try:
+                compiled = [fe.compile_circuit(c) for c in circuits]
+            except fe.CompileError:
+                continue
+            try:
+                system = pkg.System(ctx, fe.system_blob(params, compiled), len(compiled))
+            except pkg.MstarkError:
+                continue
+            mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+            remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+            proof = system.prove_sharded(system.witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+            if rank == case % world:
+                want = system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
+                assert proof == want, "random case %d (owners %s): joint proof differs from the single-GPU proof" % (case, owners)
+            done += 1
+        return done
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world,seed", [(2, 21), (4, 22), (8, 23)])
+def test_general_ownership_random_systems(pkg, fe, world, seed, monkeypatch):
+    import importlib
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as fz
+
+    monkeypatch.setenv("MSAMD_NO_JIT", "1")
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    n_cases = int(os.environ.get("MSAMD_SHARDED_FUZZ_CASES", "30"))
+    group = sharded.LocalGroup(world)
+    try:
+        res = group.run(lambda rank, g: _general_random_rank(pkg, fe, fz, np, rank, g, seed, n_cases))
+    finally:
+        group.close()
+    assert len(set(res)) == 1 and res[0] >= 10, res
+    print("general ownership, random systems:", res[0], "cases, world", world)
+
+
+def _general_gloo_worker(rank, world, port, q):
+    """the same maps over torch.distributed / gloo processes (TorchComm's staged scatter)"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4", OMP_WAIT_POLICY="passive")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import importlib
+
+        import numpy as np
+        import torch.distributed as dist
+        from __graft_entry__ import load_package
+
+        pkg = load_package()
+        fe = pkg.frontend
+        sharded = importlib.import_module("multi_stark_amd.sharded")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            ctx = pkg.Context(0)
+            comm = sharded.TorchComm(0)
+            inputs, traces = _wide_and_tables(fe, np)
+            packed = fe.pack_claims([])
+            system = pkg.System.new(ctx, fe.test_params(), inputs)
+            shas = []
+            for owners in GENERAL_MAPS[world]:
+                mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+                remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+                proof = system.prove_sharded(system.witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+                if rank == 0:
+                    assert proof == system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
+                shas.append(hashlib.sha256(proof).hexdigest())
+            q.put((rank, ",".join(shas), comm.bytes_moved))
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+    except BaseException as e:
+        q.put((rank, "ERROR: %r" % (e,), 0))
+        raise
+
+
+def test_general_ownership_over_gloo_processes():
+    world = 2
+    port = 29800 + (os.getpid() % 1000)
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_general_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert all(not str(r[1]).startswith("ERROR") for r in res), res
+    assert all(p.exitcode == 0 for p in procs)
+    assert len({r[1] for r in res}) == 1
