@@ -1233,7 +1233,7 @@ static void subtree_levels(Ctx& ctx, BTree& t, SubtreeArgs& a) {
   }
   a.len = (u32)len;
   a.sub = subtree_children_per_group(len);
-  a.counter = ctx.tree_counter;
+  a.counter = tree_counter_slot(ctx);
   a.half = bb_inv(bb_to_monty(2));
 }
 static void launch_subtree(Ctx& ctx, const Poseidon2* d_perm, BTree& t, const FriRoundCh* chp) {

@@ -88,6 +88,12 @@ void download_rowmajor(Ctx& ctx, const u64* col, size_t h, size_t w, bool bitrev
   transpose_out(ctx, col, row.p, h, w, bitrev_rows);
   ctx.d2h(host, row.p, h * w * 8);
 }
+// an extension-field input of a Level-2 call: both coordinates canonical
+E2 canonical_e2(const uint64_t v[2], const char* what) {
+  if (!v) throw std::runtime_error(std::string(what) + ": null");
+  if (v[0] >= GL_P || v[1] >= GL_P) throw std::runtime_error(std::string("non-canonical ") + what);
+  return e2(v[0], v[1]);
+}
 void check_pow2(size_t h) {
   if (h == 0 || (h & (h - 1))) throw std::runtime_error("height must be a power of two");
 }
@@ -655,7 +661,8 @@ int32_t ms_witness_claims_accumulator(ms_witness* w, const uint64_t beta[2], con
   HIP_CHECK(hipSetDevice(ctx.device));
   need_device_witness(wit);
   const size_t n_claims = wit.claim_offsets.size() - 1;
-  E2 a = n_claims ? claims_accumulator(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, e2(beta[0], beta[1]), e2(gamma[0], gamma[1])) : e2(0);
+  const E2 b = canonical_e2(beta, "beta"), g = canonical_e2(gamma, "gamma");
+  E2 a = n_claims ? claims_accumulator(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, b, g) : e2(0);
   acc_out[0] = a.c0;
   acc_out[1] = a.c1;
   return MS_OK;
@@ -669,7 +676,8 @@ int32_t ms_stage2_build(ms_witness* w, const uint64_t beta[2], const uint64_t ga
   Ctx& ctx = *sys.ctx;
   HIP_CHECK(hipSetDevice(ctx.device));
   need_device_witness(wit);
-  E2 acc = e2(acc_in[0], acc_in[1]);
+  const E2 beta_e = canonical_e2(beta, "beta"), gamma_e = canonical_e2(gamma, "gamma");
+  E2 acc = canonical_e2(acc_in, "accumulator");
   size_t pos = 0;
   std::vector<std::unique_ptr<ms_trace, void (*)(ms_trace*)>> made;
   for (size_t ci = 0; ci < sys.circuits.size(); ci++) {
@@ -683,7 +691,7 @@ int32_t ms_stage2_build(ms_witness* w, const uint64_t beta[2], const uint64_t ga
     E2 tot;
     {
       DBuf<E2> d_tot(ctx, 1);
-      stage2_circuit_async(ctx, sys, wit, ci, e2(beta[0], beta[1]), e2(gamma[0], gamma[1]), ev.d(), d_tot.p);
+      stage2_circuit_async(ctx, sys, wit, ci, beta_e, gamma_e, ev.d(), d_tot.p);
       ctx.d2h(&tot, d_tot.p, sizeof(E2));
     }
     acc = e2_add(acc, tot);
@@ -706,10 +714,17 @@ int32_t ms_pcs_commit_traces(ms_ctx* c, uint32_t log_blowup, uint32_t cap_height
   std::unique_ptr<ms_mmcs> m(new ms_mmcs());
   m->ctx = &ctx;
   std::vector<DMat> ldes;
+  // every handle is checked before the first one is consumed: a bad handle at position i leaves the others intact
+  if (n == 0 || !evals) throw std::runtime_error("ms_pcs_commit_traces: no matrices");
   for (size_t i = 0; i < n; i++) {
     ms_trace* t = evals[i];
     if (!t || t->ctx != &ctx || t->kind != 0 || !t->m.d()) throw std::runtime_error("ms_pcs_commit_traces: not an evaluation handle of this context");
     if (t->log_n > NTT_MAX_LOG || t->log_n + log_blowup > TW_LOG) throw std::runtime_error("matrix too tall");
+    for (size_t j = 0; j < i; j++)
+      if (evals[j] == t) throw std::runtime_error("ms_pcs_commit_traces: the same handle twice");
+  }
+  for (size_t i = 0; i < n; i++) {
+    ms_trace* t = evals[i];
     DMat lde;
     lde.h = t->m.h << log_blowup;
     lde.w = t->m.w;
@@ -737,6 +752,8 @@ int32_t ms_quotient(ms_system* sys, size_t ci, uint32_t log_n, ms_mmcs* s1, size
   if (ci >= s.circuits.size()) throw std::runtime_error("circuit index out of range");
   const HCircuit& c = s.circuits[ci];
   const unsigned lb = (unsigned)s.params.log_blowup, log_q = log2_strict(c.quotient_degree());
+  if (log_n > NTT_MAX_LOG || log_n + lb > TW_LOG) throw std::runtime_error("ms_quotient: log_n out of range");  // (before any 1 << log_n)
+  if (!s1 || !s2 || !publics8 || !alpha) throw std::runtime_error("ms_quotient: null argument");
   if (s1->ctx != &ctx || s2->ctx != &ctx) throw std::runtime_error("commitment belongs to another context");
   if (s1_idx >= s1->pd().ldes.size() || s2_idx >= s2->pd().ldes.size()) throw std::runtime_error("matrix index out of range");
   const DMat& m1 = s1->pd().ldes[s1_idx];
@@ -761,7 +778,7 @@ int32_t ms_quotient(ms_system* sys, size_t ci, uint32_t log_n, ms_mmcs* s1, size
     if (publics8[k] >= GL_P) throw std::runtime_error("non-canonical public value");
     qa.publics[k] = publics8[k];
   }
-  qa.alpha = e2(alpha[0], alpha[1]);
+  qa.alpha = canonical_e2(alpha, "alpha");
   DBuf<u64> qv(ctx, nq * 2);
   quotient_eval(ctx, c.prog, qa, qv.p);
   DMat lde;

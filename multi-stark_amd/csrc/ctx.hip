@@ -470,7 +470,19 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
     down_direct = true;  // the next synchronisation has to be a real stream synchronisation
     return;
   }
-  if (down_used + need > pinned_half) sync_and_deliver();
+  if (down_used + need > pinned_half) {
+    // the staging half is full. Wrapping it (synchronise, deliver, start again at offset 0) would let the segments queued
+    // next overwrite a view handed out by d2h_queue_staged that its caller has not read yet: with such a view pending, this
+    // read-back goes straight to its destination instead (staged by the runtime; the next synchronisation is a real one)
+    bool view_pending = false;
+    for (auto& d : down_pending) view_pending = view_pending || d.dst == nullptr;
+    if (view_pending) {
+      HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
+      down_direct = true;
+      return;
+    }
+    sync_and_deliver();
+  }
   // the copy itself is issued by the next synchronisation: one flag-copy kernel for all short segments, or one
   // hipMemcpyAsync each when they are many or long
   PendingD2H pd;

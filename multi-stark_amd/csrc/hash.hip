@@ -739,7 +739,7 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
         sp.g = n_inj ? drefs + inj[inj_li].first : nullptr;
         sp.inj_w = n_inj ? inj[inj_li].total_w : 0u;
         sp.inj_multi = n_inj && inj[inj_li].total_w > 128 ? 1u : 0u;
-        sp.counter = ctx.tree_counter;
+        sp.counter = tree_counter_slot(ctx);
         sp.fc = fc ? *fc : FriChallenge{};
         const unsigned nb = (unsigned)(child_len / sp.sub);
         const KernelId kid = fc ? K_OTHER : K_COMPRESS;
@@ -827,7 +827,7 @@ void fri_round_fused(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriTa
   sp.child = t.base();
   sp.len = (u32)leaves;
   sp.sub = subtree_children_per_group(leaves);
-  sp.counter = ctx.tree_counter;
+  sp.counter = tree_counter_slot(ctx);
   sp.fc = fc;
   sp.fold.cur = cur;
   sp.fold.roll = roll_in;

@@ -154,6 +154,13 @@ struct Ctx {
   void prof_collect();
 };
 
+// Ticket counter of the in-launch sub-tree hand-over for the stream the next launch goes to: the main and the side stream run
+// concurrently, and two trees sharing one counter would mix their tickets (a wrong "last arriver"). One slot per stream, a
+// cache line apart. (The hand-over itself keeps the protocol of MI355X_MICROARCH.md, "inter-workgroup visibility": sc1
+// write-through payload, drained, relaxed agent-scope ticket, sc1 loads by the last arriver - a release / acquire pair at
+// agent scope would write back and invalidate the whole L2 of the XCD for 32 bytes of payload.)
+inline u32* tree_counter_slot(Ctx& ctx) { return ctx.tree_counter + (ctx.side_depth > 0 ? 32 : 0); }
+
 // roctx range with one of the reference's tracing span names (src/prover.rs:289,336,391,413,437,538: "stark/prove",
 // "stark/stage1_commit", ...), so that rocprofv3 --marker-trace shows the same phases the reference's tracing subscriber
 // does. The roctx library is looked up at run time; without it the ranges cost nothing.

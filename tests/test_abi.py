@@ -71,3 +71,28 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle/" not in src and "libms_oracle" not in src and "import oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_missing_librccl_is_an_error_code_not_a_crash(pkg, tmp_path):
+    """MSAMD_RCCL_LIB names the library to load; when it cannot be loaded the call returns MS_ERR with the loader's reason
+    (ms_comm_rccl_unique_id needs no GPU). Run in a child process: the library caches the RCCL it finds."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes, os, sys\n"
+        "os.environ['MSAMD_RCCL_LIB'] = %r\n"
+        "L = ctypes.CDLL(%r)\n"
+        "L.ms_last_error.restype = ctypes.c_char_p\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = L.ms_comm_rccl_unique_id(buf)\n"
+        "print(rc, L.ms_last_error().decode())\n"
+        "out = ctypes.c_void_p()\n"
+        "rc2 = L.ms_comm_rccl_create(None, buf, 0, 2, ctypes.byref(out))\n"
+        "print(rc2)\n"
+    ) % (str(tmp_path / "no_such_librccl.so"), pkg.LIB_PATH)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    first, second = r.stdout.strip().splitlines()[:2]
+    assert first.startswith("-1 ") and "cannot load librccl" in first and "no_such_librccl" in first, r.stdout
+    assert second.strip() == "-1"

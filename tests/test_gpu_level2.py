@@ -148,3 +148,23 @@ def test_level2_handles_are_checked(pkg, ctx, fe):
     s1 = w.commit_stage1([256, 64], [1, 14])
     with pytest.raises(pkg.MstarkError, match="shape"):
         system.quotient(1, 6, s1, 0, s2, 1, [0] * 8, (1, 0))          # wrong matrix index
+    # inputs are validated before anything is shifted, launched or consumed
+    P = fe.P
+    with pytest.raises(pkg.MstarkError, match="log_n"):
+        system.quotient(1, 64, s1, 1, s2, 1, [0] * 8, (1, 0))         # (1 << 64 would be undefined)
+    with pytest.raises(pkg.MstarkError, match="non-canonical"):
+        system.quotient(1, 6, s1, 1, s2, 1, [0] * 8, (P, 0))          # alpha
+    with pytest.raises(pkg.MstarkError, match="non-canonical"):
+        w.stage2_build(2, (P, 2), (3, 4), (0, 0))
+    with pytest.raises(pkg.MstarkError, match="non-canonical"):
+        w.stage2_build(2, (1, 2), (3, 4), (0, P + 5))
+    with pytest.raises(pkg.MstarkError, match="non-canonical"):
+        w.claims_accumulator((1, 2), (P, 4))
+    # a bad handle in the list leaves the good ones unconsumed
+    _, fresh = w.stage2_build(2, (1, 2), (3, 4), (0, 0))
+    with pytest.raises(pkg.MstarkError):
+        pkg.pcs_commit_traces(ctx, [fresh[0], s2_traces[0]], params.log_blowup, 0)   # the second one is empty
+    assert fresh[0].info()[0] == 256                                  # still holds its evaluations
+    with pytest.raises(pkg.MstarkError, match="twice"):
+        pkg.pcs_commit_traces(ctx, [fresh[0], fresh[0]], params.log_blowup, 0)
+    assert pkg.pcs_commit_traces(ctx, fresh, params.log_blowup, 0).cap == s2.cap
