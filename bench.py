@@ -29,6 +29,10 @@ import sys
 import threading
 import time
 
+# the pool's host driver supports dmabuf IPC only: RCCL (and any sharing of device memory across processes) needs this before
+# the first HIP call of the process; exported on the boxes already, set here for a launcher that drops the environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -665,6 +669,18 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
             line["error"] = "joint proof pre-flight failed: %s" % e
             line["preflight"] = e.info
             return line
+        except Exception as e:  # noqa: BLE001
+            # a failing exchange (the library aborts its communicator, so the peers fail too instead of hanging): say what and
+            # where, keep the figures already measured, end with a non-zero status - and without the closing barrier, which
+            # a rank that failed earlier would never join
+            where = wd.where()
+            wd.finish()
+            log("[rank %d] joint proof failed in %s: %r" % (rank, where, e))
+            line = partial()
+            line["error"] = "joint proof failed (%s): %s" % (where, e)
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            os._exit(4)
     wd.finish()
     prim = done["joint"] if joint_primary else done["replicas"]
     info, dominant, dom, rows = prim

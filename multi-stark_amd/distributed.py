@@ -3,8 +3,9 @@
 The reference has no distributed mode at all. Independent proofs shard one per rank with
 no data-path collective; the only exchange is an all_gather of each rank's three 32-byte commitments
 (stage 1, stage 2, quotient) that rank 0 folds into one joint digest — the "gather per-circuit commitments" step
-of the north star. (A single joint Proof over one shared Merkle tree needs a row-range all-to-all before leaf
-hashing, SURVEY §8e: not built in this round.)"""
+of the north star. This is the "replicas" mode (bench.py's secondary figure). The single joint Proof over one shared Merkle
+tree per commitment (row-range exchange before leaf hashing) is ms_prove_sharded, with its transports in
+sharded.py / csrc/comm_rccl.hip / csrc/comm_local.hip."""
 import hashlib
 
 import torch
