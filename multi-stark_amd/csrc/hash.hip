@@ -811,7 +811,12 @@ void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc) {
 
 bool fri_round_fusable(size_t rows) {
   const char* off = getenv("MSAMD_NO_FRI_FUSED");
-  return !off && !getenv("MSAMD_NO_SUBTREE") && rows >= 4 && rows / 2 <= (size_t(1) << 21);
+  // above 2^MSAMD_FRI_FUSED_MAX_LOG leaves a round is work, not latency: fold + leaf digests, three tree levels per launch
+  // and the sub-tree launch as separate kernels keep the chip full where the one-launch form leaves most lanes idle in the
+  // upper levels of each workgroup's sub-tree
+  const char* ml = getenv("MSAMD_FRI_FUSED_MAX_LOG");
+  const unsigned max_log = ml ? (unsigned)atoi(ml) : 21u;
+  return !off && !getenv("MSAMD_NO_SUBTREE") && rows >= 4 && rows / 2 <= (size_t(1) << std::min(max_log, 21u));
 }
 
 // One commit-phase round in one launch: fold `cur` (2 * rows elements) with the beta of `prev` into `out` (rows elements),

@@ -70,3 +70,23 @@ def test_bench_witness_matches_reference_generator(fe):
     assert byte.shape == (256, 1) and add.shape == (8, 14) and int(byte.sum()) == 12 * 8
     x = sum(int(add[0, k]) << (8 * k) for k in range(4))
     assert x == int(claims[0, 1]) and int(add[0, 13]) == 1
+
+
+def test_node_vectors_have_not_drifted(fe):
+    """tests/golden/frontend_nodes.json records the node vectors this front-end compiles for the reference's circuits. Both
+    the HIP library and the oracle consume its output, so a change here (interning order, folding rule, lookup prefix) would
+    prove and verify identically on both sides: this test is what notices. (Correctness against the reference's
+    graph::compile is checked by tests/test_reference_pins.py when the reference's fixture file is present.)"""
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_frontend_golden", os.path.join(here, "make_frontend_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "frontend_nodes.json")))["circuits"]
+    got = json.loads(json.dumps(mod.describe(fe)))
+    assert set(got) == set(want)
+    for name in want:
+        assert got[name] == want[name], "front-end output changed for: %s (regenerate the golden file only if the change is intended)" % name
