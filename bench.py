@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--cpu-log-adds", type=int, default=20, help="size of the CPU baseline leg (same workload as the GPU by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-in-flight", action="store_true", help="N = 1: skip the secondary two-proofs-in-flight throughput figure")
+    ap.add_argument("--no-config4", action="store_true", help="N = 1: skip the secondary BASELINE-config-4 (BabyBear / Poseidon2) leg of the default run")
     ap.add_argument("--hbm-resident", action="store_true", help="N = 1: primary figure from a witness already resident in HBM "
                     "(round-1 definition) instead of the host-resident one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL on ROCm; gloo only to "
@@ -816,6 +817,26 @@ def main():
         result = babybear(args, pkg, fe, ctx, torch)
     elif dist is None:
         result = single_gpu(args, pkg, fe, ctx, torch)
+        if not args.no_config4 and not args.hbm_resident and args.log_adds == 20:
+            # BASELINE config 4 (the reference's second StarkGenericConfig) as a secondary object of the same line, so that the
+            # run that records config 2 also records it; its full line (roofline, CPU baseline) is `--config babybear`
+            try:
+                import copy
+
+                a4 = copy.copy(args)
+                a4.steps, a4.warmup, a4.no_cpu_baseline = max(3, min(args.steps, 10)), 2, True
+                r4 = babybear(a4, pkg, fe, ctx, torch)
+                result["config4_babybear"] = {
+                    "what": "BASELINE config 4, secondary leg of this run: " + r4["config"]["workload"],
+                    "value": r4["value"], "unit": r4["unit"], "ms_per_step": r4["ms_per_step"], "steps": a4.steps,
+                    "hbm_resident_ms": r4["config"]["hbm_resident_ms"], "stage_ms": r4["config"]["stage_ms"],
+                    "proof_bytes": r4["config"]["proof_bytes"], "verified": r4["config"]["verified"],
+                    "note": "timed with HIP events around every launch of its dominant kernel class (%s: %d launches), which adds about a "
+                            "millisecond per proof; hbm_resident_ms is timed without events" % (r4["roofline"]["kernel"], r4["roofline"]["launches"] // max(a4.steps, 1))}
+                log("config 4 (BabyBear / Poseidon2) secondary leg: %.3f ms per step, %.3f ms HBM-resident" % (
+                    r4["ms_per_step"], r4["config"]["hbm_resident_ms"] or float("nan")))
+            except Exception as e:  # noqa: BLE001  (a secondary figure must not void the run)
+                log("config 4 secondary leg skipped: %r" % (e,))
     else:
         result = multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus)
         dist.barrier()
@@ -837,12 +858,35 @@ def measured_traffic(kernel):
     return None, None
 
 
+def native_oracle_dir():
+    """The oracle compiled on THIS box with -march=native (the reference's .cargo/config.toml sets -Ctarget-cpu=native); the copy
+    that travelled with the repository is built for x86-64-v3. None when it cannot be built here (no compiler): the caller
+    then times the portable build and says so."""
+    import subprocess
+
+    if os.environ.get("MSAMD_BENCH_PORTABLE_ORACLE"):
+        return None
+    out = os.path.join(ROOT, "oracle", "_native")
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ARCH=native", "OUT=_native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=300)
+        return out if os.path.exists(os.path.join(out, "libms_oracle.so")) else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(fe, blob, log_adds):
     """The oracle (multi-threaded C++ restatement, kind "port") timed on this box's host cores over the SAME workload
     as the GPU step (2^log_adds additions; one proof is a few seconds); the thread count is chosen by a quick sweep
     on a 2^16 sample first. It is a reported baseline, not the thing measured or shipped."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    native = None
+    if "oracle" not in sys.modules:  # (the library is chosen when the wrapper is first imported)
+        native = native_oracle_dir()
+        if native:
+            os.environ["MSO_ORACLE_DIR"] = native
+    log("cpu baseline: oracle built with -march=%s" % ("native (on this box)" if native else "x86-64-v3 (the build that travelled with the repository)"))
     oracle = load_oracle()
     osys = oracle.System(blob)
     t_all = time.time()
@@ -877,9 +921,9 @@ def cpu_baseline(fe, blob, log_adds):
         "unit": "rows/s",
         "cores": best_cores,
         "kind": "port",
-        "sample": "oracle C++ restatement (OpenMP; %d threads, the best of a sweep over %s at 2^%d additions), same circuit and "
+        "sample": "oracle C++ restatement (OpenMP, -O3 -march=%s; %d threads, the best of a sweep over %s at 2^%d additions), same circuit and "
                   "params as the GPU step, 2^%d additions per proof, best of %d proofs, %.3f s/proof (witness prep excluded; "
-                  "%d host threads available)" % (best_cores, sorted(sweep), min(16, log_adds), log_adds, runs, best, avail),
+                  "%d host threads available)" % ("native" if native else "x86-64-v3", best_cores, sorted(sweep), min(16, log_adds), log_adds, runs, best, avail),
     }
 
 

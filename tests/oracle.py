@@ -11,7 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 BABYBEAR = __name__.endswith("oracle_bb")
-LIB_PATH = os.path.join(ORACLE_DIR, "libms_oracle_bb.so" if BABYBEAR else "libms_oracle.so")
+# MSO_ORACLE_DIR: another build of the same sources (bench.py's cpu_baseline leg compiles one with -march=native on the box it times)
+LIB_PATH = os.path.join(os.environ.get("MSO_ORACLE_DIR") or ORACLE_DIR, "libms_oracle_bb.so" if BABYBEAR else "libms_oracle.so")
 D = 4 if BABYBEAR else 2  # extension degree: Ext values cross the C surface as D consecutive u64
 
 # libgomp's default active spinning stalls badly when the container's CPUs are oversubscribed

@@ -10,18 +10,18 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 find_csv() { find "$1" -name "*$2" | head -1; }
 echo "== bench line"; python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.log || exit 1
-echo "== kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_stats_run.json 2> $OUT/stats.log || exit 1
+echo "== kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config4 --no-in-flight > $OUT/${TAG}_stats_run.json 2> $OUT/stats.log || exit 1
 cp "$(find_csv $OUT/stats kernel_stats.csv)" $OUT/${TAG}_kernel_stats_bench.csv
 python3 $REPO/tools/prof_summary.py $OUT/${TAG}_kernel_stats_bench.csv 27 52 > $OUT/${TAG}_kernel_stats_summary_per_proof.txt
-echo "== SQ counters"; rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/sq -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident > /dev/null 2> $OUT/sq.log || exit 1
+echo "== SQ counters"; rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/sq -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/sq.log || exit 1
 python3 $REPO/tools/pmc_summary.py "$(find_csv $OUT/sq counter_collection.csv)" > $OUT/${TAG}_pmc_sq.txt
 python3 $REPO/tools/valu_from_pmc.py "$(find_csv $OUT/sq counter_collection.csv)" $OUT/${TAG}_valu.json > /dev/null
-echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident > /dev/null 2> $OUT/fetch.log || exit 1
-echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident > /dev/null 2> $OUT/write.log || exit 1
+echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/fetch.log || exit 1
+echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/write.log || exit 1
 python3 $REPO/tools/traffic_from_pmc.py "$(find_csv $OUT/fetch counter_collection.csv)" "$(find_csv $OUT/write counter_collection.csv)" $OUT/${TAG}_traffic.json > /dev/null
 echo "== timeline"; rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python3 $REPO/tools/trace_run.py 20 notrace > /dev/null 2> $OUT/tl.log || exit 1
 python3 $REPO/tools/timeline.py "$(find_csv $OUT/tl kernel_trace.csv)" > $OUT/${TAG}_timeline_gaps.txt
-echo "== config 4"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bb -- python3 $REPO/bench.py --config babybear --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_config4_stats_run.json 2> $OUT/bb.log || exit 1
+echo "== config 4"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bb -- python3 $REPO/bench.py --config babybear --steps 5 --warmup 2 --no-cpu-baseline --no-config4 --no-in-flight > $OUT/${TAG}_config4_stats_run.json 2> $OUT/bb.log || exit 1
 cp "$(find_csv $OUT/bb kernel_stats.csv)" $OUT/${TAG}_config4_kernel_stats.csv
 python3 $REPO/tools/prof_summary.py $OUT/${TAG}_config4_kernel_stats.csv 14 30 > $OUT/${TAG}_config4_kernel_stats_summary_per_proof.txt
 python3 $REPO/bench.py --config babybear --steps 20 --warmup 5 > $OUT/${TAG}_config4_bench_line.json 2> $OUT/bb_line.log || exit 1
