@@ -34,7 +34,10 @@ class _DevBytes:
 
 
 class TorchComm:
-    def __init__(self, device_index=0, group=None):
+    def __init__(self, device_index=0, group=None, memory="device"):
+        """memory="host": the pointers handed to the callbacks are HOST addresses (CPU tests of the exchange patterns,
+        tests/test_distributed_cpu.py: the table's index arithmetic over gloo without a GPU); the library itself always
+        passes device pointers."""
         global torch, dist
         import torch  # plumbing of this transport only: RcclComm below needs neither
         import torch.distributed as dist
@@ -42,8 +45,9 @@ class TorchComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.device = torch.device("cuda", device_index)
-        self.direct = dist.get_backend(group) == "nccl"
+        self.host_memory = memory == "host"
+        self.device = torch.device("cpu") if self.host_memory else torch.device("cuda", device_index)
+        self.direct = dist.get_backend(group) == "nccl" and not self.host_memory
         self.error = None
         self.bytes_moved = 0
         self._a2a = _CB(self._all_to_all)
@@ -57,7 +61,13 @@ class TorchComm:
         self.struct.scatter_cols_start = self._scatter
 
     def _view(self, ptr, nbytes):
+        if self.host_memory:
+            return torch.frombuffer((C.c_uint8 * nbytes).from_address(int(ptr)), dtype=torch.uint8)
         return torch.as_tensor(_DevBytes(ptr, nbytes), device=self.device)
+
+    def _sync(self):
+        if not self.host_memory:
+            torch.cuda.synchronize(self.device)
 
     def _guard(self, fn):
         try:
@@ -79,14 +89,14 @@ class TorchComm:
             self.bytes_moved += n
             if self.direct:
                 dist.all_to_all_single(r, s, group=self.group)
-                torch.cuda.synchronize(self.device)
+                self._sync()
             else:
                 hs = s.cpu()
                 parts = [torch.empty(n, dtype=torch.uint8) for _ in range(self.world)]
                 dist.all_gather(parts, hs, group=self.group)  # gloo has no all_to_all on every build: take my block of each
                 hr = torch.cat([p[self.rank * per_peer:(self.rank + 1) * per_peer] for p in parts])
                 r.copy_(hr)
-                torch.cuda.synchronize(self.device)
+                self._sync()
 
         return self._guard(run)
 
@@ -105,7 +115,7 @@ class TorchComm:
                 dist.all_gather(parts, mine, group=self.group)
                 for k in range(self.world):
                     outs[k].copy_(parts[k][self.rank * per_peer:(self.rank + 1) * per_peer])
-                torch.cuda.synchronize(self.device)
+                self._sync()
 
         return self._guard(run)
 
@@ -140,7 +150,7 @@ class TorchComm:
                     blk = parts[k][self.rank * per:(self.rank + 1) * per]
                     for c in range(ncols):
                         outs[k][c].copy_(blk[c * seg:(c + 1) * seg])
-                torch.cuda.synchronize(self.device)
+                self._sync()
 
         return self._guard(run)
 
@@ -172,7 +182,7 @@ class TorchComm:
                     blk = buf[self.rank * per:(self.rank + 1) * per]
                     for c in range(ncols):
                         outs[c].copy_(blk[c * seg:(c + 1) * seg])
-                    torch.cuda.synchronize(self.device)
+                    self._sync()
 
         return self._guard(run)
 
@@ -181,7 +191,7 @@ class TorchComm:
             for w in self._pending:
                 w.wait()
             self._pending = []
-            torch.cuda.synchronize(self.device)
+            self._sync()
 
         return self._guard(run)
 
@@ -191,12 +201,12 @@ class TorchComm:
             self.bytes_moved += nbytes * self.world
             if self.direct:
                 dist.all_gather_into_tensor(r, s, group=self.group)
-                torch.cuda.synchronize(self.device)
+                self._sync()
             else:
                 parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
                 dist.all_gather(parts, s.cpu(), group=self.group)
                 r.copy_(torch.cat(parts))
-                torch.cuda.synchronize(self.device)
+                self._sync()
 
         return self._guard(run)
 

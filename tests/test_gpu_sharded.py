@@ -283,6 +283,10 @@ def _thread_rank(pkg, fe, sharded, oracle, rank, group, log_adds, variant, share
                 assert osys.prove(traces, packed) == proof, "sharded proof differs from the oracle's proof"
             assert system.verify_multiple_claims(packed, proof) == 0
         assert world == 1 or comm.bytes_moved > 0
+        if world > 1:
+            # the library's record of its calls into the transport (what a watchdog prints when a peer never arrives)
+            text, seq, inside = ctx.comm_progress()
+            assert seq > 10 and not inside and "rank %d of %d" % (rank, world) in text and "FRI queries" in text, (text, seq, inside)
         return hashlib.sha256(proof).hexdigest()
     finally:
         comm.close()
@@ -352,6 +356,50 @@ def test_thread_ranks_failure_does_not_hang(pkg, fe, monkeypatch):
         with pytest.raises(pkg.MstarkError):
             attempt(2, nth)
         assert attempt(-1, 0) == good
+
+
+def test_thread_ranks_peer_that_never_arrives(pkg, fe, monkeypatch):
+    """a peer that never joins the proof: the waiting rank gets an error that names the exchange it waited in - not a hang"""
+    import importlib
+    import time
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    monkeypatch.setenv("MSAMD_LOCAL_TIMEOUT_S", "3")
+    world = 2
+    traces, claims = fe.multi_u32_add_witness(world, 1 << 8)
+    packed = fe.pack_claims(claims)
+    owners = sharded.u32_add_owners(world)
+    group = sharded.LocalGroup(world)
+    seen = {}
+
+    def body(rank, g):
+        ctx = pkg.Context(0)
+        comm = g.comm(ctx, rank)
+        try:
+            if rank == 1:
+                time.sleep(6)  # never calls ms_prove_sharded
+                return "absent"
+            system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+            mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+            w = system.witness(mine, packed, remote_heights={2: traces[2].shape[0]})
+            t0 = time.time()
+            try:
+                system.prove_sharded(w, comm, owners)
+            except pkg.MstarkError as e:
+                seen["error"], seen["after"] = str(e), time.time() - t0
+                seen["progress"] = ctx.comm_progress()
+                return "failed as it should"
+            return "returned?!"
+        finally:
+            comm.close()
+
+    try:
+        res = group.run(body)
+    finally:
+        group.close()
+    assert res == ["failed as it should", "absent"], (res, seen)
+    assert "never arrived" in seen["error"] and "stage-1 commit" in seen["error"] and seen["after"] < 5.5, seen
+    assert "stage-1 commit" in seen["progress"][0]
 
 
 def _thread_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
