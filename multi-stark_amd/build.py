@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmstark_hip.so")
-SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "prover.hip", "verifier.hip", "witness_gen.hip", "capi.hip",
+SOURCES = ["ctx.hip", "ntt.hip", "hash.hip", "lookup.hip", "quotient.hip", "quotient_jit.hip", "open.hip", "outer.hip", "prover.hip", "verifier.hip", "witness_gen.hip", "capi.hip",
            "comm_rccl.hip", "comm_local.hip", "bb_kernels.hip", "bb_prover.hip", "pack_host.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

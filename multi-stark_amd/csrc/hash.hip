@@ -935,10 +935,12 @@ void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, cons
   HIP_CHECK(hipGetLastError());
 }
 
-Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks) {
-  DBuf<Digest> b(ctx, (nchunks + 1) / 2);
+// the tree over the chunks' chaining values; returns where the digest lies on the device (inside cvs or scratch: copied to
+// out_dev when given)
+static const Digest* blake3_cv_tree(Ctx& ctx, Digest* cvs, size_t nchunks, DBuf<Digest>& scratch, Digest* out_dev) {
+  scratch = DBuf<Digest>(ctx, (nchunks + 1) / 2);
   Digest* cur = cvs;
-  Digest* nxt = b.p;
+  Digest* nxt = scratch.p;
   size_t n = nchunks;
   while (n > 1) {
     if (n <= 2048) {  // the rest in one launch
@@ -953,9 +955,20 @@ Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks) {
     n = nn;
   }
   HIP_CHECK(hipGetLastError());
+  if (out_dev) HIP_CHECK(hipMemcpyAsync(out_dev, cur, sizeof(Digest), hipMemcpyDeviceToDevice, ctx.stream));
+  return cur;
+}
+Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks) {
+  DBuf<Digest> b;
+  const Digest* cur = blake3_cv_tree(ctx, cvs, nchunks, b, nullptr);
   Digest out;
   ctx.d2h(&out, cur, sizeof(Digest));
   return out;
+}
+// launches only: the digest is left at out_dev (device memory)
+void blake3_from_cvs_async(Ctx& ctx, Digest* cvs, size_t nchunks, Digest* out_dev) {
+  DBuf<Digest> b;
+  (void)blake3_cv_tree(ctx, cvs, nchunks, b, out_dev);
 }
 
 Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords) {

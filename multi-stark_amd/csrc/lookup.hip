@@ -57,10 +57,12 @@ __device__ __forceinline__ void for_each_inverse(const u64* __restrict__ args_ro
 
 // pass 1 (natural row order): terms[r][j] = mult * msg^-1 and the row total
 __global__ __launch_bounds__(256) void stage2_terms_k(const u64* __restrict__ mult, const u64* __restrict__ args,
-                                                      const u32* __restrict__ offs, size_t n, u32 L, u32 aw, E2 beta, E2 gamma,
-                                                      GammaPows gp, E2* __restrict__ terms, E2* __restrict__ rowsum) {
+                                                      const u32* __restrict__ offs, size_t n, u32 L, u32 aw,
+                                                      const ChallengeBG* __restrict__ ch, E2* __restrict__ terms, E2* __restrict__ rowsum) {
   size_t r = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (r >= n) return;
+  const E2 beta = ch->beta, gamma = ch->gamma;
+  const GammaPows& gp = ch->gp;
   E2 s = e2(0);
   const u64* mrow = mult + r * L;
   E2* trow = terms + r * L;
@@ -159,9 +161,11 @@ __global__ __launch_bounds__(256) void scan_add_k(E2* __restrict__ out, size_t n
     if (base + k < n) out[base + k] = e2_add(out[base + k], p);
 }
 
-__global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n, E2 beta,
-                                                    E2 gamma, GammaPows gp, E2* __restrict__ partial) {
+__global__ __launch_bounds__(256) void claims_acc_k(const u64* __restrict__ data, const u64* __restrict__ offs, size_t n,
+                                                    const ChallengeBG* __restrict__ ch, E2* __restrict__ partial) {
   __shared__ E2 sh[256];
+  const E2 beta = ch->beta, gamma = ch->gamma;
+  const GammaPows& gp = ch->gp;
   const size_t base = blockIdx.x * size_t(256 * CLAIMS_CHUNK) + threadIdx.x;  // claim t of this thread: base + t * 256
   E2 msg[CLAIMS_CHUNK];
   E2 sum = e2(0);
@@ -216,18 +220,21 @@ static void scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n, E2* total_
   HIP_CHECK(hipGetLastError());
 }
 
-static GammaPows gamma_pows(E2 gamma, size_t max_args) {
-  GammaPows gp;
-  gp.n = (u32)(max_args < (size_t)MAX_GPOW ? max_args : (size_t)MAX_GPOW);
-  E2 g = e2(1);
-  for (int i = 0; i < MAX_GPOW; i++) {
-    gp.g[i] = g;
-    g = e2_mul(g, gamma);
-  }
-  return gp;
+// beta / gamma as a block in device memory (the form the kernels read); the staging copy is taken at once, so the host block
+// may go out of scope
+DBuf<ChallengeBG> challenge_bg_upload(Ctx& ctx, E2 beta, E2 gamma) {
+  ChallengeBG h;
+  challenge_bg_fill(h, beta, gamma);
+  DBuf<ChallengeBG> d(ctx, 1);
+  ctx.h2d(d.p, &h, sizeof(h));
+  return d;
 }
 
 void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, E2* total_dev, const JitKernel* jit) {
+  DBuf<ChallengeBG> ch = challenge_bg_upload(ctx, beta, gamma);
+  stage2_build_dyn(ctx, lk, ch.p, out, total_dev, jit);
+}
+void stage2_build_dyn(Ctx& ctx, const DLookups& lk, const ChallengeBG* ch, u64* out, E2* total_dev, const JitKernel* jit) {
   size_t n = lk.height;
   if (lk.num_lookups == 0) {
     // pass-through accumulator column: zeros (src/lookup.rs:517-521)
@@ -239,21 +246,19 @@ void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* ou
   u32 L = (u32)lk.num_lookups, aw = (u32)lk.args_width;
   DBuf<E2> rowsum(ctx, n), prefix(ctx, n), terms(ctx, n * L);
   dim3 grid((unsigned)((n + 255) / 256));
-  GammaPows gp = gamma_pows(gamma, MAX_GPOW);
   hipEvent_t ev = ctx.prof_begin(K_STAGE2);
   if (jit && jit->function) {  // the circuit's own kernel: argument offsets are literals, the row is loaded up front
     Stage2Params sp;
     sp.mult = lk.mult.p;
     sp.args = lk.args.p;
     sp.n = n;
-    sp.beta = beta;
-    sp.gp = gp;
+    sp.ch = ch;
     sp.terms = terms.p;
     sp.rowsum = rowsum.p;
     stage2_jit_launch(ctx, *jit, sp);
   } else {
-    hipLaunchKernelGGL(stage2_terms_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, beta, gamma, gp,
-                       terms.p, rowsum.p);
+    hipLaunchKernelGGL(stage2_terms_k, grid, dim3(256), 0, ctx.stream, lk.mult.p, lk.args.p, lk.arg_offsets.p, n, L, aw, ch, terms.p,
+                       rowsum.p);
   }
   ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw));
   scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev);
@@ -265,6 +270,11 @@ void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* ou
 
 void stage2_from_trace_async(Ctx& ctx, const JitKernel& trace_jit, const u64* d_trace, const u64* d_pre, size_t n, size_t num_lookups,
                              size_t args_width, E2 beta, E2 gamma, u64* out, E2* total_dev) {
+  DBuf<ChallengeBG> ch = challenge_bg_upload(ctx, beta, gamma);
+  stage2_from_trace_dyn(ctx, trace_jit, d_trace, d_pre, n, num_lookups, args_width, ch.p, out, total_dev);
+}
+void stage2_from_trace_dyn(Ctx& ctx, const JitKernel& trace_jit, const u64* d_trace, const u64* d_pre, size_t n, size_t num_lookups,
+                           size_t args_width, const ChallengeBG* ch, u64* out, E2* total_dev) {
   if (!trace_jit.function || num_lookups == 0) throw std::runtime_error("stage2_from_trace: no fused kernel for this circuit");
   const unsigned logn = log2_strict(n);
   const u32 L = (u32)num_lookups;
@@ -274,8 +284,7 @@ void stage2_from_trace_async(Ctx& ctx, const JitKernel& trace_jit, const u64* d_
   sp.trace = d_trace;
   sp.pre = d_pre;
   sp.n = n;
-  sp.beta = beta;
-  sp.gp = gamma_pows(gamma, MAX_GPOW);
+  sp.ch = ch;
   sp.terms = terms.p;
   sp.rowsum = rowsum.p;
   hipEvent_t ev = ctx.prof_begin(K_STAGE2);
@@ -297,6 +306,10 @@ E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out, const
 }
 
 void claims_accumulator_async(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, E2 beta, E2 gamma, E2* out_dev) {
+  DBuf<ChallengeBG> ch = challenge_bg_upload(ctx, beta, gamma);
+  claims_accumulator_dyn(ctx, d_data, d_offs, n, ch.p, out_dev);
+}
+void claims_accumulator_dyn(Ctx& ctx, const u64* d_data, const u64* d_offs, size_t n, const ChallengeBG* ch, E2* out_dev) {
   if (n == 0) {
     HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(E2), ctx.stream));
     return;
@@ -304,8 +317,7 @@ void claims_accumulator_async(Ctx& ctx, const u64* d_data, const u64* d_offs, si
   size_t per = 256 * CLAIMS_CHUNK;
   size_t nb = (n + per - 1) / per;
   DBuf<E2> partial(ctx, nb);
-  GammaPows gp = gamma_pows(gamma, MAX_GPOW);
-  hipLaunchKernelGGL(claims_acc_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, d_data, d_offs, n, beta, gamma, gp, partial.p);
+  hipLaunchKernelGGL(claims_acc_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, d_data, d_offs, n, ch, partial.p);
   hipLaunchKernelGGL(scan_totals_k, dim3(1), dim3(256), 0, ctx.stream, partial.p, nb, out_dev);  // only the total is used
   HIP_CHECK(hipGetLastError());
 }

@@ -287,6 +287,7 @@ size_t blake3_num_chunks(size_t prefix_len, size_t nwords);
 void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords, size_t c0, size_t c1,
                       Digest* cvs);
 Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks);
+void blake3_from_cvs_async(Ctx& ctx, Digest* cvs, size_t nchunks, Digest* out_dev);  // launches only; digest left on the device
 
 // ---------------------------------------------------------------- lookup.hip
 struct JitKernel;
@@ -302,6 +303,14 @@ E2 stage2_build(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmaj
 // launches only: the contribution is left in *total_dev (device memory)
 void stage2_build_async(Ctx& ctx, const DLookups& lk, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev,
                         const JitKernel* jit = nullptr);
+// the same three with beta / gamma already in device memory (lookup_params.h::ChallengeBG; written by h2d or by the device
+// transcript): the forms the by-value ones wrap
+struct ChallengeBG;
+DBuf<ChallengeBG> challenge_bg_upload(Ctx& ctx, E2 beta, E2 gamma);
+void stage2_build_dyn(Ctx& ctx, const DLookups& lk, const ChallengeBG* ch, u64* out_colmajor_bitrev, E2* total_dev, const JitKernel* jit = nullptr);
+void stage2_from_trace_dyn(Ctx& ctx, const JitKernel& trace_jit, const u64* d_trace, const u64* d_pre, size_t n, size_t num_lookups,
+                           size_t args_width, const ChallengeBG* ch, u64* out_colmajor_bitrev, E2* total_dev);
+void claims_accumulator_dyn(Ctx& ctx, const u64* d_claim_data, const u64* d_claim_offsets, size_t n_claims, const ChallengeBG* ch, E2* out_dev);
 // the same from the row-major trace (and preprocessed trace) with the circuit's fused kernel: no LookupValues needed
 void stage2_from_trace_async(Ctx& ctx, const JitKernel& trace_jit, const u64* d_trace, const u64* d_pre, size_t n, size_t num_lookups,
                              size_t args_width, E2 beta, E2 gamma, u64* out_colmajor_bitrev, E2* total_dev);
@@ -349,13 +358,32 @@ struct DProgram {
   size_t n_zeros = 0, n_lookups = 0, constraint_count = 0;
   size_t main_w = 0, pre_w = 0, s2_w = 0;
 };
+struct QDyn;  // quotient_params.h: the challenge-dependent part of a quotient launch, in device memory
 struct QuotientArgs {
   const u64 *pre = nullptr, *s1 = nullptr, *s2 = nullptr;  // column-major LDEs (bit-reversed rows)
   size_t pre_h = 0, s1_h = 0, s2_h = 0;                    // LDE heights (column strides)
   unsigned log_n = 0, log_q = 0;
-  u64 publics[8];
+  u64 publics[8];   // [beta, gamma, acc_in, acc_out] and alpha when the host knows them ...
   E2 alpha;
+  // ... or the same already in device memory, written by the device transcript (outer.hip): the challenge block and the
+  // reversed alpha powers (constraint_count entries); publics / alpha above are then ignored
+  const QDyn* dyn = nullptr;
+  const E2* alpha_rev = nullptr;
 };
+u64 quotient_inj_norm(unsigned log_n);  // 1 / (n g): the normalisation of the accumulator's injection (src/prover.rs:782-784)
+
+// ---- the outer transcript on the device (outer.hip): beta/gamma, alpha, zeta sampled in the stream; the host replays and checks
+struct OuterTarget {  // where one active circuit's challenge-dependent quotient inputs go
+  QDyn* dyn;
+  E2* alpha_rev;
+  unsigned log_n;
+  size_t k;  // constraint count
+};
+bool outer_fits(size_t ncap, size_t na);  // every transcript piece is a single BLAKE3 chunk
+void outer_beta_gamma(Ctx& ctx, const Digest* d_digest, ChallengeBG* d_bg, u32* d_state12);
+void outer_alpha(Ctx& ctx, const u32* d_state12, const Digest* d_cap, size_t ncap, const E2* d_tot, size_t na, const ChallengeBG* d_bg,
+                 const std::vector<OuterTarget>& targets, E2* d_accs, E2* d_alpha, u32* d_state8, DBuf<uint8_t>& keep);
+void outer_zeta(Ctx& ctx, const u32* d_state8, const Digest* d_cap, size_t ncap, const u32* d_lds, size_t n_ld, E2* d_points);
 // writes quotient values in storage order: out[c * nq + t] for c in {0,1}
 void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* out);
 
@@ -363,6 +391,7 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
 // 1/(z - x_i) for i < H over the bit-reversed coset x_i = 7 w_H^{bitrev(i)}; out: E2[H] (AoS)
 // xout (nullable): x_i / (z - x_i) for i < n_x, the barycentric weights of the trace-domain coset
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);
+void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);  // the point read from device memory
 // opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i].
 // bary_sums_async only launches (raw sums to device memory, index c * np + p); bary_finish applies scale_p on the host.
 void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* xden0, const E2* xden1,

@@ -23,8 +23,10 @@ __device__ __forceinline__ u64 coset_point(const u64* __restrict__ t0, const u64
 constexpr int DEN_CHUNK = 16;
 // out[i] = 1 / (z - x_i) for i < H; xout[i] = x_i / (z - x_i) for i < n_x (the barycentric weights: only the
 // first H / blowup storage rows, i.e. the trace-domain coset, are ever used there)
-__global__ __launch_bounds__(256) void inv_denoms_k(E2 z, unsigned log_h, const u64* __restrict__ t0, const u64* __restrict__ t1,
-                                                    E2* __restrict__ out, E2* __restrict__ xout, size_t n_x) {
+// (zp != nullptr: the point is read from device memory - the device transcript sampled it, outer.hip)
+__global__ __launch_bounds__(256) void inv_denoms_k(E2 zv, const E2* __restrict__ zp, unsigned log_h, const u64* __restrict__ t0,
+                                                    const u64* __restrict__ t1, E2* __restrict__ out, E2* __restrict__ xout, size_t n_x) {
+  const E2 z = zp ? *zp : zv;
   const size_t H = size_t(1) << log_h;
   // element k of this thread is base + k * 256: lanes touch consecutive elements, so every store is coalesced
   const size_t base = blockIdx.x * size_t(256 * DEN_CHUNK) + threadIdx.x;
@@ -647,14 +649,18 @@ __global__ void gather_queries_k(const GatherSeg* __restrict__ segs, const u64* 
 
 }  // namespace
 
-void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x) {
+static void inv_denoms_launch(Ctx& ctx, E2 z, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x) {
   if (log_h > TW_LOG) throw std::runtime_error("LDE height above 2^28 is not supported");
   size_t H = size_t(1) << log_h;
   if (n_x > H) throw std::runtime_error("inv_denoms: weight vector longer than the domain");
   size_t blocks = (H + 256 * DEN_CHUNK - 1) / (256 * DEN_CHUNK);
-  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)blocks), dim3(256), 0, ctx.stream, z, log_h, ctx.tw0, ctx.tw1, out,
-                     xout, xout ? n_x : size_t(0));
+  hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)blocks), dim3(256), 0, ctx.stream, z, z_dev, log_h, ctx.tw0, ctx.tw1, out, xout,
+                     xout ? n_x : size_t(0));
   HIP_CHECK(hipGetLastError());
+}
+void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x) { inv_denoms_launch(ctx, z, nullptr, log_h, out, xout, n_x); }
+void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x) {
+  inv_denoms_launch(ctx, e2(0), z_dev, log_h, out, xout, n_x);
 }
 
 // launches only: raw sums sum_{i<h} col_c[i] x_i invden_p[i] into `out_dev` (w * npoints values, index c * np + p)

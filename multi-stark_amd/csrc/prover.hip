@@ -20,6 +20,8 @@
 #include <thread>
 
 #include "host.h"
+#include "lookup_params.h"
+#include "quotient_params.h"
 
 namespace msamd {
 
@@ -974,6 +976,18 @@ struct OpenRound {
 
 bool e2_same(E2 a, E2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
 
+// Opening points that only the DEVICE knows while the opening's first kernels are queued (the device transcript sampled
+// zeta, outer.hip): a point is named by a placeholder (sym_point(id): c1 is not a canonical field element, so it never equals
+// a real point), its value lies at d_points[id], and `resolve` - called right after the opened-value read-back, the first
+// moment the host needs the values - returns every value; pcs_open then swaps the placeholders for them.
+struct SymbolicPoints {
+  const E2* d_points = nullptr;
+  size_t n = 0;
+  std::function<void(std::vector<E2>& values)> resolve;
+};
+inline E2 sym_point(size_t id) { return e2((u64)id, ~u64(0)); }
+inline bool is_sym_point(E2 z) { return z.c1 == ~u64(0); }
+
 // MSAMD_TRACE=1: synchronise and print the wall time of each phase of the opening (diagnostics only)
 struct PhaseTrace {
   Ctx& ctx;
@@ -1045,7 +1059,8 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
                const FriHead* head = nullptr, DTree* round0 = nullptr);
 
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
-void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes) {
+void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes,
+              const SymbolicPoints* sym = nullptr) {
   Ctx& ctx = *sys.ctx;
   const Params& prm = sys.params;
   const unsigned lb = (unsigned)prm.log_blowup;
@@ -1097,7 +1112,12 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       SideScope sc(ctx, pass == 1);
       dens[k] = DBuf<E2>(ctx, uh[k]);
       xdens[k] = DBuf<E2>(ctx, uh[k] >> lb);  // weights of the trace-domain coset: a prefix in bit-reversed storage
-      inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p, xdens[k].p, uh[k] >> lb);
+      if (is_sym_point(upts[k])) {
+        if (!sym || upts[k].c0 >= sym->n) throw std::runtime_error("pcs_open: symbolic opening point without a device value");
+        inv_denoms_dev(ctx, sym->d_points + upts[k].c0, log2_strict(uh[k]), dens[k].p, xdens[k].p, uh[k] >> lb);
+      } else {
+        inv_denoms(ctx, upts[k], log2_strict(uh[k]), dens[k].p, xdens[k].p, uh[k] >> lb);
+      }
     }
   }
 
@@ -1133,6 +1153,17 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   g_probes.mark("opened values queued");
   ctx.d2h(h_sums.data(), d_sums.p, total_vals * sizeof(E2));
   g_probes.mark("sync 4 (opened values)");
+  if (sym) {  // the host learns the points now (and replays the transcript that produced them)
+    std::vector<E2> values(sym->n);
+    sym->resolve(values);
+    auto swap_in = [&](E2& z) {
+      if (is_sym_point(z)) z = values[z.c0];
+    };
+    for (auto& z : upts) swap_in(z);
+    for (auto& r : rounds)
+      for (auto& pts : r.points)
+        for (auto& z : pts) swap_in(z);
+  }
   {
     size_t off = 0;
     for (auto& r : rounds) {
@@ -1616,16 +1647,21 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
 }
 }  // namespace
 
-void stage2_circuit_async(Ctx& ctx, const HSystem& sys, const HWitness& wit, size_t ci, E2 beta, E2 gamma, u64* out, E2* total_dev) {
+// beta / gamma in device memory (uploaded by the host or sampled there by outer.hip)
+void stage2_circuit_dyn(Ctx& ctx, const HSystem& sys, const HWitness& wit, size_t ci, const ChallengeBG* bg, u64* out, E2* total_dev) {
   const HCircuit& c = sys.circuits[ci];
   const DLookups& lk = wit.lookups[ci];
   if (c.num_lookups && !lk.mult.p) {  // no LookupValues were materialised for this circuit: evaluate them in the kernel
     if (!c.stage2_trace_jit.function || !wit.traces[ci].p) throw std::runtime_error("stage 2: this circuit has neither lookup values nor a fused kernel");
-    stage2_from_trace_async(ctx, c.stage2_trace_jit, wit.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, wit.heights[ci], c.num_lookups,
-                            c.args_width, beta, gamma, out, total_dev);
+    stage2_from_trace_dyn(ctx, c.stage2_trace_jit, wit.traces[ci].p, c.pre_width ? c.d_preprocessed.p : nullptr, wit.heights[ci], c.num_lookups,
+                          c.args_width, bg, out, total_dev);
     return;
   }
-  stage2_build_async(ctx, lk, beta, gamma, out, total_dev, &c.stage2_jit);
+  stage2_build_dyn(ctx, lk, bg, out, total_dev, &c.stage2_jit);
+}
+void stage2_circuit_async(Ctx& ctx, const HSystem& sys, const HWitness& wit, size_t ci, E2 beta, E2 gamma, u64* out, E2* total_dev) {
+  DBuf<ChallengeBG> bg = challenge_bg_upload(ctx, beta, gamma);
+  stage2_circuit_dyn(ctx, sys, wit, ci, bg.p, out, total_dev);
 }
 
 // claims, length-prefixed (src/prover.rs:369-373), absorbed into `ch`. Large claim sets are hashed on the device: the
@@ -1742,6 +1778,23 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   size_t cap_off = 0, prefix_chunks = 0, nchunks = 0;
   DBuf<u64> d_words;
   DBuf<Digest> d_cvs;
+  // The outer transcript on the device (outer.hip): with the claims digest already computed there, beta/gamma, alpha and
+  // zeta are sampled in the stream and every launch up to the opened-value sums is queued without a host round trip; the
+  // host challenger replays the steps when the commitments arrive with the opened values, and is the authority.
+  const bool dev_outer = device_claims && outer_fits(ncap, NA) && !getenv("MSAMD_HOST_TRANSCRIPT");
+  struct OuterDev {
+    DBuf<Digest> digest;
+    DBuf<u32> state;  // 12 words behind gamma, 8 words behind alpha
+    DBuf<E2> accs, alpha, points;
+    DBuf<u32> lds;
+    DBuf<uint8_t> circuits;
+    std::vector<DBuf<uint8_t>> qdyn;  // per active circuit: QDyn, then the reversed alpha powers
+    Digest h_digest;
+    E2 h_bg[2], h_alpha;
+    std::vector<E2> h_points;
+    std::vector<unsigned> uniq_ld;  // the distinct trace heights: points[1 + k] = zeta * g(2^uniq_ld[k])
+  } od;
+  DBuf<ChallengeBG> d_bg;
   if (device_claims) {
     s1_cap.assign(ncap, Digest());
     if (sys.has_pre) ch.observe_cap(sys.pre_commit);
@@ -1807,23 +1860,41 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     ctx.side_join();
     blake3_chunk_cvs(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, 0, prefix_chunks, d_cvs.p);
     ctx.d2h_queue(s1_cap.data(), d_cap, ncap * sizeof(Digest));
-    Digest d = blake3_from_cvs(ctx, d_cvs.p, nchunks);  // synchronises: s1_cap has arrived too
-    g_probes.mark("sync 1 (cap + claims digest)");
-    ch.flush_with(d);
+    if (dev_outer) {
+      od.digest = DBuf<Digest>(ctx, 1);
+      od.state = DBuf<u32>(ctx, 20);
+      d_bg = DBuf<ChallengeBG>(ctx, 1);
+      blake3_from_cvs_async(ctx, d_cvs.p, nchunks, od.digest.p);
+      outer_beta_gamma(ctx, od.digest.p, d_bg.p, od.state.p);
+      ctx.d2h_queue(&od.h_digest, od.digest.p, sizeof(Digest));
+      ctx.d2h_queue(od.h_bg, d_bg.p, 2 * sizeof(E2));  // beta, gamma lead the block
+      g_probes.mark("claims digest + beta/gamma queued");
+    } else {
+      Digest d = blake3_from_cvs(ctx, d_cvs.p, nchunks);  // synchronises: s1_cap has arrived too
+      g_probes.mark("sync 1 (cap + claims digest)");
+      ch.flush_with(d);
+    }
     d_words.reset();
     d_cvs.reset();
   }
-  const E2 beta = ch.sample_ext();
-  ch.observe_ext(beta);
-  const E2 gamma = ch.sample_ext();
-  ch.observe_ext(gamma);
+  E2 beta = e2(0), gamma = e2(0), alpha = e2(0), zeta = e2(0);
+  auto tx_beta_gamma = [&]() {
+    beta = ch.sample_ext();
+    ch.observe_ext(beta);
+    gamma = ch.sample_ext();
+    ch.observe_ext(gamma);
+  };
+  if (!dev_outer) {
+    tx_beta_gamma();
+    d_bg = challenge_bg_upload(ctx, beta, gamma);
+  }
   // initial accumulator from the claims (src/prover.rs:382-387). Nothing below needs the accumulators on the
   // host until they are observed after the stage-2 commitment, so the claims sum and every circuit's contribution
   // stay in device memory (d_tot[0] = claims, d_tot[1 + pos] = circuit) and come back with that commitment.
   DBuf<E2> d_tot(ctx, NA + 1);
   std::vector<E2> h_tot(NA + 1);
-  if (n_claims > 256) {
-    claims_accumulator_async(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, beta, gamma, d_tot.p);
+  if (n_claims > 256 || dev_outer) {
+    claims_accumulator_dyn(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, d_bg.p, d_tot.p);
   } else {
     E2 acc0 = e2(0);
     for (size_t i = 0; i < n_claims; i++) {
@@ -1846,7 +1917,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     size_t n = wit.heights[ci];
     SideScope sc(ctx, on_side[pos]);
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
-    stage2_circuit_async(ctx, sys, wit, ci, beta, gamma, s2_evals[pos].p, d_tot.p + 1 + pos);
+    stage2_circuit_dyn(ctx, sys, wit, ci, d_bg.p, s2_evals[pos].p, d_tot.p + 1 + pos);
   }
   lap(1);
   t0 = now_ms();
@@ -1872,21 +1943,52 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   }
   ctx.d2h_queue(h_tot.data(), d_tot.p, (NA + 1) * sizeof(E2));
   g_probes.mark("stage 2 queued");
-  std::vector<Digest> s2_cap = merkle_cap(ctx, s2.tree);  // synchronises: h_tot is complete as well
-  g_probes.mark("sync 2 (stage-2 cap)");
-  const E2 acc_initial = h_tot[0];
+  auto dev_cap = [&](const DTree& t) -> const Digest* {
+    const size_t cl = t.cap_layer();
+    if (t.layer_len[cl] != ncap) throw std::runtime_error("a commitment's cap size differs from the stage-1 cap");
+    return t.base() + t.layer_off[cl];
+  };
+  std::vector<Digest> s2_cap, q_cap;
+  E2 acc_initial = e2(0);
   std::vector<E2> accs;
-  {
+  auto tx_alpha = [&]() {  // src/prover.rs:382-433
+    acc_initial = h_tot[0];
+    accs.clear();
     E2 acc = acc_initial;
     for (size_t pos = 0; pos < NA; pos++) {
       acc = e2_add(acc, h_tot[1 + pos]);
       accs.push_back(acc);
     }
+    ch.observe_cap(s2_cap);
+    for (auto& a : accs) ch.observe_ext(a);
+    alpha = ch.sample_ext();
+  };
+  if (dev_outer) {
+    s2_cap.assign(ncap, Digest());
+    accs.assign(NA, e2(0));
+    const Digest* d_cap = dev_cap(s2.tree);
+    ctx.d2h_queue(s2_cap.data(), d_cap, ncap * sizeof(Digest));
+    od.accs = DBuf<E2>(ctx, NA + 1);
+    od.alpha = DBuf<E2>(ctx, 1);
+    od.qdyn.resize(NA);
+    std::vector<OuterTarget> targets(NA);
+    for (size_t pos = 0; pos < NA; pos++) {
+      const size_t k = sys.circuits[aidx[pos]].prog.constraint_count;
+      od.qdyn[pos] = DBuf<uint8_t>(ctx, sizeof(QDyn) + std::max<size_t>(k, 1) * sizeof(E2));
+      targets[pos].dyn = reinterpret_cast<QDyn*>(od.qdyn[pos].p);
+      targets[pos].alpha_rev = reinterpret_cast<E2*>(od.qdyn[pos].p + sizeof(QDyn));
+      targets[pos].log_n = log_degrees[pos];
+      targets[pos].k = k;
+    }
+    outer_alpha(ctx, od.state.p, d_cap, ncap, d_tot.p, NA, d_bg.p, targets, od.accs.p, od.alpha.p, od.state.p + 12, od.circuits);
+    ctx.d2h_queue(&od.h_alpha, od.alpha.p, sizeof(E2));
+    lap(2);
+  } else {
+    s2_cap = merkle_cap(ctx, s2.tree);  // synchronises: h_tot is complete as well
+    g_probes.mark("sync 2 (stage-2 cap)");
+    lap(2);
+    tx_alpha();
   }
-  lap(2);
-  ch.observe_cap(s2_cap);
-  for (auto& a : accs) ch.observe_ext(a);
-  const E2 alpha = ch.sample_ext();
 
   // ---- quotient (src/prover.rs:437-528)
   t0 = now_ms();
@@ -1899,7 +2001,6 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
       size_t ci = aidx[pos];
       const HCircuit& c = sys.circuits[ci];
       SideScope sc(ctx, on_side[pos]);
-      const E2 acc_in = pos ? accs[pos - 1] : acc_initial;
       unsigned log_n = log_degrees[pos], log_q = log2_strict(c.quotient_degree());
       size_t n = size_t(1) << log_n, nq = n << log_q;
       QuotientArgs qa;
@@ -1914,12 +2015,17 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
       qa.s2_h = s2.ldes[pos].h;
       qa.log_n = log_n;
       qa.log_q = log_q;
-      const E2 four[4] = {beta, gamma, acc_in, accs[pos]};
-      for (int k = 0; k < 4; k++) {
-        qa.publics[2 * k] = four[k].c0;
-        qa.publics[2 * k + 1] = four[k].c1;
+      if (dev_outer) {
+        qa.dyn = reinterpret_cast<const QDyn*>(od.qdyn[pos].p);
+        qa.alpha_rev = reinterpret_cast<const E2*>(od.qdyn[pos].p + sizeof(QDyn));
+      } else {
+        const E2 four[4] = {beta, gamma, pos ? accs[pos - 1] : acc_initial, accs[pos]};
+        for (int k = 0; k < 4; k++) {
+          qa.publics[2 * k] = four[k].c0;
+          qa.publics[2 * k + 1] = four[k].c1;
+        }
+        qa.alpha = alpha;
       }
-      qa.alpha = alpha;
       DBuf<u64> qv(ctx, nq * 2);
       quotient_eval(ctx, c.prog, qa, qv.p);
       DMat lde;
@@ -1933,24 +2039,58 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     commit_matrices(ctx, std::move(qldes), (unsigned)prm.cap_height, qd);
   }
   g_probes.mark("quotient queued");
-  std::vector<Digest> q_cap = merkle_cap(ctx, qd.tree);
-  g_probes.mark("sync 3 (quotient cap)");
-  ch.observe_cap(q_cap);
-  lap(3);
-
-  // ---- opening (src/prover.rs:538-581)
-  t0 = now_ms();
-  phase.next("stark/fri_open");
-  const E2 zeta = ch.sample_ext();
+  auto tx_zeta = [&]() {
+    ch.observe_cap(q_cap);
+    zeta = ch.sample_ext();
+  };
+  // zeta and zeta * g per trace height: values in host mode, placeholders for device values otherwise (pcs_open swaps them)
+  E2 pt_zeta = e2(0);
+  std::vector<E2> pt_next(NA);
+  SymbolicPoints sym;
+  if (dev_outer) {
+    q_cap.assign(ncap, Digest());
+    const Digest* d_cap = dev_cap(qd.tree);
+    ctx.d2h_queue(q_cap.data(), d_cap, ncap * sizeof(Digest));
+    std::vector<size_t> id_of(NA);
+    for (size_t pos = 0; pos < NA; pos++) {
+      size_t k = 0;
+      while (k < od.uniq_ld.size() && od.uniq_ld[k] != log_degrees[pos]) k++;
+      if (k == od.uniq_ld.size()) od.uniq_ld.push_back(log_degrees[pos]);
+      id_of[pos] = 1 + k;
+    }
+    const size_t n_ld = od.uniq_ld.size();
+    od.lds = DBuf<u32>(ctx, n_ld);
+    ctx.h2d(od.lds.p, od.uniq_ld.data(), n_ld * sizeof(u32));
+    od.points = DBuf<E2>(ctx, 1 + n_ld);
+    od.h_points.assign(1 + n_ld, e2(0));
+    outer_zeta(ctx, od.state.p + 12, d_cap, ncap, od.lds.p, n_ld, od.points.p);
+    ctx.d2h_queue(od.h_points.data(), od.points.p, (1 + n_ld) * sizeof(E2));
+    pt_zeta = sym_point(0);
+    for (size_t pos = 0; pos < NA; pos++) pt_next[pos] = sym_point(id_of[pos]);
+    sym.d_points = od.points.p;
+    sym.n = 1 + n_ld;
+    lap(3);
+    t0 = now_ms();
+    phase.next("stark/fri_open");
+  } else {
+    q_cap = merkle_cap(ctx, qd.tree);
+    g_probes.mark("sync 3 (quotient cap)");
+    lap(3);
+    // ---- opening (src/prover.rs:538-581)
+    t0 = now_ms();
+    phase.next("stark/fri_open");
+    tx_zeta();
+    pt_zeta = zeta;
+    for (size_t pos = 0; pos < NA; pos++) pt_next[pos] = e2_mul_base(zeta, gl_two_adic_generator(log_degrees[pos]));
+  }
   std::vector<OpenRound> rounds(3);
   rounds[0].data = &s1;
   rounds[1].data = &s2;
   rounds[2].data = &qd;
-  for (unsigned ld : log_degrees) {
-    E2 zn = e2_mul_base(zeta, gl_two_adic_generator(ld));
-    rounds[0].points.push_back({zeta, zn});
-    rounds[1].points.push_back({zeta, zn});
-    rounds[2].points.push_back({zeta});
+  for (size_t pos = 0; pos < NA; pos++) {
+    rounds[0].points.push_back({pt_zeta, pt_next[pos]});
+    rounds[1].points.push_back({pt_zeta, pt_next[pos]});
+    rounds[2].points.push_back({pt_zeta});
   }
   if (sys.has_pre) {
     OpenRound r0;
@@ -1958,8 +2098,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     for (size_t ci = 0; ci < C; ci++) {
       if (sys.pre_indices[ci] < 0) continue;
       if (apos[ci] >= 0) {
-        E2 zn = e2_mul_base(zeta, gl_two_adic_generator(log_degrees[apos[ci]]));
-        r0.points.push_back({zeta, zn});
+        r0.points.push_back({pt_zeta, pt_next[apos[ci]]});
       } else {
         r0.points.push_back({});
       }
@@ -1977,17 +2116,40 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     w.b.reserve(16 * vals + 64 * (NA + 8) + 32 * (s1_cap.size() + s2_cap.size() + q_cap.size()) + 8192);
   }
-  w.u64_(C);
-  for (auto a : active) w.u8(a);
-  w.cap(s1_cap);
-  w.cap(s2_cap);
-  w.cap(q_cap);
-  w.u64_(accs.size());
-  for (auto& a : accs) w.ext(a);
-  w.u64_(log_degrees.size());
-  for (unsigned ld : log_degrees) w.u8((uint8_t)ld);
+  auto write_header = [&](PW& h) {
+    h.u64_(C);
+    for (auto a : active) h.u8(a);
+    h.cap(s1_cap);
+    h.cap(s2_cap);
+    h.cap(q_cap);
+    h.u64_(accs.size());
+    for (auto& a : accs) h.ext(a);
+    h.u64_(log_degrees.size());
+    for (unsigned ld : log_degrees) h.u8((uint8_t)ld);
+  };
+  write_header(w);  // device transcript: same length, contents still on their way - rewritten in `resolve`
+  const size_t header_len = w.b.size();
+  sym.resolve = [&](std::vector<E2>& values) {
+    // everything queued since the stage-1 commitment has arrived: replay the transcript on the host and compare
+    ch.flush_with(od.h_digest);
+    tx_beta_gamma();
+    tx_alpha();
+    tx_zeta();
+    bool same = e2_same(beta, od.h_bg[0]) && e2_same(gamma, od.h_bg[1]) && e2_same(alpha, od.h_alpha) && e2_same(zeta, od.h_points[0]);
+    values[0] = zeta;
+    for (size_t k = 0; k < od.uniq_ld.size(); k++) {
+      values[1 + k] = e2_mul_base(zeta, gl_two_adic_generator(od.uniq_ld[k]));
+      same = same && e2_same(values[1 + k], od.h_points[1 + k]);
+    }
+    if (!same) throw std::runtime_error("the device transcript's challenges differ from the host challenger's");
+    PW h;
+    write_header(h);
+    if (h.b.size() != header_len) throw std::runtime_error("proof header changed length");
+    memcpy(w.b.data(), h.b.data(), header_len);
+    g_probes.mark("transcript replayed");
+  };
   std::vector<OpenedRound> opened;
-  pcs_open(sys, rounds, ch, opened, w);
+  pcs_open(sys, rounds, ch, opened, w, dev_outer ? &sym : nullptr);
   lap(4);
   write_round(w, opened[2]);
   w.u8(sys.has_pre ? 1 : 0);

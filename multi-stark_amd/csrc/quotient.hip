@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
           v = p.s2[size_t(ins.w) * p.s2_h + row];
         break;
       }
-      case OP_PUBLIC: v = p.publics[ins.z]; break;
+      case OP_PUBLIC: v = p.dyn->publics[ins.z]; break;
       case OP_IS_FIRST: v = is_first; break;
       case OP_IS_LAST: v = is_last; break;
       case OP_IS_TRANS: v = is_trans; break;
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
     acc_mad(fa0, cv, a.c0);
     acc_mad(fa1, cv, a.c1);
   }
-  const u64 beta0 = p.publics[0], beta1 = p.publics[1], gamma0 = p.publics[2], gamma1 = p.publics[3];
-  const u64 inj0 = gl_mul(is_last, p.delta_scaled[0]), inj1 = gl_mul(is_last, p.delta_scaled[1]);
+  const u64 beta0 = p.dyn->publics[0], beta1 = p.dyn->publics[1], gamma0 = p.dyn->publics[2], gamma1 = p.dyn->publics[3];
+  const u64 inj0 = gl_mul(is_last, p.dyn->delta_scaled[0]), inj1 = gl_mul(is_last, p.dyn->delta_scaled[1]);
   auto fold2 = [&](u64 c0, u64 c1) {
     E2 a = p.alpha_rev[ci], b = p.alpha_rev[ci + 1];
     acc_mad(fa0, c0, a.c0);
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void quotient_k(QParams p) {
         acc_init(g1);
         for (u32 k = 0; k < na; k++) {
           const u64 v = slots[ls[2 + k] * stride];
-          acc_mad(g0, v, p.gpow[k].c0);
-          acc_mad(g1, v, p.gpow[k].c1);
+          acc_mad(g0, v, p.dyn->gpow[k].c0);
+          acc_mad(g1, v, p.dyn->gpow[k].c1);
         }
         f0 = acc_reduce(g0);
         f1 = acc_reduce(g1);
@@ -342,6 +342,10 @@ bool lookup_values_device(Ctx& ctx, const DProgram& prefix, const u64* d_trace, 
   return true;
 }
 
+u64 quotient_inj_norm(unsigned log_n) {  // 1 / (n g), src/prover.rs:782-784
+  return gl_inv(gl_mul((u64)(size_t(1) << log_n) % GL_P, gl_two_adic_generator(log_n)));
+}
+
 void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* out) {
   const unsigned lognq = a.log_n + a.log_q;
   if (lognq > 26) throw std::runtime_error("quotient domain larger than 2^26 is not supported");
@@ -355,22 +359,27 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
     xx = gl_mul(xx, wq);
   }
   const size_t k = prog.constraint_count;
-  std::vector<E2> arev(k);
-  E2 ap = e2(1);
-  for (size_t i = 0; i < k; i++) {
-    arev[k - 1 - i] = ap;
-    ap = e2_mul(ap, a.alpha);
-  }
-  // the per-circuit kernels read these small tables from their argument block; the interpreter from device memory
-  const bool inl = prog.jit.function && prog.jit.inline_tables && q <= 8 && k <= QP_INLINE_ALPHA;
+  const bool inl = prog.jit.function && prog.jit.inline_tables && q <= 8 && k <= QP_INLINE_ALPHA;  // Z_H tables in the argument block
   DBuf<u64> dzh;
-  DBuf<E2> darev;
   if (!inl) {
     dzh = DBuf<u64>(ctx, 2 * q);
-    darev = DBuf<E2>(ctx, std::max<size_t>(k, 1));
     ctx.h2d(dzh.p, zh.data(), q * 8);
     ctx.h2d(dzh.p + q, zhi.data(), q * 8);
-    ctx.h2d(darev.p, arev.data(), k * sizeof(E2));
+  }
+  const u64 g = gl_two_adic_generator(a.log_n);
+  // the challenge-dependent block: given by the caller in device memory (device transcript), or built here from the values
+  DBuf<uint8_t> dyn_buf;
+  const QDyn* dyn = a.dyn;
+  const E2* alpha_rev = a.alpha_rev;
+  if (!dyn) {
+    std::vector<uint8_t> host(sizeof(QDyn) + std::max<size_t>(k, 1) * sizeof(E2));
+    QDyn* d = reinterpret_cast<QDyn*>(host.data());
+    E2* arev = reinterpret_cast<E2*>(host.data() + sizeof(QDyn));
+    quotient_dyn_fill(*d, arev, k, a.publics, a.alpha, quotient_inj_norm(a.log_n));
+    dyn_buf = DBuf<uint8_t>(ctx, host.size());
+    ctx.h2d(dyn_buf.p, host.data(), host.size());
+    dyn = reinterpret_cast<const QDyn*>(dyn_buf.p);
+    alpha_rev = reinterpret_cast<const E2*>(dyn_buf.p + sizeof(QDyn));
   }
 
   QParams p;
@@ -382,24 +391,18 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
   p.s2_h = a.s2_h;
   p.log_n = a.log_n;
   p.log_q = a.log_q;
-  memcpy(p.publics, a.publics, sizeof(p.publics));
-  u64 g = gl_two_adic_generator(a.log_n);
-  u64 inj_norm = gl_inv(gl_mul((u64)n % GL_P, g));  // src/prover.rs:782-784
-  p.delta_scaled[0] = gl_mul(gl_sub(a.publics[6], a.publics[4]), inj_norm);
-  p.delta_scaled[1] = gl_mul(gl_sub(a.publics[7], a.publics[5]), inj_norm);
+  p.dyn = dyn;
   p.g_inv = gl_inv(g);
   p.zh = dzh.p;
   p.zh_inv = dzh.p ? dzh.p + q : nullptr;
-  p.alpha_rev = darev.p;
+  p.alpha_rev = alpha_rev;
   memset(p.zh_in, 0, sizeof(p.zh_in));
   memset(p.zh_inv_in, 0, sizeof(p.zh_inv_in));
-  memset(p.alpha_rev_in, 0, sizeof(p.alpha_rev_in));
   if (inl) {
     for (size_t j = 0; j < 8; j++) {  // period q: any lane index masked with 7 lands on the right entry
       p.zh_in[j] = zh[j % q];
       p.zh_inv_in[j] = zhi[j % q];
     }
-    for (size_t i = 0; i < k; i++) p.alpha_rev_in[i] = arev[i];
   }
   p.code = prog.code.p;
   p.consts = prog.consts.p;
@@ -413,13 +416,6 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
   p.t1 = ctx.tw1;
   p.out = out;
   p.scratch = nullptr;
-  {
-    E2 g = e2(1), gam = e2(a.publics[2], a.publics[3]);
-    for (int i = 0; i < 32; i++) {
-      p.gpow[i] = g;
-      g = e2_mul(g, gam);
-    }
-  }
 
   const double bytes = double(nq) * 8.0 * (2.0 * (prog.main_w + prog.s2_w + prog.pre_w) + 2.0);
   unsigned threads = 256;

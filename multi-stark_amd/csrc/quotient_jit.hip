@@ -34,7 +34,8 @@ bool inline_tables_fit(size_t n_zeros, size_t n_lookups, size_t quotient_degree)
 std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<uint32_t>& zeros,
                            const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups, bool inl) {
   const size_t nn = nodes.size();
-  const char* AR = inl ? "p.alpha_rev_in" : "p.alpha_rev";
+  const char* AR = "p.alpha_rev";  // device memory: the challenges never travel in the argument block
+  (void)inl;
   std::vector<char> needed(nn, 0);
   for (auto z : zeros) needed[z] = 1;
   for (auto& l : lookups) {
@@ -78,7 +79,7 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
         o << "p." << src << "[size_t(" << n.a << ") * p." << src << "_h + " << (n.offset ? "tn" : "t") << "]";
         break;
       }
-      case OP_PUBLIC: o << "p.publics[" << n.a << "]"; break;
+      case OP_PUBLIC: o << "p.dyn->publics[" << n.a << "]"; break;
       case OP_IS_FIRST: o << "is_first"; break;
       case OP_IS_LAST: o << "is_last"; break;
       case OP_IS_TRANS: o << "is_trans"; break;
@@ -95,8 +96,8 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
     o << "  { const E2 a = " << AR << "[" << ci << "]; accs_mad(fa0, v" << z << ", a.c0); accs_mad(fa1, v" << z << ", a.c1); }\n";
     ci++;
   }
-  o << "  const u64 beta0 = p.publics[0], beta1 = p.publics[1];\n"
-       "  const u64 inj0 = gl_mul(is_last, p.delta_scaled[0]), inj1 = gl_mul(is_last, p.delta_scaled[1]);\n"
+  o << "  const u64 beta0 = p.dyn->publics[0], beta1 = p.dyn->publics[1];\n"
+       "  const u64 inj0 = gl_mul(is_last, p.dyn->delta_scaled[0]), inj1 = gl_mul(is_last, p.dyn->delta_scaled[1]);\n"
        "  (void)beta0; (void)beta1;\n";
   auto fold2 = [&](const std::string& c0, const std::string& c1) {
     o << "  { const E2 a = " << AR << "[" << ci << "], b = " << AR << "[" << ci + 1 << "];\n"
@@ -124,13 +125,13 @@ std::string circuit_source(const std::vector<PNode>& nodes, const std::vector<ui
       if (na <= 32) {
         o << "    GlAcc g0, g1;\n    acc_init(g0);\n    acc_init(g1);\n";
         for (size_t k = 0; k < na; k++)
-          o << "    acc_mad(g0, v" << l.second[k] << ", p.gpow[" << k << "].c0); acc_mad(g1, v" << l.second[k] << ", p.gpow[" << k
+          o << "    acc_mad(g0, v" << l.second[k] << ", p.dyn->gpow[" << k << "].c0); acc_mad(g1, v" << l.second[k] << ", p.dyn->gpow[" << k
             << "].c1);\n";
         o << "    f0_" << j << " = acc_reduce(g0);\n    f1_" << j << " = acc_reduce(g1);\n";
       } else {
         o << "    u64 h0 = 0, h1 = 0, g0, g1;\n";
         for (size_t k = na; k-- > 0;)
-          o << "    mul2(h0, h1, p.publics[2], p.publics[3], g0, g1); h0 = gl_add(g0, v" << l.second[k] << "); h1 = g1;\n";
+          o << "    mul2(h0, h1, p.dyn->publics[2], p.dyn->publics[3], g0, g1); h0 = gl_add(g0, v" << l.second[k] << "); h1 = g1;\n";
         o << "    f0_" << j << " = h0;\n    f1_" << j << " = h1;\n";
       }
       o << "  }\n  u64 c0_" << j << ", c1_" << j << ";\n"
@@ -456,8 +457,8 @@ std::string stage2_source(const std::vector<uint32_t>& counts) {
       const size_t j = j0 + t;
       o << "    { GlAcc g0, g1; acc_init(g0); acc_init(g1);\n";
       for (size_t k = 0; k < counts[j]; k++)
-        o << "      acc_mad(g0, a" << offs[j] + k << ", p.gp.g[" << k << "].c0); acc_mad(g1, a" << offs[j] + k << ", p.gp.g[" << k << "].c1);\n";
-      o << "      msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.beta.c0), gl_add(acc_reduce(g1), p.beta.c1)); }\n";
+        o << "      acc_mad(g0, a" << offs[j] + k << ", p.ch->gp.g[" << k << "].c0); acc_mad(g1, a" << offs[j] + k << ", p.ch->gp.g[" << k << "].c1);\n";
+      o << "      msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.ch->beta.c0), gl_add(acc_reduce(g1), p.ch->beta.c1)); }\n";
     }
     o << "    e2_batch_inverse<16>(msg, " << cnt << ");\n";
     for (size_t t = 0; t < cnt; t++) {
@@ -545,8 +546,8 @@ std::string stage2_trace_source(const std::vector<PNode>& nodes, const std::vect
       const auto& l = lookups[j0 + t];
       o << "    { GlAcc g0, g1; acc_init(g0); acc_init(g1);\n";
       for (size_t k = 0; k < l.second.size(); k++)
-        o << "      acc_mad(g0, v" << l.second[k] << ", p.gp.g[" << k << "].c0); acc_mad(g1, v" << l.second[k] << ", p.gp.g[" << k << "].c1);\n";
-      o << "      msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.beta.c0), gl_add(acc_reduce(g1), p.beta.c1)); }\n";
+        o << "      acc_mad(g0, v" << l.second[k] << ", p.ch->gp.g[" << k << "].c0); acc_mad(g1, v" << l.second[k] << ", p.ch->gp.g[" << k << "].c1);\n";
+      o << "      msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.ch->beta.c0), gl_add(acc_reduce(g1), p.ch->beta.c1)); }\n";
     }
     o << "    e2_batch_inverse<16>(msg, " << cnt << ");\n";
     for (size_t t = 0; t < cnt; t++) {

@@ -408,7 +408,8 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
 # host-side query step, no single-workgroup FRI tail, host sweep for the lookup values, interpreter kernels instead of
 # the hiprtc-compiled ones (the library reads these variables at call time)
 @pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE",
-                                 "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC", "MSAMD_NO_SIDE_STREAM", "MSAMD_OLD_TRANSPOSE", "MSAMD_GENERIC_LEAF_HASH", "MSAMD_NO_DEEP_LEAVES"])
+                                 "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC", "MSAMD_NO_SIDE_STREAM", "MSAMD_OLD_TRANSPOSE", "MSAMD_GENERIC_LEAF_HASH", "MSAMD_NO_DEEP_LEAVES",
+                                 "MSAMD_HOST_TRANSCRIPT"])
 def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     import os
 
@@ -426,6 +427,53 @@ def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     finally:
         del os.environ[var]
     assert got == want
+
+
+# The outer transcript on the device (csrc/outer.hip): with more than 8192 claim words the claims digest is computed on the
+# device and beta/gamma, alpha, zeta are sampled there; the host challenger replays and checks. Shapes that exercise every
+# piece: several circuits of one height (one next-row point for all of them), a preprocessed commitment (a fourth opening
+# round on symbolic points), a Merkle cap of several digests inside the hashed pieces, few long claims (the claims sum on the
+# device with fewer than 256 claims). Each is compared with the oracle and with the host-transcript path, and the probe log
+# must show that the device path actually ran.
+@pytest.mark.parametrize("case", ["multi_air", "preprocessed", "cap4", "long_claims"])
+def test_device_transcript(pkg, ctx, oracle, fe, case, monkeypatch, capfd):
+    import numpy as np
+
+    if case == "multi_air":
+        inputs, params = fe.multi_u32_add_system_inputs(8), fe.bench_params()
+        traces, claims = fe.multi_u32_add_witness(8, 1 << 11)
+    elif case == "preprocessed":
+        rng = np.random.default_rng(5)
+        calls = [(int(rng.integers(0, 4)), int(rng.integers(0, 256)), int(rng.integers(0, 256))) for _ in range(3000)]
+        inputs, params = fe.byte_operations_inputs(), fe.test_params()
+        traces, claims = fe.byte_operations_witness(calls)
+    elif case == "cap4":
+        inputs = fe.u32_add_system_inputs()
+        params = fe.Params(log_blowup=2, cap_height=2, log_final_poly_len=2, num_queries=20, commit_proof_of_work_bits=3, query_proof_of_work_bits=5)
+        traces, claims = fe.u32_add_bench_witness(1 << 12)
+    else:
+        # four claims of 3000 words on top of a balanced system: no circuit pushes them, so the verifier rejects the proof,
+        # but the prover does not check the balance - the bytes are compared with the oracle's without a verdict
+        inputs, params = fe.u32_add_system_inputs(), fe.test_params()
+        traces, claims = fe.u32_add_bench_witness(1 << 6)
+        rng = np.random.default_rng(9)
+        claims = list(claims) + [[int(v) for v in rng.integers(0, 2**62, size=3000)] for _ in range(4)]
+    packed = fe.pack_claims(claims)
+    g = pkg.System.new(ctx, params, inputs)
+    o = oracle.System(g.blob)
+    want = o.prove(traces, packed) if case == "long_claims" else None
+    monkeypatch.setenv("MSAMD_TRACE_HOST", "1")
+    capfd.readouterr()
+    got = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    err = capfd.readouterr().err
+    assert "transcript replayed" in err and "sync 2 (stage-2 cap)" not in err, err[-2000:]
+    monkeypatch.delenv("MSAMD_TRACE_HOST")
+    if want is None:
+        want = o.prove(traces, packed)
+        assert o.verify(packed, got) == 0
+    assert got == want
+    monkeypatch.setenv("MSAMD_HOST_TRANSCRIPT", "1")
+    assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
 
 
 # handles may die in any order (a garbage collector gives none): the library keeps a context alive while systems or
