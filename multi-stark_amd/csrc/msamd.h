@@ -415,7 +415,8 @@ struct DeepPoints {
 // ro[i] = sum over matrices/points of coeff * (red_z - sum_c alpha^c m[i][c]) / (z - x_i)
 // alpha_pows_host (optional): the same powers on the host; short lists then travel inside the kernel's argument block
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro,
-                 const E2* alpha_pows_host = nullptr, Digest* fri_leaves = nullptr /* height / 2 leaf digests of FRI's first round */);
+                 const E2* alpha_pows_host = nullptr, Digest* fri_leaves = nullptr /* height / 2 leaf digests of FRI's first round */,
+                 const DeepMat* mats_dev = nullptr /* the list already in device memory */);
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
 // row0 / rows_total: `cur`, `roll_in`, `out` are the slice [row0, row0 + rows) of a folded layer of rows_total rows (0 = whole layer)
 void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out, size_t row0 = 0, size_t rows_total = 0);

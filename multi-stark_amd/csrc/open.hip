@@ -20,37 +20,58 @@ __device__ __forceinline__ u64 coset_point(const u64* __restrict__ t0, const u64
   return gl_mul_small(gl_mul(t1[e >> TW_HALF], t0[e & ((1u << TW_HALF) - 1)]), 7);
 }
 
-constexpr int DEN_CHUNK = 16;
+constexpr int DEN_CHUNK = 32;
+constexpr int DEN_LOG_CHUNK = 5;
 // out[i] = 1 / (z - x_i) for i < H; xout[i] = x_i / (z - x_i) for i < n_x (the barycentric weights: only the
 // first H / blowup storage rows, i.e. the trace-domain coset, are ever used there)
 // (zp != nullptr: the point is read from device memory - the device transcript sampled it, outer.hip)
+//
+// 1 / (z - x) = conj(z - x) / N, N = (z0 - x)^2 - 7 z1^2 in the base field, and a thread inverts the norms of its 32
+// elements together (Montgomery's trick: one base-field inversion, 72 multiplications, per 32 elements). Element k of a
+// thread is base + 256 k, so every store is coalesced; its point is x_base times a constant that depends on k alone
+// (bit-reversed storage: the bits of k land in a fixed field of the exponent), read through the scalar unit. Both passes
+// are ROLLED loops with the prefix products in LDS (the norms are recomputed on the way back): fully unrolled, the kernel
+// was 80 KB of straight-line code at 274 registers - one wave per SIMD, waiting on the instruction cache.
 __global__ __launch_bounds__(256) void inv_denoms_k(E2 zv, const E2* __restrict__ zp, unsigned log_h, const u64* __restrict__ t0,
                                                     const u64* __restrict__ t1, E2* __restrict__ out, E2* __restrict__ xout, size_t n_x) {
+  __shared__ u64 pre[DEN_CHUNK][256];
   const E2 z = zp ? *zp : zv;
   const size_t H = size_t(1) << log_h;
-  // element k of this thread is base + k * 256: lanes touch consecutive elements, so every store is coalesced
-  const size_t base = blockIdx.x * size_t(256 * DEN_CHUNK) + threadIdx.x;
+  const u32 tid = threadIdx.x;
+  const size_t base = blockIdx.x * size_t(256 * DEN_CHUNK) + tid;
   if (base >= H) return;
-  E2 d[DEN_CHUNK];
-  u64 x[DEN_CHUNK];
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < DEN_CHUNK; k++) {
-    const size_t i = base + size_t(k) * 256;
-    if (i < H) {
-      x[k] = coset_point(t0, t1, (u32)i, log_h);
-      d[k] = e2(gl_sub(z.c0, x[k]), z.c1);
-      cnt = k + 1;
-    }
+  const u64 nb = gl_mul_small(gl_sqr(z.c1), (u32)GL_EXT_W);  // 7 z1^2
+  const u64 nz1 = gl_neg(z.c1);
+  const u64 x0 = coset_point(t0, t1, (u32)base, log_h);
+  // bitrev(base + 256 k) = bitrev(base) + bitrev(256 k) when H >= 256 * 32 (disjoint bit fields), and
+  // w_H^bitrev(256 k) = w_(2^13)^rev5(k) is a single entry of the upper table; shorter domains take the direct route
+  static_assert(TW_LOG - 8 - DEN_LOG_CHUNK >= TW_HALF, "the constant must be a single table entry");
+  const bool fast = log_h >= 8 + DEN_LOG_CHUNK;
+  auto point = [&](int k) -> u64 {
+    if (k == 0) return x0;
+    if (fast) return gl_mul(x0, t1[(__brev((u32)k) >> (32 - DEN_LOG_CHUNK)) << (TW_LOG - 8 - DEN_LOG_CHUNK - TW_HALF)]);
+    return coset_point(t0, t1, (u32)(base + size_t(k) * 256), log_h);
+  };
+  const size_t left = (H - base + 255) / 256;
+  const int cnt = left < (size_t)DEN_CHUNK ? (int)left : DEN_CHUNK;
+  u64 acc = 1;
+#pragma unroll 1
+  for (int k = 0; k < cnt; k++) {
+    const u64 d0 = gl_sub(z.c0, point(k));
+    pre[k][tid] = acc;
+    acc = gl_mul(acc, gl_sub(gl_sqr(d0), nb));
   }
-  e2_batch_inverse<DEN_CHUNK>(d, cnt);
-#pragma unroll
-  for (int k = 0; k < DEN_CHUNK; k++) {
+  u64 inv = gl_inv(acc);
+#pragma unroll 1
+  for (int k = cnt - 1; k >= 0; k--) {
     const size_t i = base + size_t(k) * 256;
-    if (k < cnt) {
-      out[i] = d[k];
-      if (i < n_x) xout[i] = e2_mul_base(d[k], x[k]);
-    }
+    const u64 x = point(k);
+    const u64 d0 = gl_sub(z.c0, x);
+    const u64 ni = gl_mul(inv, pre[k][tid]);
+    inv = gl_mul(inv, gl_sub(gl_sqr(d0), nb));
+    const E2 d = e2(gl_mul(d0, ni), gl_mul(nz1, ni));
+    out[i] = d;
+    if (i < n_x) xout[i] = e2_mul_base(d, x);
   }
 }
 
@@ -697,7 +718,7 @@ void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npo
 }
 
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* apow_dev, E2* ro,
-                 const E2* apow_host, Digest* fri_leaves) {
+                 const E2* apow_host, Digest* fri_leaves, const DeepMat* mats_dev) {
   if (pts.n > 2) throw std::runtime_error("deep_reduce: more than two opening points at one height");
   for (auto& m : mats)
     for (u32 k = 0; k < m.npoints; k++)
@@ -706,9 +727,13 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
   // argument block they cost more than the two small uploads save)
   (void)apow_host;
   if (!apow_dev) throw std::runtime_error("deep_reduce: alpha powers missing");
-  DBuf<DeepMat> dm(ctx, mats.size());
-  ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
-  DeepParams p{dm.p, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves};
+  DBuf<DeepMat> dm;
+  if (!mats_dev) {  // (pcs_open uploads every height's list together with the alpha powers: one copy instead of one per height)
+    dm = DBuf<DeepMat>(ctx, mats.size());
+    ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
+    mats_dev = dm.p;
+  }
+  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves};
   double bytes = 16.0 * height * (1 + pts.n);
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);

@@ -1192,8 +1192,6 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   std::vector<E2> apow(gw + 1);
   apow[0] = e2(1);
   for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
-  DBuf<E2> d_apow(ctx, gw + 1);
-  ctx.h2d(d_apow.p, apow.data(), (gw + 1) * sizeof(E2));
   // reduced openings per LDE height; the opening points of one height are numbered locally (at most two)
   std::vector<size_t> num_reduced(33, 0);
   std::vector<std::vector<DeepMat>> lists(33);
@@ -1238,6 +1236,25 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       lists[lh].push_back(dm);
     }
   }
+  // the alpha powers and every height's matrix list cross in ONE copy (each copy is a launch of its own in the stream)
+  static_assert(sizeof(DeepMat) % 8 == 0 && sizeof(E2) == 16, "the blob keeps both aligned");
+  size_t n_mats = 0;
+  for (auto& l : lists) n_mats += l.size();
+  std::vector<uint8_t> deep_blob((gw + 1) * sizeof(E2) + n_mats * sizeof(DeepMat));
+  memcpy(deep_blob.data(), apow.data(), (gw + 1) * sizeof(E2));
+  std::vector<size_t> list_off(33, 0);
+  {
+    size_t off = (gw + 1) * sizeof(E2);
+    for (int lh = 32; lh >= 0; lh--) {
+      list_off[lh] = off;
+      if (lists[lh].empty()) continue;
+      memcpy(deep_blob.data() + off, lists[lh].data(), lists[lh].size() * sizeof(DeepMat));
+      off += lists[lh].size() * sizeof(DeepMat);
+    }
+  }
+  DBuf<uint8_t> d_deep(ctx, deep_blob.size());
+  ctx.h2d(d_deep.p, deep_blob.data(), deep_blob.size());
+  const E2* d_apow = reinterpret_cast<const E2*>(d_deep.p);
   std::vector<DBuf<E2>> inputs;  // descending height
   DTree fri_round0;              // the tallest vector is FRI's first committed matrix: its leaf layer is hashed where it is produced
   if (use_side) ctx.side_fork();  // behind the upload of the alpha powers
@@ -1254,7 +1271,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         merkle_alloc(ctx, fri_round0, h / 2);
         leaves = fri_round0.base();
       }
-      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow.p, ro.p, apow.data(), leaves);
+      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow, ro.p, apow.data(), leaves, reinterpret_cast<const DeepMat*>(d_deep.p + list_off[lh]));
     }
     inputs.push_back(std::move(ro));
   }
