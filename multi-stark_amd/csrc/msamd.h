@@ -394,8 +394,10 @@ void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout = nullptr, siz
 void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);  // the point read from device memory
 // opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i].
 // bary_sums_async only launches (raw sums to device memory, index c * np + p); bary_finish applies scale_p on the host.
+// second_is_next: the second point is the first times the generator of the matrix's trace domain (the usual pair zeta,
+// zeta * g): its weights are the first point's read through a permutation (open.hip::rev_dec) and xden1 is ignored
 void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* xden0, const E2* xden1,
-                     int npoints, E2* out_dev);
+                     int npoints, E2* out_dev, bool second_is_next = false);
 void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npoints, E2* out /* p * w + c */);
 struct DeepMat {
   const u64* d;         // column-major LDE
@@ -411,6 +413,8 @@ struct DeepPoints {
   uint32_t pad;
   const E2* den[2];     // 1 / (z_q - x_i), device
   E2 K[2];              // sum over matrices opened at z_q of coeff * (sum_c alpha^c y_q[c])
+  uint32_t shift[2];    // 0, or: z_q = z' * w^shift for the point z' whose denominators den[q] holds (w = the domain's generator);
+                        // the kernel then reads den[q] through open.hip::rev_dec, and K / the coefficients carry the factor w^-shift
 };
 // ro[i] = sum over matrices/points of coeff * (red_z - sum_c alpha^c m[i][c]) / (z - x_i)
 // alpha_pows_host (optional): the same powers on the host; short lists then travel inside the kernel's argument block

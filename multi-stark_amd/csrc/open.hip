@@ -75,6 +75,19 @@ __global__ __launch_bounds__(256) void inv_denoms_k(E2 zv, const E2* __restrict_
   }
 }
 
+// Storage index of the point that lies `dec` steps of the domain's generator BEFORE storage index j (bit-reversed storage of a
+// coset of 2^log_h points): x_{sigma(j)} = x_j * w^-dec. For zeta' = zeta * g with g = w^dec (g the generator of the trace
+// domain, dec = the blowup) that gives 1 / (zeta' - x_j) = g^-1 / (zeta - x_sigma(j)) and
+// x_j / (zeta' - x_j) = x_sigma(j) / (zeta - x_sigma(j)): the second opening point of a matrix needs no denominators of
+// its own, it reads the first point's through sigma. Consecutive j map to consecutive sigma(j) except where the borrow runs
+// through the whole index, so the accesses stay coalesced.
+__device__ __forceinline__ size_t rev_dec(size_t j, unsigned log_h, u32 dec) {
+  if (log_h == 0) return j;
+  const u32 n = __brev((u32)j) >> (32 - log_h);
+  const u32 m = (n - dec) & (u32)((size_t(1) << log_h) - 1);
+  return __brev(m) >> (32 - log_h);
+}
+
 __device__ __forceinline__ u64 wave_sum(u64 v) {
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
@@ -94,7 +107,7 @@ constexpr int BARY_COLS = 4;   // columns per workgroup: their split accumulator
 template <int NP>
 __global__ __launch_bounds__(BARY_T) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
                                                       const E2* __restrict__ xden0, const E2* __restrict__ xden1,
-                                                      E2* __restrict__ partial, u32 nblk, u32 ngrp) {
+                                                      E2* __restrict__ partial, u32 nblk, u32 ngrp, u32 next1) {
   constexpr int NV = BARY_COLS * NP * 2;  // sums per thread
   __shared__ u64 sh[NV][BARY_T + 1];
   const size_t h = size_t(1) << log_h;
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(BARY_T) void bary_partial_k(const u64* __restrict__
       const E2 a = xden0[ii];
       xd[buf][u][0] = e2(in ? a.c0 : 0, in ? a.c1 : 0);
       if (NP == 2) {
-        const E2 b = xden1[ii];
+        const E2 b = xden1[next1 ? rev_dec(ii, log_h, 1) : ii];  // next1: the second point is the first times the trace generator
         xd[buf][u][NP - 1] = e2(in ? b.c0 : 0, in ? b.c1 : 0);
       }
 #pragma unroll
@@ -193,6 +206,7 @@ struct DeepParams {
   E2* ro;
   size_t height;
   Digest* leaves;  // when set: digest of FRI row i / 2 = (ro[i], ro[i + 1]), the leaf layer of the first commit-phase round
+  u32 log_height;  // log2 of the FULL domain the rows belong to (only read for shifted points)
 };
 // ro[i] = sum_q den_q[i] * (K_q - sum_m coeff_{m,q} * s_m[i]),  s_m[i] = sum_c alpha^c m[i][c]
 // (= sum over matrices and points of coeff * (red_z - s_m[i]) / (z_q - x_i), regrouped by point so that the
@@ -272,8 +286,9 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
       const E2 t0 = e2(gl_sub(K.c0, acc_reduce(T[q][0])), gl_sub(K.c1, acc_reduce(T[q][1])));
       const E2 t1 = e2(gl_sub(K.c0, acc_reduce(T[q][2])), gl_sub(K.c1, acc_reduce(T[q][3])));
       const E2* __restrict__ den = p.pts.den[q];
-      r0 = e2_add(r0, e2_mul(t0, den[i]));
-      r1 = e2_add(r1, e2_mul(t1, den[i + 1]));
+      const u32 dec = p.pts.shift[q];  // 0, or the point is an earlier one times w^dec: read that one's denominators (rev_dec)
+      r0 = e2_add(r0, e2_mul(t0, den[dec ? rev_dec(i, p.log_height, dec) : i]));
+      r1 = e2_add(r1, e2_mul(t1, den[dec ? rev_dec(i + 1, p.log_height, dec) : i + 1]));
     }
   }
   p.ro[i] = r0;
@@ -686,7 +701,7 @@ void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout
 
 // launches only: raw sums sum_{i<h} col_c[i] x_i invden_p[i] into `out_dev` (w * npoints values, index c * np + p)
 void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* xden0, const E2* xden1, int npoints,
-                     E2* out_dev) {
+                     E2* out_dev, bool second_is_next) {
   if (npoints == 0) return;
   size_t h = size_t(1) << log_h;
   size_t nblk = (h + BARY_T * BARY_ROWS - 1) / (BARY_T * BARY_ROWS);
@@ -697,9 +712,10 @@ void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned 
   hipEvent_t ev = ctx.prof_begin(K_BARY);
   dim3 grid((unsigned)nlin);
   if (npoints == 1)
-    hipLaunchKernelGGL(bary_partial_k<1>, grid, dim3(BARY_T), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden0, partial.p, (u32)nblk, (u32)ngrp);
+    hipLaunchKernelGGL(bary_partial_k<1>, grid, dim3(BARY_T), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden0, partial.p, (u32)nblk, (u32)ngrp, 0u);
   else
-    hipLaunchKernelGGL(bary_partial_k<2>, grid, dim3(BARY_T), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, xden1, partial.p, (u32)nblk, (u32)ngrp);
+    hipLaunchKernelGGL(bary_partial_k<2>, grid, dim3(BARY_T), 0, ctx.stream, mat, mat_h, (u32)w, log_h, xden0, second_is_next ? xden0 : xden1, partial.p,
+                       (u32)nblk, (u32)ngrp, second_is_next ? 1u : 0u);
   size_t tot = w * npoints;
   hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, out_dev);
   ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
@@ -733,7 +749,11 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
     ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
     mats_dev = dm.p;
   }
-  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves};
+  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves, 0};
+  if (pts.shift[0] || pts.shift[1]) {
+    if (height & (height - 1)) throw std::runtime_error("deep_reduce: shifted points need the whole (power-of-two) domain");
+    p.log_height = log2_strict(height);
+  }
   double bytes = 16.0 * height * (1 + pts.n);
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);

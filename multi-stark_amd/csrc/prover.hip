@@ -984,6 +984,7 @@ struct SymbolicPoints {
   const E2* d_points = nullptr;
   size_t n = 0;
   std::function<void(std::vector<E2>& values)> resolve;
+  std::vector<int> next_log;  // per id: point id = point 0 times the generator of the subgroup of order 2^next_log[id] (-1: unrelated)
 };
 inline E2 sym_point(size_t id) { return e2((u64)id, ~u64(0)); }
 inline bool is_sym_point(E2 z) { return z.c1 == ~u64(0); }
@@ -1074,6 +1075,40 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   const unsigned log_gmax = log2_strict(gmax);
   PhaseTrace tr(ctx);
 
+  // The usual pair of points of a matrix is (z, z * g), g the generator of its trace domain: the second point then needs no
+  // inverse denominators of its own - 1 / (z g - x_j) = g^-1 / (z - x_sigma(j)) for a permutation sigma of the storage order
+  // (open.hip::rev_dec) - which saves one full-domain pass per trace height (MSAMD_NO_NEXT_SHIFT=1: every point its own pass)
+  const bool allow_next = !getenv("MSAMD_NO_NEXT_SHIFT");
+  std::vector<std::vector<char>> is_next(rounds.size());
+  for (size_t ri = 0; ri < rounds.size(); ri++) {
+    auto& r = rounds[ri];
+    is_next[ri].assign(r.data->ldes.size(), 0);
+    for (size_t mi = 0; allow_next && mi < r.data->ldes.size(); mi++) {
+      auto& pts = r.points[mi];
+      const unsigned lh = log2_strict(r.data->ldes[mi].h);
+      if (pts.size() != 2 || lh < lb || lh > 31) continue;
+      const bool s0 = is_sym_point(pts[0]), s1 = is_sym_point(pts[1]);
+      if (s0 && s1)
+        is_next[ri][mi] = sym && pts[0].c0 == 0 && pts[1].c0 < sym->next_log.size() && sym->next_log[pts[1].c0] == (int)(lh - lb);
+      else if (!s0 && !s1)
+        is_next[ri][mi] = e2_same(pts[1], e2_mul_base(pts[0], gl_two_adic_generator(lh - lb))) && !e2_same(pts[0], pts[1]);
+    }
+  }
+  // (a matrix of the same height that opens the second point in its own right would make it a third point of that height
+  // for the reduced openings: keep the plain form there)
+  for (size_t ri = 0; ri < rounds.size(); ri++)
+    for (size_t mi = 0; mi < rounds[ri].data->ldes.size(); mi++) {
+      if (!is_next[ri][mi]) continue;
+      const size_t h = rounds[ri].data->ldes[mi].h;
+      const E2 second = rounds[ri].points[mi][1];
+      for (size_t rj = 0; rj < rounds.size() && is_next[ri][mi]; rj++)
+        for (size_t mj = 0; mj < rounds[rj].data->ldes.size(); mj++) {
+          if (rounds[rj].data->ldes[mj].h != h) continue;
+          auto& q = rounds[rj].points[mj];
+          for (size_t pj = 0; pj < q.size(); pj++)
+            if (!(pj == 1 && is_next[rj][mj]) && e2_same(q[pj], second)) is_next[ri][mi] = 0;
+        }
+    }
   // unique opening points and the tallest matrix opened at each
   std::vector<E2> upts;
   std::vector<size_t> uh;
@@ -1084,12 +1119,15 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     uh.push_back(0);
     return upts.size() - 1;
   };
-  for (auto& r : rounds)
+  for (size_t ri = 0; ri < rounds.size(); ri++) {
+    auto& r = rounds[ri];
     for (size_t mi = 0; mi < r.data->ldes.size(); mi++)
-      for (auto& z : r.points[mi]) {
-        size_t k = point_index(z);
+      for (size_t pi = 0; pi < r.points[mi].size(); pi++) {
+        if (pi == 1 && is_next[ri][mi]) continue;  // read through the first point's arrays
+        size_t k = point_index(r.points[mi][pi]);
         uh[k] = std::max(uh[k], r.data->ldes[mi].h);
       }
+  }
   // short matrices beside tall ones: their launches go to the side stream (see prove()), queued behind the tall ones'
   ctx.side_config();
   const size_t short_h = size_t(1) << (ctx.side_max_log + lb);
@@ -1134,7 +1172,8 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   DBuf<E2> d_sums(ctx, std::max<size_t>(total_vals, 1));
   for (int pass = 0; pass < 2; pass++) {
     size_t off = 0;
-    for (auto& r : rounds)
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+      auto& r = rounds[ri];
       for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
         const DMat& m = r.data->ldes[mi];
         auto& pts = r.points[mi];
@@ -1142,12 +1181,14 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         int np = (int)pts.size();
         if ((int)(use_side && m.h <= short_h) == pass) {
           SideScope sc(ctx, pass == 1);
+          const bool nx = is_next[ri][mi];
           const E2* d0 = xdens[point_index(pts[0])].p;
-          const E2* d1 = np == 2 ? xdens[point_index(pts[1])].p : d0;
-          bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off);
+          const E2* d1 = np == 2 && !nx ? xdens[point_index(pts[1])].p : d0;
+          bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off, nx);
         }
         off += np * m.w;
       }
+    }
   }
   std::vector<E2> h_sums(std::max<size_t>(total_vals, 1));
   g_probes.mark("opened values queued");
@@ -1198,6 +1239,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   std::vector<DeepPoints> hpts(33);
   std::vector<std::vector<size_t>> hpt_global(33);
   std::vector<char> present(33, 0);
+  constexpr size_t NEXT_MARK = size_t(1) << 62;
   for (auto& hp : hpts) memset(&hp, 0, sizeof(hp));
   for (size_t ri = 0; ri < rounds.size(); ri++) {
     auto& r = rounds[ri];
@@ -1213,20 +1255,25 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       dm.w = (uint32_t)m.w;
       dm.npoints = (uint32_t)pts.size();
       for (size_t pi = 0; pi < pts.size(); pi++) {
-        const size_t gk = point_index(pts[pi]);
+        // a "next" point is named by the first point's arrays plus a mark (all matrices of one height share g, so the pair
+        // (arrays, mark) identifies the point at this height)
+        const bool nx = pi == 1 && is_next[ri][mi];
+        const size_t gk = point_index(pts[nx ? 0 : pi]) | (nx ? NEXT_MARK : size_t(0));
         size_t local = 0;
         while (local < hpt_global[lh].size() && hpt_global[lh][local] != gk) local++;
         if (local == hpt_global[lh].size()) {
           if (local == 2) throw std::runtime_error("pcs_open: more than two opening points at one LDE height");
           hpt_global[lh].push_back(gk);
-          hpts[lh].den[local] = dens[gk].p;
+          hpts[lh].den[local] = dens[gk & ~NEXT_MARK].p;
+          hpts[lh].shift[local] = nx ? (uint32_t(1) << lb) : 0u;  // g = w_H^blowup
           hpts[lh].K[local] = e2(0);
           hpts[lh].n = (uint32_t)(local + 1);
         }
-        const E2 coeff = e2_pow(alpha, num_reduced[lh]);
+        E2 coeff = e2_pow(alpha, num_reduced[lh]);
         E2 rz = e2(0);
         const std::vector<E2>& ys = opened[ri][mi][pi];
         for (size_t c = 0; c < m.w; c++) rz = e2_add(rz, e2_mul(apow[c], ys[c]));
+        if (nx) coeff = e2_mul_base(coeff, gl_inv(gl_two_adic_generator(lh - lb)));  // 1 / (z g - x_j) = g^-1 / (z - x_sigma(j))
         dm.pt[pi] = (uint32_t)local;
         dm.coeff[pi] = coeff;
         dm.coeff7[pi] = gl_mul(coeff.c1, GL_EXT_W);
@@ -2086,6 +2133,8 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     for (size_t pos = 0; pos < NA; pos++) pt_next[pos] = sym_point(id_of[pos]);
     sym.d_points = od.points.p;
     sym.n = 1 + n_ld;
+    sym.next_log.assign(1 + n_ld, -1);
+    for (size_t k = 0; k < n_ld; k++) sym.next_log[1 + k] = (int)od.uniq_ld[k];
     lap(3);
     t0 = now_ms();
     phase.next("stark/fri_open");

@@ -4,6 +4,7 @@ bytes must be identical and the two verifiers must agree. The witnesses are rand
 is irrelevant for parity: both provers must still emit the same bytes, and both verifiers the same verdict class.
 
 usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips the hiprtc compile of every new circuit)
+       FUZZ_BIG=1 ... wider and taller systems;  FUZZ_CLAIMS=1 ... more than 8192 claim words (device-side outer transcript)
        FUZZ_FIELD=babybear python3 tools/fuzz_parity.py ...   the same systems over the reference's second configuration
        (BabyBear / Poseidon2, include/mstark_bb.h) against oracle/libms_oracle_bb.so
 The oracle is used only as the checker."""
@@ -22,6 +23,7 @@ BABYBEAR = os.environ.get("FUZZ_FIELD", "") == "babybear"
 P = 2013265921 if BABYBEAR else 0xFFFFFFFF00000001
 KPERM = None
 BIG = bool(os.environ.get("FUZZ_BIG"))  # wider / taller systems: rows over one BLAKE3 chunk, > 16 lookups, 2^15 rows
+LONG_CLAIMS = bool(os.environ.get("FUZZ_CLAIMS"))  # more than 8192 claim words: the claims digest and the outer transcript run on the device
 
 
 def rand_field(rng, shape):
@@ -100,6 +102,13 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
     if all(t.shape[0] == 0 for t in traces):
         traces[0] = rand_field(rng, (circuits[0].preprocessed.shape[0] if circuits[0].preprocessed is not None else 4, traces[0].shape[1]))
     claims = [[int(x) for x in rand_field(rng, int(rng.integers(0, 6)))] for _ in range(int(rng.integers(0, 5)))]
+    if LONG_CLAIMS and not BABYBEAR:
+        # few long claims or many short ones, 8200 .. 20000 words in all (csrc/outer.hip takes over above 8192)
+        n_cl = int(rng.choice([1, 2, 7, 100, 255, 256, 257, 700, 3000]))
+        total = int(rng.integers(8200, 20000))
+        cuts = np.sort(rng.integers(0, total + 1, n_cl - 1)) if n_cl > 1 else np.array([], dtype=np.int64)
+        lens = np.diff(np.concatenate([[0], cuts, [total]]))
+        claims = [[int(x) for x in rand_field(rng, int(m))] for m in lens]
     packed = fe.pack_claims(claims)
     try:
         compiled = [fe.compile_circuit(c) for c in circuits]
