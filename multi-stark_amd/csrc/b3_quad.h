@@ -88,6 +88,35 @@ __device__ __forceinline__ void b3_quad_compress_iv(const u32* msg, u32 block_le
   h_hi = b ^ d;
 }
 
+// The same with a chaining value carried from block to block (counter 0: the blocks of chunk 0 of a stream). Lane c holds
+// words c and 4 + c of the chaining value in (lo, hi), in and out; `msg` = the block's 16 words (LDS).
+__device__ __forceinline__ void b3_quad_compress_cv(const u32* msg, u32 block_len, u32 flags, u32& lo, u32& hi) {
+  const u32 c = threadIdx.x & 3;
+  const u32 sh4 = 4 * c;
+  u32 mw[7][4];
+#pragma unroll
+  for (int r = 0; r < 7; r++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) mw[r][k] = msg[(b3q::packed(r, k) >> sh4) & 15u];
+  }
+  u32 a = lo, b = hi;
+  u32 cc = c == 0 ? B3_IV0 : c == 1 ? B3_IV1 : c == 2 ? B3_IV2 : B3_IV3;
+  u32 d = c == 2 ? block_len : c == 3 ? flags : 0u;  // counter = 0
+#pragma unroll
+  for (int r = 0; r < 7; r++) {
+    B3Q_G(mw[r][0], mw[r][1])
+    b = b3q::qperm(b, 0x39);
+    cc = b3q::qperm(cc, 0x4E);
+    d = b3q::qperm(d, 0x93);
+    B3Q_G(mw[r][2], mw[r][3])
+    b = b3q::qperm(b, 0x93);
+    cc = b3q::qperm(cc, 0x4E);
+    d = b3q::qperm(d, 0x39);
+  }
+  lo = a ^ cc;
+  hi = b ^ d;
+}
+
 // parent of the two adjacent 32-byte digests at `children` (LDS): BLAKE3 of those 64 bytes as a root
 __device__ __forceinline__ void b3_quad_parent(const u32* children, u32& h_lo, u32& h_hi) {
   b3_quad_compress_iv<false>(children, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT, h_lo, h_hi);

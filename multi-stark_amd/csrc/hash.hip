@@ -637,7 +637,8 @@ __global__ __launch_bounds__(256) void cv_level_k(const Digest* __restrict__ pre
 
 // the last levels of the left-full tree (n <= 2048 chaining values) in one workgroup, one parent per quad: replaces a
 // dozen launches of cv_level_k whose grids have shrunk to a few hundred threads
-__global__ __launch_bounds__(1024) void cv_tail_k(const Digest* __restrict__ prev, Digest* __restrict__ out, u32 n) {
+// (sib_out: also write, per level, the value at index 1 BEFORE the level is paired - the sibling of the leftmost path)
+__global__ __launch_bounds__(1024) void cv_tail_k(const Digest* __restrict__ prev, Digest* __restrict__ out, u32 n, Digest* __restrict__ sib_out = nullptr) {
   __shared__ __attribute__((aligned(16))) u32 sh[2048 * 8];
   const u32 t = threadIdx.x;
   for (u32 i = t; i < n; i += 1024) {
@@ -650,6 +651,10 @@ __global__ __launch_bounds__(1024) void cv_tail_k(const Digest* __restrict__ pre
   while (n > 1) {
     const u32 nn = (n + 1) / 2;
     const u32 flags = B3_PARENT | (n == 2 ? (u32)B3_ROOT : 0u);
+    if (sib_out) {
+      if (t < 8) reinterpret_cast<u32*>(sib_out)[t] = sh[8 + t];
+      sib_out++;
+    }
     u32 lo[4], hi[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
@@ -935,6 +940,74 @@ void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, cons
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- the tree over the chunks of a stream whose chunk 0 arrives LATE (the claims transcript: chunk 0 holds the stage-1
+// commitment). The chaining value of chunk 0 enters the tree on its leftmost path only; the sibling of that path at level l
+// is the sub-tree over chunks [2^l, 2^(l+1)) (cut at the end of the stream), none of which depends on chunk 0. They are
+// computed early - the ordinary level launches run over all chaining values with a placeholder in slot 0 and every level's
+// value at index 1 is kept (beside the stage-1 tree) - and what is left behind the commitment
+// is one wave: the 16 blocks of chunk 0 and one parent per level, each compression on a quad (claims_root_k) - instead of
+// the chunk, five tree levels and the tree's tail as launches of their own.
+struct ClaimsRootArgs {
+  const uint8_t* prefix;  // the stream's host-built prefix, placeholder bytes where the commitment goes
+  const u64* words;       // the stream behind the prefix
+  size_t pl, len;         // prefix length, stream length in bytes
+  const u32* cap;         // the commitment (device), patched over prefix bytes [cap_off, cap_off + cap_bytes)
+  u32 cap_off, cap_bytes;
+  const Digest* sib[32];  // per tree level: where the leftmost path's sibling lies
+  u32 nchunks;
+  Digest* out;
+};
+__global__ __launch_bounds__(64) void claims_root_k(ClaimsRootArgs a) {
+  __shared__ u32 sh[256];
+  __shared__ u32 pm[16];
+  const u32 t = threadIdx.x, c = t & 3;
+  const u32 clen = a.len < 1024 ? (u32)a.len : 1024u;
+  for (u32 i = t; i < 256; i += 64) {
+    u32 wv = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u32 idx = 4 * i + k;
+      u32 byte = 0;
+      if (idx < clen) {
+        if (idx >= a.cap_off && idx - a.cap_off < a.cap_bytes) {
+          const u32 q = idx - a.cap_off;
+          byte = (a.cap[q >> 2] >> (8 * (q & 3))) & 0xff;
+        } else {
+          byte = stream_byte(a.prefix, a.pl, a.words, idx);
+        }
+      }
+      wv |= byte << (8 * k);
+    }
+    sh[i] = wv;
+  }
+  __syncthreads();
+  // every quad of the wave runs the same chain (the DPP moves stay inside a quad); quad 0 writes
+  u32 lo = c == 0 ? B3_IV0 : c == 1 ? B3_IV1 : c == 2 ? B3_IV2 : B3_IV3;
+  u32 hi = c == 0 ? B3_IV4 : c == 1 ? B3_IV5 : c == 2 ? B3_IV6 : B3_IV7;
+  const u32 nblocks = (clen + 63) / 64;
+  for (u32 b = 0; b < nblocks; b++) {
+    const u32 bl = clen - 64 * b < 64 ? clen - 64 * b : 64;
+    const u32 flags = (b == 0 ? (u32)B3_CHUNK_START : 0u) | (b == nblocks - 1 ? (u32)B3_CHUNK_END : 0u);
+    b3_quad_compress_cv(sh + 16 * b, bl, flags, lo, hi);
+  }
+  for (u32 l = 0; (1u << l) < a.nchunks; l++) {
+    if (t < 4) {
+      pm[c] = lo;
+      pm[4 + c] = hi;
+    }
+    if (t >= 8 && t < 16) pm[t] = reinterpret_cast<const u32*>(a.sib[l])[t - 8];
+    __syncthreads();
+    const bool last = (2u << l) >= a.nchunks;
+    b3_quad_compress_iv<false>(pm, 64, B3_PARENT | (last ? (u32)B3_ROOT : 0u), lo, hi);
+    __syncthreads();
+  }
+  if (t < 4) {
+    u32* o = reinterpret_cast<u32*>(a.out);
+    o[c] = lo;
+    o[4 + c] = hi;
+  }
+}
+
 // the tree over the chunks' chaining values; returns where the digest lies on the device (inside cvs or scratch: copied to
 // out_dev when given)
 static const Digest* blake3_cv_tree(Ctx& ctx, Digest* cvs, size_t nchunks, DBuf<Digest>& scratch, Digest* out_dev) {
@@ -969,6 +1042,59 @@ Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks) {
 void blake3_from_cvs_async(Ctx& ctx, Digest* cvs, size_t nchunks, Digest* out_dev) {
   DBuf<Digest> b;
   (void)blake3_cv_tree(ctx, cvs, nchunks, b, out_dev);
+}
+
+// early half: cvs[1 .. nchunks) are complete, cvs[0] is a placeholder. Runs the tree's levels and records where the leftmost
+// path's sibling of every level lies (levels: every level in a buffer of its own, kept until the late half has run)
+void blake3_late_chunk0_prepare(Ctx& ctx, const Digest* cvs, size_t nchunks, LateChunk0& lc) {
+  if (nchunks < 2 || nchunks > (size_t(1) << 30)) throw std::runtime_error("blake3_late_chunk0: chunk count out of range");
+  lc.levels = DBuf<Digest>(ctx, nchunks + 64);
+  lc.sib.clear();
+  const Digest* cur = cvs;
+  Digest* nxt = lc.levels.p;
+  size_t n = nchunks;
+  while (n > 1) {
+    if (n <= 2048) {  // the rest in one launch, which writes its levels' siblings one after the other
+      Digest* tail_sib = nxt + 1;
+      size_t m = n;
+      while (m > 1) {
+        lc.sib.push_back(tail_sib++);
+        m = (m + 1) / 2;
+      }
+      hipLaunchKernelGGL(cv_tail_k, dim3(1), dim3(1024), 0, ctx.stream, cur, nxt, (u32)n, nxt + 1);
+      break;
+    }
+    lc.sib.push_back(cur + 1);
+    const size_t nn = (n + 1) / 2;
+    hipLaunchKernelGGL(cv_level_k, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx.stream, cur, nxt, n, 0u);
+    cur = nxt;
+    nxt += nn;
+    n = nn;
+  }
+  HIP_CHECK(hipGetLastError());
+  if (lc.sib.size() > 32) throw std::runtime_error("blake3_late_chunk0: too many levels");
+}
+// late half: chunk 0 (prefix with the commitment patched in from device memory, then the stream's words) and the leftmost path
+void blake3_late_chunk0_finish(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords, const Digest* d_cap,
+                               size_t cap_off, size_t ncap, const LateChunk0& lc, size_t nchunks, Digest* out_dev) {
+  if (prefix_len > 1024 || cap_off + 32 * ncap > prefix_len) throw std::runtime_error("blake3_late_chunk0: the prefix must lie inside chunk 0");
+  ClaimsRootArgs a;
+  memset(&a, 0, sizeof(a));
+  a.prefix = d_prefix;
+  a.words = d_words;
+  a.pl = prefix_len;
+  a.len = prefix_len + 8 * nwords;
+  a.cap = reinterpret_cast<const u32*>(d_cap);
+  a.cap_off = (u32)cap_off;
+  a.cap_bytes = (u32)(32 * ncap);
+  unsigned levels = 0;
+  while ((size_t(1) << levels) < nchunks) levels++;
+  if (lc.sib.size() != levels) throw std::runtime_error("blake3_late_chunk0: level count mismatch");
+  for (unsigned l = 0; l < levels; l++) a.sib[l] = lc.sib[l];
+  a.nchunks = (u32)nchunks;
+  a.out = out_dev;
+  hipLaunchKernelGGL(claims_root_k, dim3(1), dim3(64), 0, ctx.stream, a);
+  HIP_CHECK(hipGetLastError());
 }
 
 Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords) {

@@ -1868,12 +1868,19 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     nchunks = blake3_num_chunks(ch.input.size(), claim_words);
     prefix_chunks = std::min(nchunks, (ch.input.size() + 1023) / 1024);
   }
+  // chunk 0 alone depends on the commitment: the rest of the tree is hashed early too (hash.hip: blake3_late_chunk0_*)
+  const bool late_chunk0 = device_claims && prefix_chunks == 1 && nchunks >= 2 && !getenv("MSAMD_OLD_CLAIMS_TREE");
+  LateChunk0 late0;
+  DBuf<uint8_t> d_prefix;
   auto claims_chunks = [&]() {  // everything of the claims digest that does not depend on the stage-1 commitment
     up.wait_claims();
     d_words = DBuf<u64>(ctx, claim_words);
     claims_transcript_words(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, claim_elems, d_words.p);
     d_cvs = DBuf<Digest>(ctx, nchunks);
     blake3_chunk_cvs(ctx, nullptr, ch.input.size(), d_words.p, claim_words, prefix_chunks, nchunks, d_cvs.p);
+    d_prefix = DBuf<uint8_t>(ctx, ch.input.size());
+    ctx.h2d(d_prefix.p, ch.input.data(), ch.input.size());  // placeholder bytes where the commitment goes
+    if (late_chunk0) blake3_late_chunk0_prepare(ctx, d_cvs.p, nchunks, late0);
   };
 
   // ---- stage 1 commit (src/prover.rs:336-351)
@@ -1917,29 +1924,34 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     const size_t cl = s1.tree.cap_layer();
     if (s1.tree.layer_len[cl] != ncap) throw std::runtime_error("stage-1 cap size differs from the transcript's placeholder");
     const Digest* d_cap = s1.tree.base() + s1.tree.layer_off[cl];
-    DBuf<uint8_t> d_prefix(ctx, ch.input.size());
-    ctx.h2d(d_prefix.p, ch.input.data(), ch.input.size());
-    HIP_CHECK(hipMemcpyAsync(d_prefix.p + cap_off, d_cap, ncap * sizeof(Digest), hipMemcpyDeviceToDevice, ctx.stream));
     if (!early_claims) claims_chunks();
     ctx.side_join();
-    blake3_chunk_cvs(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, 0, prefix_chunks, d_cvs.p);
+    od.digest = DBuf<Digest>(ctx, 1);
+    if (late_chunk0) {
+      blake3_late_chunk0_finish(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, d_cap, cap_off, ncap, late0, nchunks, od.digest.p);
+    } else {
+      HIP_CHECK(hipMemcpyAsync(d_prefix.p + cap_off, d_cap, ncap * sizeof(Digest), hipMemcpyDeviceToDevice, ctx.stream));
+      blake3_chunk_cvs(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, 0, prefix_chunks, d_cvs.p);
+      blake3_from_cvs_async(ctx, d_cvs.p, nchunks, od.digest.p);
+    }
     ctx.d2h_queue(s1_cap.data(), d_cap, ncap * sizeof(Digest));
     if (dev_outer) {
-      od.digest = DBuf<Digest>(ctx, 1);
       od.state = DBuf<u32>(ctx, 20);
       d_bg = DBuf<ChallengeBG>(ctx, 1);
-      blake3_from_cvs_async(ctx, d_cvs.p, nchunks, od.digest.p);
       outer_beta_gamma(ctx, od.digest.p, d_bg.p, od.state.p);
       ctx.d2h_queue(&od.h_digest, od.digest.p, sizeof(Digest));
       ctx.d2h_queue(od.h_bg, d_bg.p, 2 * sizeof(E2));  // beta, gamma lead the block
       g_probes.mark("claims digest + beta/gamma queued");
     } else {
-      Digest d = blake3_from_cvs(ctx, d_cvs.p, nchunks);  // synchronises: s1_cap has arrived too
+      Digest d;
+      ctx.d2h(&d, od.digest.p, sizeof(Digest));  // synchronises: s1_cap has arrived too
       g_probes.mark("sync 1 (cap + claims digest)");
       ch.flush_with(d);
     }
     d_words.reset();
     d_cvs.reset();
+    late0.reset();
+    d_prefix.reset();
   }
   E2 beta = e2(0), gamma = e2(0), alpha = e2(0), zeta = e2(0);
   auto tx_beta_gamma = [&]() {
