@@ -12,6 +12,7 @@
 
 #include "b3_dev.h"
 #include "b3_quad.h"
+#include "outer_dev.h"
 #include "challenge_dev.h"
 #include "fri_dev.h"
 #include "msamd.h"
@@ -956,6 +957,8 @@ struct ClaimsRootArgs {
   const Digest* sib[32];  // per tree level: where the leftmost path's sibling lies
   u32 nchunks;
   Digest* out;
+  ChallengeBG* bg;  // when set: the launch goes on to sample beta and gamma from the digest (outer_dev.h)
+  u32* state_out;
 };
 __global__ __launch_bounds__(64) void claims_root_k(ClaimsRootArgs a) {
   __shared__ u32 sh[256];
@@ -1005,6 +1008,12 @@ __global__ __launch_bounds__(64) void claims_root_k(ClaimsRootArgs a) {
     u32* o = reinterpret_cast<u32*>(a.out);
     o[c] = lo;
     o[4 + c] = hi;
+    pm[c] = lo;
+    pm[4 + c] = hi;
+  }
+  if (a.bg) {
+    __syncthreads();
+    outer_beta_gamma_step(pm, a.bg, a.state_out);
   }
 }
 
@@ -1076,7 +1085,8 @@ void blake3_late_chunk0_prepare(Ctx& ctx, const Digest* cvs, size_t nchunks, Lat
 }
 // late half: chunk 0 (prefix with the commitment patched in from device memory, then the stream's words) and the leftmost path
 void blake3_late_chunk0_finish(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords, const Digest* d_cap,
-                               size_t cap_off, size_t ncap, const LateChunk0& lc, size_t nchunks, Digest* out_dev) {
+                               size_t cap_off, size_t ncap, const LateChunk0& lc, size_t nchunks, Digest* out_dev, ChallengeBG* d_bg,
+                               u32* d_state12) {
   if (prefix_len > 1024 || cap_off + 32 * ncap > prefix_len) throw std::runtime_error("blake3_late_chunk0: the prefix must lie inside chunk 0");
   ClaimsRootArgs a;
   memset(&a, 0, sizeof(a));
@@ -1093,6 +1103,8 @@ void blake3_late_chunk0_finish(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_
   for (unsigned l = 0; l < levels; l++) a.sib[l] = lc.sib[l];
   a.nchunks = (u32)nchunks;
   a.out = out_dev;
+  a.bg = d_bg;
+  a.state_out = d_state12;
   hipLaunchKernelGGL(claims_root_k, dim3(1), dim3(64), 0, ctx.stream, a);
   HIP_CHECK(hipGetLastError());
 }

@@ -289,6 +289,7 @@ void blake3_chunk_cvs(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, cons
 Digest blake3_from_cvs(Ctx& ctx, Digest* cvs, size_t nchunks);
 void blake3_from_cvs_async(Ctx& ctx, Digest* cvs, size_t nchunks, Digest* out_dev);  // launches only; digest left on the device
 // a stream whose chunk 0 is known last (it holds a commitment): everything that does not depend on it early, one wave late
+struct ChallengeBG;  // lookup_params.h
 struct LateChunk0 {
   DBuf<Digest> levels;             // every tree level above the chunks, one after the other
   std::vector<const Digest*> sib;  // per level: the sibling of the leftmost path
@@ -299,7 +300,9 @@ struct LateChunk0 {
 };
 void blake3_late_chunk0_prepare(Ctx& ctx, const Digest* cvs, size_t nchunks, LateChunk0& lc);
 void blake3_late_chunk0_finish(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords, const Digest* d_cap,
-                               size_t cap_off, size_t ncap, const LateChunk0& lc, size_t nchunks, Digest* out_dev);
+                               size_t cap_off, size_t ncap, const LateChunk0& lc, size_t nchunks, Digest* out_dev,
+                               ChallengeBG* d_bg = nullptr /* when set: beta and gamma are sampled in the same launch (outer.hip) */,
+                               u32* d_state12 = nullptr);
 
 // ---------------------------------------------------------------- lookup.hip
 struct JitKernel;

@@ -1927,8 +1927,13 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     if (!early_claims) claims_chunks();
     ctx.side_join();
     od.digest = DBuf<Digest>(ctx, 1);
+    if (dev_outer) {
+      od.state = DBuf<u32>(ctx, 20);
+      d_bg = DBuf<ChallengeBG>(ctx, 1);
+    }
     if (late_chunk0) {
-      blake3_late_chunk0_finish(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, d_cap, cap_off, ncap, late0, nchunks, od.digest.p);
+      blake3_late_chunk0_finish(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, d_cap, cap_off, ncap, late0, nchunks, od.digest.p,
+                                dev_outer ? d_bg.p : nullptr, dev_outer ? od.state.p : nullptr);
     } else {
       HIP_CHECK(hipMemcpyAsync(d_prefix.p + cap_off, d_cap, ncap * sizeof(Digest), hipMemcpyDeviceToDevice, ctx.stream));
       blake3_chunk_cvs(ctx, d_prefix.p, ch.input.size(), d_words.p, claim_words, 0, prefix_chunks, d_cvs.p);
@@ -1936,9 +1941,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     }
     ctx.d2h_queue(s1_cap.data(), d_cap, ncap * sizeof(Digest));
     if (dev_outer) {
-      od.state = DBuf<u32>(ctx, 20);
-      d_bg = DBuf<ChallengeBG>(ctx, 1);
-      outer_beta_gamma(ctx, od.digest.p, d_bg.p, od.state.p);
+      if (!late_chunk0) outer_beta_gamma(ctx, od.digest.p, d_bg.p, od.state.p);
       ctx.d2h_queue(&od.h_digest, od.digest.p, sizeof(Digest));
       ctx.d2h_queue(od.h_bg, d_bg.p, 2 * sizeof(E2));  // beta, gamma lead the block
       g_probes.mark("claims digest + beta/gamma queued");
@@ -1970,6 +1973,11 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   DBuf<E2> d_tot(ctx, NA + 1);
   std::vector<E2> h_tot(NA + 1);
   if (n_claims > 256 || dev_outer) {
+    // nothing reads the claims' sum before the accumulators are formed behind the stage-2 commitment: with a side stream it
+    // runs there, beside the long circuits' stage-2 terms (the streams join in front of that commitment)
+    const bool beside = ctx.side_enabled && !getenv("MSAMD_CLAIMS_ACC_MAIN");
+    if (beside && !ctx.side_forked) ctx.side_fork();
+    SideScope sc(ctx, beside);
     claims_accumulator_dyn(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, d_bg.p, d_tot.p);
   } else {
     E2 acc0 = e2(0);
