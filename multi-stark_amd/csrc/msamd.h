@@ -413,6 +413,16 @@ void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout
 // zeta * g): its weights are the first point's read through a permutation (open.hip::rev_dec) and xden1 is ignored
 void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned log_h, const E2* xden0, const E2* xden1,
                      int npoints, E2* out_dev, bool second_is_next = false);
+struct BarySpec {  // one matrix of a batched launch: the arguments of bary_sums_async
+  const u64* mat;
+  size_t mat_h, w;
+  unsigned log_h;
+  const E2 *xden0, *xden1;
+  int npoints;
+  E2* out_dev;
+  bool second_is_next;
+};
+void bary_sums_batch(Ctx& ctx, const std::vector<BarySpec>& specs, DBuf<E2>& partial_keep);  // all matrices in one pair of launches
 void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npoints, E2* out /* p * w + c */);
 struct DeepMat {
   const u64* d;         // column-major LDE

@@ -105,16 +105,14 @@ constexpr int BARY_COLS = 4;   // columns per workgroup: their split accumulator
 // all of the step's loads issued before its products (at 2-3 waves per SIMD the loop is otherwise a chain of load
 // latencies), accumulates unreduced, and the cross-lane reduction happens once per block through LDS.
 template <int NP>
-__global__ __launch_bounds__(BARY_T) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
-                                                      const E2* __restrict__ xden0, const E2* __restrict__ xden1,
-                                                      E2* __restrict__ partial, u32 nblk, u32 ngrp, u32 next1) {
+__device__ __forceinline__ void bary_partial_body(u64 (*sh)[BARY_T + 1], const u32 lin, const u64* __restrict__ mat, size_t mat_h, u32 w,
+                                                  unsigned log_h, const E2* __restrict__ xden0, const E2* __restrict__ xden1,
+                                                  E2* __restrict__ partial, u32 nblk, u32 ngrp, u32 next1) {
   constexpr int NV = BARY_COLS * NP * 2;  // sums per thread
-  __shared__ u64 sh[NV][BARY_T + 1];
   const size_t h = size_t(1) << log_h;
   // Every column group of a row block reads the same weights (32 bytes per row against 8 per column): the linear
   // workgroup id is decoded so that the groups of one row block follow each other on ONE XCD (workgroups are dealt
   // round-robin to the 8 XCDs) and the weights enter that XCD's L2 once.
-  const u32 lin = blockIdx.x;
   const u32 blk = (lin / (8 * ngrp)) * 8 + (lin & 7);
   if (blk >= nblk) return;
   const u32 grp = (lin >> 3) % ngrp;
@@ -184,6 +182,60 @@ __global__ __launch_bounds__(BARY_T) void bary_partial_k(const u64* __restrict__
     dst[j] = s;
   }
 }
+template <int NP>
+__global__ __launch_bounds__(BARY_T) void bary_partial_k(const u64* __restrict__ mat, size_t mat_h, u32 w, unsigned log_h,
+                                                      const E2* __restrict__ xden0, const E2* __restrict__ xden1,
+                                                      E2* __restrict__ partial, u32 nblk, u32 ngrp, u32 next1) {
+  __shared__ u64 sh[BARY_COLS * NP * 2][BARY_T + 1];
+  bary_partial_body<NP>(sh, blockIdx.x, mat, mat_h, w, log_h, xden0, xden1, partial, nblk, ngrp, next1);
+}
+
+// Several matrices in ONE launch. A matrix's grid is a single round of workgroups at two or three waves per SIMD - its
+// duration is the latency of one workgroup's loop, whatever the matrix - so the matrices of an opening (the three
+// commitments, the preprocessed trace) run beside each other instead of one after the other.
+constexpr int BARY_MAX_JOBS = 8;
+struct BaryJob {
+  const u64* mat;
+  size_t mat_h;
+  const E2 *xden0, *xden1;
+  E2* partial;   // nblk x w x np
+  E2* out;       // w x np
+  u32 w, log_h, nblk, ngrp, next1, np;
+  u32 wg_begin;  // first workgroup of the partial launch
+  u32 out_begin; // first output of the final launch
+};
+struct BaryBatch {
+  BaryJob job[BARY_MAX_JOBS];
+  u32 n;
+};
+__global__ __launch_bounds__(BARY_T) void bary_partial_batch_k(BaryBatch b) {
+  __shared__ u64 sh[BARY_COLS * 2 * 2][BARY_T + 1];
+  u32 j = 0;
+  while (j + 1 < b.n && blockIdx.x >= b.job[j + 1].wg_begin) j++;
+  const BaryJob& q = b.job[j];
+  const u32 lin = blockIdx.x - q.wg_begin;
+  if (q.np == 2)
+    bary_partial_body<2>(sh, lin, q.mat, q.mat_h, q.w, q.log_h, q.xden0, q.xden1, q.partial, q.nblk, q.ngrp, q.next1);
+  else
+    bary_partial_body<1>(sh, lin, q.mat, q.mat_h, q.w, q.log_h, q.xden0, q.xden0, q.partial, q.nblk, q.ngrp, 0u);
+}
+__global__ __launch_bounds__(64) void bary_final_batch_k(BaryBatch b) {
+  u32 j = 0;
+  while (j + 1 < b.n && blockIdx.x >= b.job[j + 1].out_begin) j++;
+  const BaryJob& q = b.job[j];
+  const size_t id = blockIdx.x - q.out_begin;  // over c * np + p
+  const size_t stride = size_t(q.w) * q.np;
+  u64 s0 = 0, s1 = 0;
+  for (size_t k = threadIdx.x; k < q.nblk; k += 64) {
+    const E2 v = q.partial[k * stride + id];
+    s0 = gl_add(s0, v.c0);
+    s1 = gl_add(s1, v.c1);
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (threadIdx.x == 0) q.out[id] = e2(s0, s1);
+}
+
 // one wave per output (c, p): strided sum over the blocks' partials, then a wave reduction
 __global__ __launch_bounds__(64) void bary_final_k(const E2* __restrict__ partial, size_t nblk, u32 w, int np, E2* __restrict__ out) {
   const size_t id = blockIdx.x;  // over c * np + p
@@ -720,6 +772,54 @@ void bary_sums_async(Ctx& ctx, const u64* mat, size_t mat_h, size_t w, unsigned 
   hipLaunchKernelGGL(bary_final_k, dim3((unsigned)tot), dim3(64), 0, ctx.stream, partial.p, nblk, (u32)w, npoints, out_dev);
   ctx.prof_end(K_BARY, ev, double(h) * 8.0 * w);
   HIP_CHECK(hipGetLastError());
+}
+
+// the same for several matrices at once (at most BARY_MAX_JOBS per launch pair; `partial_keep` holds the partial sums)
+void bary_sums_batch(Ctx& ctx, const std::vector<BarySpec>& specs, DBuf<E2>& partial_keep) {
+  size_t total_partial = 0;
+  for (auto& sp : specs) {
+    if (sp.npoints < 1 || sp.npoints > 2) throw std::runtime_error("bary: one or two points per matrix");
+    const size_t h = size_t(1) << sp.log_h;
+    total_partial += ((h + BARY_T * BARY_ROWS - 1) / (BARY_T * BARY_ROWS)) * sp.w * sp.npoints;
+  }
+  partial_keep = DBuf<E2>(ctx, std::max<size_t>(total_partial, 1));
+  size_t poff = 0;
+  for (size_t first = 0; first < specs.size(); first += BARY_MAX_JOBS) {
+    BaryBatch b;
+    memset(&b, 0, sizeof(b));
+    u64 wg = 0, outs = 0;
+    double bytes = 0;
+    for (size_t k = first; k < specs.size() && k < first + BARY_MAX_JOBS; k++) {
+      const BarySpec& sp = specs[k];
+      BaryJob& q = b.job[b.n++];
+      const size_t h = size_t(1) << sp.log_h;
+      const size_t nblk = (h + BARY_T * BARY_ROWS - 1) / (BARY_T * BARY_ROWS), ngrp = (sp.w + BARY_COLS - 1) / BARY_COLS;
+      q.mat = sp.mat;
+      q.mat_h = sp.mat_h;
+      q.xden0 = sp.xden0;
+      q.xden1 = sp.second_is_next ? sp.xden0 : sp.xden1;
+      q.partial = partial_keep.p + poff;
+      q.out = sp.out_dev;
+      q.w = (u32)sp.w;
+      q.log_h = sp.log_h;
+      q.nblk = (u32)nblk;
+      q.ngrp = (u32)ngrp;
+      q.next1 = sp.second_is_next ? 1u : 0u;
+      q.np = (u32)sp.npoints;
+      q.wg_begin = (u32)wg;
+      q.out_begin = (u32)outs;
+      poff += nblk * sp.w * sp.npoints;
+      wg += ((nblk + 7) / 8) * 8 * ngrp;
+      outs += sp.w * sp.npoints;
+      bytes += double(h) * 8.0 * sp.w;
+    }
+    if (wg > 0x7fffffffu) throw std::runtime_error("bary: matrices too large");
+    hipEvent_t ev = ctx.prof_begin(K_BARY);
+    hipLaunchKernelGGL(bary_partial_batch_k, dim3((unsigned)wg), dim3(BARY_T), 0, ctx.stream, b);
+    hipLaunchKernelGGL(bary_final_batch_k, dim3((unsigned)outs), dim3(64), 0, ctx.stream, b);
+    ctx.prof_end(K_BARY, ev, bytes);
+    HIP_CHECK(hipGetLastError());
+  }
 }
 
 // y = sum * (z^h - s^h) / (h s^h), s = GENERATOR (p3 interpolate_coset); sums indexed c * np + p

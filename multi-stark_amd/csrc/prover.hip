@@ -1170,8 +1170,11 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       total_vals += r.points[mi].size() * r.data->ldes[mi].w;
     }
   DBuf<E2> d_sums(ctx, std::max<size_t>(total_vals, 1));
+  DBuf<E2> bary_partials[2];
+  const bool batch_bary = !getenv("MSAMD_NO_BARY_BATCH");
   for (int pass = 0; pass < 2; pass++) {
     size_t off = 0;
+    std::vector<BarySpec> specs;  // the matrices of one stream share a pair of launches
     for (size_t ri = 0; ri < rounds.size(); ri++) {
       auto& r = rounds[ri];
       for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
@@ -1180,14 +1183,22 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         if (pts.empty()) continue;
         int np = (int)pts.size();
         if ((int)(use_side && m.h <= short_h) == pass) {
-          SideScope sc(ctx, pass == 1);
           const bool nx = is_next[ri][mi];
           const E2* d0 = xdens[point_index(pts[0])].p;
           const E2* d1 = np == 2 && !nx ? xdens[point_index(pts[1])].p : d0;
-          bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off, nx);
+          if (batch_bary) {
+            specs.push_back(BarySpec{m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off, nx});
+          } else {
+            SideScope sc(ctx, pass == 1);
+            bary_sums_async(ctx, m.d(), m.h, m.w, log2_strict(m.h) - lb, d0, d1, np, d_sums.p + off, nx);
+          }
         }
         off += np * m.w;
       }
+    }
+    if (!specs.empty()) {
+      SideScope sc(ctx, pass == 1);
+      bary_sums_batch(ctx, specs, bary_partials[pass]);
     }
   }
   std::vector<E2> h_sums(std::max<size_t>(total_vals, 1));
