@@ -1240,6 +1240,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     }
   }
   tr.mark("bary_eval");
+  g_probes.mark("opened values observed");
   const E2 alpha = ch.sample_ext();
   std::vector<E2> apow(gw + 1);
   apow[0] = e2(1);
@@ -1294,6 +1295,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       lists[lh].push_back(dm);
     }
   }
+  g_probes.mark("reduced-opening coefficients");
   // the alpha powers and every height's matrix list cross in ONE copy (each copy is a launch of its own in the stream)
   static_assert(sizeof(DeepMat) % 8 == 0 && sizeof(E2) == 16, "the blob keeps both aligned");
   size_t n_mats = 0;
@@ -1333,6 +1335,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     }
     inputs.push_back(std::move(ro));
   }
+  g_probes.mark("reduced openings queued");
   ctx.side_join();  // the short reduced openings read the tall points' denominators, released next
   for (auto& d : dens) d.reset();
   for (auto& d : xdens) d.reset();
