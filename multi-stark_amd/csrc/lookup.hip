@@ -76,12 +76,16 @@ __global__ __launch_bounds__(256) void stage2_terms_k(const u64* __restrict__ mu
 
 // pass 2: thread t owns storage row t = natural row bitrev(t): one scattered 16 L-byte row read, then 2L coalesced
 // column stores of the running sum (the other way round costs 2L scattered 8-byte stores per row)
+// (block_prefix: the scan's third step - adding each block's offset to its rows' prefixes - done here instead of in a pass of
+// its own; rowprefix then holds prefixes inside blocks of `per` rows)
 __global__ __launch_bounds__(256) void stage2_write_k(const E2* __restrict__ terms, size_t n, unsigned logn, u32 L,
-                                                      const E2* __restrict__ rowprefix, u64* __restrict__ out) {
+                                                      const E2* __restrict__ rowprefix, u64* __restrict__ out,
+                                                      const E2* __restrict__ block_prefix, u32 per) {
   size_t rr = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (rr >= n) return;
   const size_t r = bitrev64(rr, logn);
   E2 run = rowprefix[r];
+  if (block_prefix) run = e2_add(run, block_prefix[r / per]);
   const E2* __restrict__ trow = terms + r * L;
   // eight terms in flight per thread: the row sits at a scattered address, so its loads must not wait for the sums
   for (u32 j0 = 0; j0 < L; j0 += 8) {
@@ -210,13 +214,18 @@ __global__ __launch_bounds__(256) void claims_words_k(const u64* __restrict__ da
 }  // namespace
 
 // exclusive prefix sums of in[0..n) into out; the grand total goes to *total_dev (device), nothing is read back
-static void scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n, E2* total_dev) {
-  size_t per = 256 * SCAN_ITEMS;
+// (block_prefix_out: leave the last step - adding the blocks' offsets - to the consumer, which gets the offsets here)
+constexpr u32 SCAN_PER_BLOCK = 256 * SCAN_ITEMS;
+static void scan_exclusive(Ctx& ctx, const E2* in, E2* out, size_t n, E2* total_dev, DBuf<E2>* block_prefix_out = nullptr) {
+  size_t per = SCAN_PER_BLOCK;
   size_t nb = (n + per - 1) / per;
   DBuf<E2> tot(ctx, nb);
   hipLaunchKernelGGL(scan_block_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, in, out, n, tot.p);
   hipLaunchKernelGGL(scan_totals_k, dim3(1), dim3(256), 0, ctx.stream, tot.p, nb, total_dev);
-  hipLaunchKernelGGL(scan_add_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, out, n, tot.p);
+  if (block_prefix_out)
+    *block_prefix_out = std::move(tot);
+  else
+    hipLaunchKernelGGL(scan_add_k, dim3((unsigned)nb), dim3(256), 0, ctx.stream, out, n, tot.p);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -261,9 +270,11 @@ void stage2_build_dyn(Ctx& ctx, const DLookups& lk, const ChallengeBG* ch, u64* 
                        rowsum.p);
   }
   ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + aw));
-  scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev);
+  DBuf<E2> block_prefix;
+  scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev, &block_prefix);
   ev = ctx.prof_begin(K_STAGE2);
-  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out);
+  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out,
+                     (const E2*)block_prefix.p, SCAN_PER_BLOCK);
   ctx.prof_end(K_STAGE2, ev, double(n) * 16.0 * L);
   HIP_CHECK(hipGetLastError());
 }
@@ -290,9 +301,11 @@ void stage2_from_trace_dyn(Ctx& ctx, const JitKernel& trace_jit, const u64* d_tr
   hipEvent_t ev = ctx.prof_begin(K_STAGE2);
   stage2_trace_jit_launch(ctx, trace_jit, sp);
   ctx.prof_end(K_STAGE2, ev, double(n) * 8.0 * (L + args_width));
-  scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev);
+  DBuf<E2> block_prefix;
+  scan_exclusive(ctx, rowsum.p, prefix.p, n, total_dev, &block_prefix);
   ev = ctx.prof_begin(K_STAGE2);
-  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out);
+  hipLaunchKernelGGL(stage2_write_k, grid, dim3(256), 0, ctx.stream, (const E2*)terms.p, n, logn, L, (const E2*)prefix.p, out,
+                     (const E2*)block_prefix.p, SCAN_PER_BLOCK);
   ctx.prof_end(K_STAGE2, ev, double(n) * 16.0 * L);
   HIP_CHECK(hipGetLastError());
 }
