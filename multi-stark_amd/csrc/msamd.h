@@ -406,6 +406,8 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
 // 1/(z - x_i) for i < H over the bit-reversed coset x_i = 7 w_H^{bitrev(i)}; out: E2[H] (AoS)
 // xout (nullable): x_i / (z - x_i) for i < n_x, the barycentric weights of the trace-domain coset
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);
+// storage rows [row0, row0 + rows) only (out / xout still point at row 0 of the full arrays)
+void inv_denoms_rows(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0, size_t rows);
 void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);  // the point read from device memory
 // opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i].
 // bary_sums_async only launches (raw sums to device memory, index c * np + p); bary_finish applies scale_p on the host.

@@ -32,13 +32,15 @@ constexpr int DEN_LOG_CHUNK = 5;
 // (bit-reversed storage: the bits of k land in a fixed field of the exponent), read through the scalar unit. Both passes
 // are ROLLED loops with the prefix products in LDS (the norms are recomputed on the way back): fully unrolled, the kernel
 // was 80 KB of straight-line code at 274 registers - one wave per SIMD, waiting on the instruction cache.
+// (row0, H: the launch covers storage rows [row0, H) of the 2^log_h-point domain - a rank of the joint prover needs the
+// denominators of its own row range only)
 __global__ __launch_bounds__(256) void inv_denoms_k(E2 zv, const E2* __restrict__ zp, unsigned log_h, const u64* __restrict__ t0,
-                                                    const u64* __restrict__ t1, E2* __restrict__ out, E2* __restrict__ xout, size_t n_x) {
+                                                    const u64* __restrict__ t1, E2* __restrict__ out, E2* __restrict__ xout, size_t n_x,
+                                                    size_t row0, size_t H) {
   __shared__ u64 pre[DEN_CHUNK][256];
   const E2 z = zp ? *zp : zv;
-  const size_t H = size_t(1) << log_h;
   const u32 tid = threadIdx.x;
-  const size_t base = blockIdx.x * size_t(256 * DEN_CHUNK) + tid;
+  const size_t base = row0 + blockIdx.x * size_t(256 * DEN_CHUNK) + tid;
   if (base >= H) return;
   const u64 nb = gl_mul_small(gl_sqr(z.c1), (u32)GL_EXT_W);  // 7 z1^2
   const u64 nz1 = gl_neg(z.c1);
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void inv_denoms_k(E2 zv, const E2* __restrict_
   // bitrev(base + 256 k) = bitrev(base) + bitrev(256 k) when H >= 256 * 32 (disjoint bit fields), and
   // w_H^bitrev(256 k) = w_(2^13)^rev5(k) is a single entry of the upper table; shorter domains take the direct route
   static_assert(TW_LOG - 8 - DEN_LOG_CHUNK >= TW_HALF, "the constant must be a single table entry");
-  const bool fast = log_h >= 8 + DEN_LOG_CHUNK;
+  const bool fast = log_h >= 8 + DEN_LOG_CHUNK && (row0 & (size_t(256 * DEN_CHUNK) - 1)) == 0;
   auto point = [&](int k) -> u64 {
     if (k == 0) return x0;
     if (fast) return gl_mul(x0, t1[(__brev((u32)k) >> (32 - DEN_LOG_CHUNK)) << (TW_LOG - 8 - DEN_LOG_CHUNK - TW_HALF)]);
@@ -737,14 +739,21 @@ __global__ void gather_queries_k(const GatherSeg* __restrict__ segs, const u64* 
 
 }  // namespace
 
-static void inv_denoms_launch(Ctx& ctx, E2 z, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x) {
+static void inv_denoms_launch(Ctx& ctx, E2 z, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0 = 0,
+                              size_t rows = ~size_t(0)) {
   if (log_h > TW_LOG) throw std::runtime_error("LDE height above 2^28 is not supported");
   size_t H = size_t(1) << log_h;
   if (n_x > H) throw std::runtime_error("inv_denoms: weight vector longer than the domain");
-  size_t blocks = (H + 256 * DEN_CHUNK - 1) / (256 * DEN_CHUNK);
+  if (rows == ~size_t(0)) rows = H - std::min(row0, H);
+  if (row0 > H || rows > H - row0) throw std::runtime_error("inv_denoms: row range outside the domain");
+  if (rows == 0) return;
+  size_t blocks = (rows + 256 * DEN_CHUNK - 1) / (256 * DEN_CHUNK);
   hipLaunchKernelGGL(inv_denoms_k, dim3((unsigned)blocks), dim3(256), 0, ctx.stream, z, z_dev, log_h, ctx.tw0, ctx.tw1, out, xout,
-                     xout ? n_x : size_t(0));
+                     xout ? n_x : size_t(0), row0, row0 + rows);
   HIP_CHECK(hipGetLastError());
+}
+void inv_denoms_rows(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0, size_t rows) {
+  inv_denoms_launch(ctx, z, nullptr, log_h, out, xout, n_x, row0, rows);
 }
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x) { inv_denoms_launch(ctx, z, nullptr, log_h, out, xout, n_x); }
 void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x) {
