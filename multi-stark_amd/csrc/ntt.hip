@@ -281,6 +281,10 @@ __device__ __forceinline__ void reg_round16(u64 (&x)[16], u32 lo, unsigned shift
 __device__ __forceinline__ u32 pad_hi(u32 e) { return e + ((e >> 8) << 4); }  // 16 spare slots per 256
 __device__ __forceinline__ u32 pad_lo(u32 e) { return e + (e >> 4); }         // 1 spare slot per 16
 constexpr int NTT12_LDS = 4096 + 256 + 16;
+// half a tile of the strided pass (256 rows x 8): 8 spare slots per 128, so that the four row groups of a wave's transposed
+// access start 16 banks apart
+__device__ __forceinline__ u32 pad_half(u32 e) { return e + ((e >> 7) << 3); }
+constexpr int NTT8S_LDS = 2048 + 128 + 8;
 
 // 12-bit contiguous pass over one 4096-element tile (bits 11..0 of the position inside the tile).
 template <bool DIT, bool INV>
@@ -364,7 +368,10 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
                                                const u64* __restrict__ t0, const u64* __restrict__ t1,
                                                const u64* __restrict__ ttab, unsigned src_div, const u64* __restrict__ scale,
                                                u64 out_mul, u32 gx, u32 ncols) {
-  __shared__ u64 sm[NTT12_LDS];
+  // The one exchange of this pass only moves values between the 16 threads that share l, so the two halves of the tile
+  // (l < 8, l >= 8) go through the SAME 17 KB one after the other: twice the workgroups fit a CU's LDS (the 35 KB of the whole
+  // tile capped the pass at four waves per SIMD, and it waits on its strided loads for a quarter of its time)
+  __shared__ u64 sm[NTT8S_LDS];
   const size_t n = size_t(1) << logn;
   const unsigned logB = 8 + logS;
   const unsigned tiles = 1u << (logS - 4);
@@ -404,10 +411,18 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
     }
     reg_round16<false, INV>(x, hq, 4, twc, twc3);  // h bits 7..4
 #pragma unroll
-    for (int j = 0; j < 16; j++) sm[pad_hi((hq + 16 * j) * 16 + l)] = x[j];
-    __syncthreads();
+    for (u32 half = 0; half < 2; half++) {
+      if ((l >> 3) == half) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq * 16 + j) * 16 + l)];
+        for (int j = 0; j < 16; j++) sm[pad_half((hq + 16 * j) * 8 + (l & 7))] = x[j];
+      }
+      __syncthreads();
+      if ((l >> 3) == half) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = sm[pad_half((hq * 16 + j) * 8 + (l & 7))];
+      }
+      __syncthreads();
+    }
     reg_stages16_uniform<false, INV>(x);  // h bits 3..0
     u64 tw[16];  // the sixteen inter-pass twiddles are requested together, before the first product needs one
 #pragma unroll
@@ -439,10 +454,18 @@ __global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64*
     }
     reg_stages16_uniform<true, INV>(x);  // h bits 0..3
 #pragma unroll
-    for (int j = 0; j < 16; j++) sm[pad_hi((hq * 16 + j) * 16 + l)] = x[j];
-    __syncthreads();
+    for (u32 half = 0; half < 2; half++) {
+      if ((l >> 3) == half) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = sm[pad_hi((hq + 16 * j) * 16 + l)];
+        for (int j = 0; j < 16; j++) sm[pad_half((hq * 16 + j) * 8 + (l & 7))] = x[j];
+      }
+      __syncthreads();
+      if ((l >> 3) == half) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = sm[pad_half((hq + 16 * j) * 8 + (l & 7))];
+      }
+      __syncthreads();
+    }
     reg_round16<true, INV>(x, hq, 4, twc, twc3);  // h bits 4..7
 #pragma unroll
     for (int j = 0; j < 16; j++) {
