@@ -362,8 +362,10 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
 // is the one kernel where waves still park on HBM latency (profiles/r01_pmc_sq.txt), and interleaving load / scale load /
 // multiply per element kept fewer requests in flight (-9 % on the launch). Taking two tiles per workgroup and prefetching
 // the second was tried as well: no gain, it halves the occupancy.
+// (six workgroups per CU for the inverse direction: 80 registers, five of them spilled - measured 153 -> 144 us; the forward
+// direction keeps its 108: squeezed to 96 it spills twelve and loses 5 %)
 template <bool DIT, bool INV>
-__global__ __launch_bounds__(256) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
+__global__ __launch_bounds__(256, DIT ? 6 : 4) void ntt8s_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
                                                const u64* __restrict__ twc, const u64* __restrict__ twc3,
                                                const u64* __restrict__ t0, const u64* __restrict__ t1,
                                                const u64* __restrict__ ttab, unsigned src_div, const u64* __restrict__ scale,
