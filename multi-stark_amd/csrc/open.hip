@@ -101,7 +101,9 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 
 constexpr int BARY_T = 128;     // threads per workgroup
 constexpr int BARY_ROWS = 32;  // rows per thread (the reduction of a thread's accumulators costs as much as ~6 rows of products)
-constexpr int BARY_COLS = 4;   // columns per workgroup: their split accumulators (gl_dev.h GlAccS) stay in registers for the whole block
+constexpr int BARY_COLS = 2;   // columns per workgroup: their split accumulators (gl_dev.h GlAccS) stay in registers for the whole block
+// (round 3: 2, not 4 - with four the kernel needed 266 registers, ONE wave per SIMD, and sat at 0.37 of the issue rate: 149 -> 115 us
+// per proof; one column re-reads the weights too often: 137; 16 or 64 rows per thread: the same 115)
 // partial[(blk * w + c) * np + p] = sum over the block's rows of col_c[i] * xden_p[i], xden_p[i] = x_i / (z_p - x_i).
 // grid = (row blocks, column groups): every thread walks BARY_ROWS rows of BARY_COLS columns, two rows per step with
 // all of the step's loads issued before its products (at 2-3 waves per SIMD the loop is otherwise a chain of load
