@@ -16,6 +16,8 @@ python3 $REPO/tools/prof_summary.py $OUT/${TAG}_kernel_stats_bench.csv 27 52 > $
 echo "== SQ counters"; rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/sq -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/sq.log || exit 1
 python3 $REPO/tools/pmc_summary.py "$(find_csv $OUT/sq counter_collection.csv)" > $OUT/${TAG}_pmc_sq.txt
 python3 $REPO/tools/valu_from_pmc.py "$(find_csv $OUT/sq counter_collection.csv)" $OUT/${TAG}_valu.json > /dev/null
+echo "== clock + VALU rate"; rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/clk -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/clk.log || exit 1
+python3 $REPO/tools/clock_from_pmc.py "$(find_csv $OUT/clk counter_collection.csv)" > $OUT/${TAG}_clock_valu.txt
 echo "== FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/fetch.log || exit 1
 echo "== WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --hbm-resident --no-config4 --no-in-flight > /dev/null 2> $OUT/write.log || exit 1
 python3 $REPO/tools/traffic_from_pmc.py "$(find_csv $OUT/fetch counter_collection.csv)" "$(find_csv $OUT/write counter_collection.csv)" $OUT/${TAG}_traffic.json > /dev/null
@@ -25,5 +27,5 @@ echo "== config 4"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT
 cp "$(find_csv $OUT/bb kernel_stats.csv)" $OUT/${TAG}_config4_kernel_stats.csv
 python3 $REPO/tools/prof_summary.py $OUT/${TAG}_config4_kernel_stats.csv 14 30 > $OUT/${TAG}_config4_kernel_stats_summary_per_proof.txt
 python3 $REPO/bench.py --config babybear --steps 20 --warmup 5 > $OUT/${TAG}_config4_bench_line.json 2> $OUT/bb_line.log || exit 1
-rm -rf $OUT/stats $OUT/sq $OUT/fetch $OUT/write $OUT/tl $OUT/bb
+rm -rf $OUT/stats $OUT/sq $OUT/clk $OUT/fetch $OUT/write $OUT/tl $OUT/bb
 ls -la $OUT
