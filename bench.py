@@ -181,6 +181,11 @@ def roofline_of(dominant, dom, full_size=True):
                         valu_file, "" if full_size else "scaled by algorithmic bytes to this run's launch size "),
             "lane_ops_per_launch": ops, "achieved_Tops": tops, "peak_Tops": VALU_PEAK_TOPS, "frac": tops / VALU_PEAK_TOPS,
         }
+        clock_file = os.path.join(ROOT, "profiles", "r03_clock_valu.txt")
+        if os.path.exists(clock_file):
+            line["valu"]["peak_note"] = ("peak_Tops is at the nominal 2.4 GHz; under these kernels the card holds 2.2-2.3 GHz, and the committed pass "
+                                         "profiles/r03_clock_valu.txt (GRBM_GUI_ACTIVE / 8 / duration, SQ_INSTS_VALU of the same dispatches) gives each "
+                                         "class's issue rate against the peak at the clock it ran at")
     return line
 
 

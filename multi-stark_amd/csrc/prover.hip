@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include <sched.h>
+#include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -63,21 +64,34 @@ double now_ms() {
 struct HostProbes {
   bool on = false;
   double t0 = 0;
-  std::vector<std::pair<const char*, double>> marks;
+  long faults0 = 0;
+  struct Mark {
+    const char* what;
+    double t;
+    long faults;  // minor page faults of this thread so far
+  };
+  std::vector<Mark> marks;
+  static long faults_now() {
+    struct rusage ru;
+    return getrusage(RUSAGE_THREAD, &ru) == 0 ? ru.ru_minflt : 0;
+  }
   void start() {
     on = getenv("MSAMD_TRACE_HOST") != nullptr;
     marks.clear();
     t0 = now_ms();
+    if (on) faults0 = faults_now();
   }
   void mark(const char* what) {
-    if (on) marks.emplace_back(what, now_ms());
+    if (on) marks.push_back(Mark{what, now_ms(), faults_now()});
   }
   void print() const {
     if (!on) return;
     double prev = t0;
+    long pf = faults0;
     for (auto& m : marks) {
-      fprintf(stderr, "[msamd]   %-34s at %8.1f us (+%7.1f)\n", m.first, 1e3 * (m.second - t0), 1e3 * (m.second - prev));
-      prev = m.second;
+      fprintf(stderr, "[msamd]   %-34s at %8.1f us (+%7.1f)  page faults +%ld\n", m.what, 1e3 * (m.t - t0), 1e3 * (m.t - prev), m.faults - pf);
+      prev = m.t;
+      pf = m.faults;
     }
   }
 };
