@@ -588,6 +588,11 @@ __global__ __launch_bounds__(1024) void fri_tail_k(FriTailParams p) {
     __syncthreads();
     gout += 8 * rows;
     for (u32 n = rows >> 1; n >= 1; n >>= 1) {
+      if (n <= 16) {  // the last levels on one wave (tree_dev.h)
+        tree_levels_first_wave(tree, n, reinterpret_cast<Digest*>(gout));
+        gout += 8 * (2 * n - 1);
+        break;
+      }
       tree_level_plain(tree, n, reinterpret_cast<Digest*>(gout));
       gout += 8 * n;
     }
@@ -688,17 +693,21 @@ __global__ __launch_bounds__(1024) void fri_query_challenge_k(const u32* __restr
   if (t == 0) out[0] = wit;
   // every query index is 8 bytes popped from the back of the output buffer; an exhausted buffer is refilled by
   // digest <- BLAKE3(digest): a chain of dependent compressions, each run by one quad (half the latency of one lane)
+  // (only the first wave goes on: the chain's two hand-overs per link then cost a wave barrier, not a barrier of sixteen waves)
   const u64 imask = (u64(1) << log_max_height) - 1;
+  if (t >= 64) return;
   for (u32 q = 0; q < n_queries; q++) {
     if (pos == 0) {
       u32 lo = 0, hi = 0;
       if (t < 4) b3_quad_row32(dg, lo, hi);
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       if (t < 4) {
         dg[t] = lo;
         dg[4 + t] = hi;
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       pos = 32;
     }
     pos -= 8;

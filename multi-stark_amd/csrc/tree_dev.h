@@ -80,4 +80,32 @@ __device__ __forceinline__ void tree_level_plain(u32* sh, u32 n, Digest* gout) {
   }
 }
 
+// Every remaining level from n <= 16 nodes down to the root (2n digests at sh, as above), by the FIRST WAVE alone: its
+// quads hand each level over with a wave barrier, where tree_level_plain would stop all sixteen waves of the workgroup
+// twice per level. Results to sh and, level after level, to gout (n + n/2 + ... + 1 digests). Called by every thread;
+// ends with a barrier.
+__device__ __forceinline__ void tree_levels_first_wave(u32* sh, u32 n, Digest* gout) {
+  const u32 t = threadIdx.x;
+  if (t < 64) {
+    const u32 q = t >> 2, c = t & 3;
+    u32* out = reinterpret_cast<u32*>(gout);
+    for (; n >= 1; n >>= 1) {
+      u32 lo = 0, hi = 0;
+      if (q < n) b3_quad_parent(sh + 16 * q, lo, hi);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (q < n) {
+        sh[8 * q + c] = lo;
+        sh[8 * q + 4 + c] = hi;
+        out[8 * q + c] = lo;
+        out[8 * q + 4 + c] = hi;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      out += 8 * n;
+    }
+  }
+  __syncthreads();
+}
+
 }  // namespace msamd
