@@ -205,7 +205,7 @@ static Params params_from(const u64* p7) {
   Params p;
   p.log_blowup = p7[0], p.cap_height = p7[1], p.log_final_poly_len = p7[2], p.max_log_arity = p7[3], p.num_queries = p7[4];
   p.commit_pow_bits = p7[5], p.query_pow_bits = p7[6];
-  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 is restated");
+  if (p.max_log_arity < 1 || p.max_log_arity > 16) throw std::runtime_error("max_log_arity out of range (1..16)");
   return p;
 }
 long mso_pcs_open(const u64* params7, size_t n_rounds, void* const* mmcs, const u64* n_points, const u64* points, void* challenger,

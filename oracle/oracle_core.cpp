@@ -514,7 +514,7 @@ System system_from_blob(const uint8_t* blob, size_t len) {
   p.num_queries = rd.word();
   p.commit_pow_bits = rd.word();
   p.query_pow_bits = rd.word();
-  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 is restated");
+  if (p.max_log_arity < 1 || p.max_log_arity > 16) throw std::runtime_error("max_log_arity out of range (1..16)");
   if (p.log_blowup < 1 || p.log_blowup > 8) throw std::runtime_error("bad log_blowup");
 #ifdef MSO_BABYBEAR
   {

@@ -415,8 +415,29 @@ std::vector<EF> fri_fold_matrix(EF beta, const std::vector<EF>& cur) {
   return out;
 }
 
-// roll-in factor for a reduced opening of matching height: beta^2
-EF fri_roll_in_factor(EF beta) { return ef_square(beta); }
+// roll-in factor for a reduced opening of matching height: the fold of a round of arity 2^a combines the 2^a
+// interleaved parts with beta^0 .. beta^(2^a - 1); the rolled-in vector takes the next power, beta^(2^a) (beta^2 when binary)
+EF fri_roll_in_factor(EF beta, unsigned log_arity) { return ef_exp_pow2(beta, log_arity); }
+
+// [UPSTREAM-RECALL p3-fri compute_log_arity_for_round] a round folds as far as max_log_arity allows without stepping over
+// the next input's height or below the final height (src/types.rs:189-190: "Maximum folding arity per FRI round (log2)")
+unsigned fri_log_arity_for_round(unsigned log_height, int next_input_log_height, unsigned log_final_height, unsigned max_log_arity) {
+  unsigned a = std::min(max_log_arity, log_height - log_final_height);
+  if (next_input_log_height >= 0) a = std::min(a, log_height - (unsigned)next_input_log_height);
+  return a;
+}
+
+// A round of arity 2^a: row r of the committed matrix holds storage elements [r 2^a, (r+1) 2^a) - the evaluations over the
+// coset x <w_{2^a}> in bit-reversed order - and folds to the value at beta of the polynomial of degree < 2^a through them,
+// which is `a` binary folds with beta, beta^2, beta^4, ... (f = sum_j x^j f_j(x^(2^a)) -> sum_j beta^j f_j)
+std::vector<EF> fri_fold_matrix_arity(EF beta, unsigned log_arity, std::vector<EF> cur) {
+  EF bp = beta;
+  for (unsigned j = 0; j < log_arity; j++) {
+    cur = fri_fold_matrix(bp, cur);
+    bp = ef_square(bp);
+  }
+  return cur;
+}
 
 void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenger& ch,
               std::vector<OpenedRound>& opened, FriProof& proof) {
@@ -548,14 +569,17 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
     for (size_t k = 1; k < inputs.size(); k++) min_h = std::min(min_h, inputs[k].size());
     if (min_h <= stop) throw std::runtime_error("FRI: a committed matrix is not taller than blowup * final polynomial length");
   }
+  const unsigned log_final_height = lb + (unsigned)prm.log_final_poly_len;
+  std::vector<unsigned> arities;
   while (folded.size() > stop) {
-    size_t rows = folded.size() / 2;
-    Mat leaves(rows, 2 * EXT_D);  // ExtensionMmcs: width-2 extension rows flattened to 2 D base columns
+    const unsigned la = fri_log_arity_for_round(log2_strict(folded.size()), next_in < inputs.size() ? (int)log2_strict(inputs[next_in].size()) : -1,
+                                                log_final_height, (unsigned)prm.max_log_arity);
+    arities.push_back(la);
+    const size_t ar = size_t(1) << la;
+    size_t rows = folded.size() >> la;
+    Mat leaves(rows, ar * EXT_D);  // ExtensionMmcs: width-2^a extension rows flattened to 2^a D base columns
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < rows; i++) {
-      ef_to(folded[2 * i], &leaves.v[2 * EXT_D * i]);
-      ef_to(folded[2 * i + 1], &leaves.v[2 * EXT_D * i + EXT_D]);
-    }
+    for (size_t i = 0; i < rows * ar; i++) ef_to(folded[i], &leaves.v[EXT_D * i]);
     fri_trees.emplace_back();
     std::vector<Mat> one;
     one.push_back(std::move(leaves));
@@ -565,9 +589,9 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
     proof.commit_phase_commits.push_back(cap);
     proof.commit_pow_witnesses.push_back(ch.grind((unsigned)prm.commit_pow_bits));
     EF beta = ch.sample_ext();
-    folded = fri_fold_matrix(beta, folded);
+    folded = fri_fold_matrix_arity(beta, la, std::move(folded));
     if (next_in < inputs.size() && inputs[next_in].size() == folded.size()) {
-      EF f = fri_roll_in_factor(beta);
+      EF f = fri_roll_in_factor(beta, la);
       const std::vector<EF>& in = inputs[next_in++];
 #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < folded.size(); i++) folded[i] = ef_add(folded[i], ef_mul(f, in[i]));
@@ -596,16 +620,19 @@ void pcs_open(const Params& prm, const std::vector<OpenRound>& rounds, Challenge
       unsigned lmh = log2_strict(r.tree->max_height());
       qp.input_proof.push_back(mmcs_open_batch(*r.tree, index >> (log_gmax - lmh)));
     }
+    size_t index_i = index;
     for (size_t i = 0; i < fri_trees.size(); i++) {
-      size_t index_i = index >> i;
-      size_t sib = index_i ^ 1, pair = index_i >> 1;
-      BatchOpening bo = mmcs_open_batch(fri_trees[i], pair);
+      const unsigned la = arities[i];
+      const size_t ar = size_t(1) << la, own = index_i & (ar - 1), row_i = index_i >> la;
+      BatchOpening bo = mmcs_open_batch(fri_trees[i], row_i);
       CommitPhaseStep st;
-      st.log_arity = 1;
+      st.log_arity = (uint8_t)la;
       const std::vector<u64>& row = bo.opened_values[0];
-      st.sibling_values.push_back(ef_from(&row[EXT_D * (sib % 2)]));
+      for (size_t j = 0; j < ar; j++)  // the row without the queried position's own value, in row order
+        if (j != own) st.sibling_values.push_back(ef_from(&row[EXT_D * j]));
       st.proof = std::move(bo.proof);
       qp.commit_phase_openings.push_back(std::move(st));
+      index_i = row_i;
     }
     proof.query_proofs.push_back(std::move(qp));
   }
@@ -806,7 +833,20 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
   EF alpha = ch.sample_ext();
   size_t nrounds = proof.commit_phase_commits.size();
   if (proof.commit_pow_witnesses.size() != nrounds) return false;
-  unsigned log_gmax = (unsigned)(nrounds + lb + prm.log_final_poly_len);
+  // the rounds' arities are read off the first query's openings (every query must repeat them, and each is checked against
+  // the schedule once the input heights are known below); their sum places the tallest input
+  std::vector<unsigned> arities(nrounds, 1);
+  if (!proof.query_proofs.empty()) {
+    const QueryProof& q0 = proof.query_proofs[0];
+    if (q0.commit_phase_openings.size() != nrounds) return false;
+    for (size_t i = 0; i < nrounds; i++) {
+      arities[i] = q0.commit_phase_openings[i].log_arity;
+      if (arities[i] < 1 || arities[i] > prm.max_log_arity) return false;
+    }
+  }
+  unsigned log_gmax = (unsigned)(lb + prm.log_final_poly_len);
+  for (unsigned a : arities) log_gmax += a;
+  if (log_gmax > 62) return false;
   std::vector<EF> betas;
   for (size_t i = 0; i < nrounds; i++) {
     ch.observe_cap(proof.commit_phase_commits[i]);
@@ -866,28 +906,44 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
     EF folded = it->second.second;
     ++it;
     size_t idx = index;
+    unsigned log_height = log_gmax;
     for (size_t i = 0; i < nrounds; i++) {
-      unsigned log_folded_height = log_gmax - 1 - (unsigned)i;
       const CommitPhaseStep& st = qp.commit_phase_openings[i];
-      if (st.log_arity != 1 || st.sibling_values.size() != 1) return false;
-      size_t sib = idx ^ 1, pair = idx >> 1;
-      EF evals[2];
-      evals[idx % 2] = folded;
-      evals[sib % 2] = st.sibling_values[0];
+      const unsigned la = arities[i];
+      const size_t ar = size_t(1) << la;
+      // the arity the prover had to choose here (compute_log_arity_for_round)
+      if (log_height <= log_final_height) return false;
+      if (la != fri_log_arity_for_round(log_height, it != ro.rend() ? (int)it->first : -1, log_final_height, (unsigned)prm.max_log_arity)) return false;
+      if (st.log_arity != la || st.sibling_values.size() != ar - 1) return false;
+      const unsigned log_folded_height = log_height - la;
+      const size_t own = idx & (ar - 1), row = idx >> la;
+      std::vector<EF> evals(ar);
+      for (size_t j = 0, k = 0; j < ar; j++) evals[j] = j == own ? folded : st.sibling_values[k++];
       BatchOpening bo;
-      bo.opened_values.emplace_back(2 * EXT_D);
-      ef_to(evals[0], bo.opened_values[0].data()), ef_to(evals[1], bo.opened_values[0].data() + EXT_D);
+      bo.opened_values.emplace_back(ar * EXT_D);
+      for (size_t j = 0; j < ar; j++) ef_to(evals[j], bo.opened_values[0].data() + EXT_D * j);
       bo.proof = st.proof;
-      if (!mmcs_verify_batch(proof.commit_phase_commits[i], {Dim{2 * EXT_D, size_t(1) << log_folded_height}}, pair, bo))
+      if (!mmcs_verify_batch(proof.commit_phase_commits[i], {Dim{ar * EXT_D, size_t(1) << log_folded_height}}, row, bo))
         return false;
-      idx = pair;
-      // fold_row: interpolate (x0, e0), (-x0, e1) and evaluate at beta
-      u64 x0 = f_pow(f_two_adic_generator(log_folded_height + 1), bitrev(idx, log_folded_height));
-      u64 x1 = f_neg(x0);
-      EF slope = ef_mul_base(ef_sub(evals[1], evals[0]), f_inv(f_sub(x1, x0)));
-      folded = ef_add(evals[0], ef_mul(ef_sub(betas[i], ef(x0)), slope));
+      idx = row;
+      // fold_row: the polynomial of degree < 2^a through the row's points, evaluated at beta - as binary steps with
+      // beta, beta^2, ...: a step interpolates (x0, e0), (-x0, e1) and evaluates at the step's challenge
+      EF bp = betas[i];
+      for (unsigned s = 0; s < la; s++) {
+        const unsigned lf = log_height - s - 1;  // log height of this step's output
+        const size_t m = ar >> (s + 1);
+        for (size_t t = 0; t < m; t++) {
+          u64 x0 = f_pow(f_two_adic_generator(lf + 1), bitrev(idx * m + t, lf));
+          u64 x1 = f_neg(x0);
+          EF slope = ef_mul_base(ef_sub(evals[2 * t + 1], evals[2 * t]), f_inv(f_sub(x1, x0)));
+          evals[t] = ef_add(evals[2 * t], ef_mul(ef_sub(bp, ef(x0)), slope));
+        }
+        bp = ef_square(bp);
+      }
+      folded = evals[0];
+      log_height = log_folded_height;
       if (it != ro.rend() && it->first == log_folded_height) {
-        folded = ef_add(folded, ef_mul(fri_roll_in_factor(betas[i]), it->second.second));
+        folded = ef_add(folded, ef_mul(fri_roll_in_factor(betas[i], la), it->second.second));
         ++it;
       }
     }
