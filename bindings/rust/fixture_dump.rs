@@ -454,6 +454,38 @@ mod tests {
         );
     }
 
+    /// `max_log_arity` above 1 (`src/types.rs:189-190`), which no call site of the crate sets: rounds of arity 4 and 8, the
+    /// second with proof of work and a 2-coefficient final polynomial (the arity schedule has to stop at the final height).
+    /// These pin the row layout of a wide round, the schedule and the roll-in factor of the repository's restatement.
+    #[test]
+    fn simple_proof_arity4() {
+        pythagorean(
+            256,
+            CommitmentParameters { log_blowup: 1, cap_height: 0 },
+            FriParameters {
+                log_final_poly_len: 0,
+                max_log_arity: 2,
+                num_queries: 20,
+                commit_proof_of_work_bits: 0,
+                query_proof_of_work_bits: 0,
+            },
+        );
+    }
+    #[test]
+    fn simple_proof_arity8_pow() {
+        pythagorean(
+            512,
+            CommitmentParameters { log_blowup: 2, cap_height: 1 },
+            FriParameters {
+                log_final_poly_len: 1,
+                max_log_arity: 3,
+                num_queries: 20,
+                commit_proof_of_work_bits: 3,
+                query_proof_of_work_bits: 5,
+            },
+        );
+    }
+
     /// The Poseidon2 constants of the BabyBear configuration: `Perm::new_from_rng_128(&mut SmallRng::seed_from_u64(42))`
     /// (`src/test_circuits/baby_bear_config.rs:54-55`). p3-poseidon2 keeps them private, so the stream is replayed the way
     /// `Poseidon2::new_from_rng` draws it (4 initial external rounds x 16, 4 terminal x 16, then 13 internal constants) and

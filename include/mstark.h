@@ -77,10 +77,13 @@ const char* ms_kernel_name(int32_t kernel_id);
 
 /* ---- System::new (src/system.rs:115-203). `blob` is the front-end's system blob: params, then per circuit the
  * compiled node program (graph::ConstraintGraph fields, src/graph.rs:62-76), lookups and preprocessed trace.
- * FRI folding is binary: FriParameters::max_log_arity (src/types.rs:190,215) must be 1, which is what every config,
- * example and bench of the reference sets (benches/multi_stark.rs:252, examples/simple_proof.rs:54, pcs_example.rs:39, ...);
- * ms_system_create, ms_pcs_open and ms_pcs_verify (and their msbb_ counterparts) refuse any other value with an
- * error code rather than produce a proof the reference would fold differently. */
+ * FriParameters::max_log_arity (src/types.rs:189-190,215) may be 1 .. 6: a commit-phase round folds 2^a values per row, a as
+ * large as max_log_arity allows without stepping over the next input's height or below the final height; a row of 2^a
+ * extension values is one leaf (at most one BLAKE3 chunk, hence 6). Every config, example and bench of the reference
+ * sets 1 (benches/multi_stark.rs:252, examples/simple_proof.rs:54, pcs_example.rs:39, ...), which is the path the
+ * device-side transcript and the fused round kernels serve; wider rounds are driven from the host (one synchronisation
+ * per round). ms_system_create, ms_pcs_open and ms_pcs_verify (and their msbb_ counterparts) refuse other values with
+ * an error code. */
 int32_t ms_system_create(ms_ctx* ctx, const uint8_t* blob, size_t len, ms_system** out);
 void ms_system_destroy(ms_system* sys);
 /* preprocessed commitment (System.preprocessed_commit): writes n_digests * 32 bytes; n_digests = 0 if none */

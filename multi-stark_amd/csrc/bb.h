@@ -58,8 +58,11 @@ void bb_permute_batch(Ctx& ctx, const Poseidon2* d_perm, u32* d_states, size_t n
 struct DevChallenger;
 struct FriBeta;
 // with d_ch the launch that produces the root also runs the round's challenger step (observe the cap, sample beta -> *d_beta_out)
+// log_arity: the round commits rows of 2^log_arity values (FriParameters::max_log_arity, src/types.rs:189-190); the same bound as
+// the Goldilocks path's (msamd.h FRI_MAX_LOG_ARITY), although the sponge itself has none
+static const unsigned BB_FRI_MAX_LOG_ARITY = 6;
 void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& out,
-                     DevChallenger* d_ch = nullptr, FriBeta* d_beta_out = nullptr);
+                     DevChallenger* d_ch = nullptr, FriBeta* d_beta_out = nullptr, unsigned log_arity = 1);
 // a whole commit-phase round in one launch (fold with the previous round's beta, leaf digests, tree, challenger step)
 bool bb_fri_round_fusable(size_t rows, unsigned cap_height);
 void bb_fri_round_fused(Ctx& ctx, const Poseidon2* d_perm, const E4* cur, size_t rows, const FriBeta* prev, const E4* roll_in, E4* out,

@@ -333,6 +333,26 @@ __global__ __launch_bounds__(256) void leaf_hash8_k(const u32* __restrict__ rows
   for (int i = 0; i < 8; i++) d.w[i] = st[i];
   out[r] = d;
 }
+// FRI layer leaves of a round of arity 2^a >= 4 (max_log_arity > 1): row i = 2^a E4 = nblk blocks of 8 words, absorbed one
+// block per permutation (PaddingFreeSponge, rate 8)
+__global__ __launch_bounds__(256) void leaf_hash_wide_k(const u32* __restrict__ words, size_t rows, unsigned nblk, const Poseidon2* __restrict__ perm,
+                                                        Digest8* __restrict__ out) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  u32 st[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) st[i] = 0;
+  const uint4* p = (const uint4*)(words + r * 8 * nblk);
+  for (unsigned b = 0; b < nblk; b++) {
+    uint4 x = p[2 * b], y = p[2 * b + 1];
+    st[0] = x.x, st[1] = x.y, st[2] = x.z, st[3] = x.w, st[4] = y.x, st[5] = y.y, st[6] = y.z, st[7] = y.w;
+    bb_poseidon2(*perm, st);
+  }
+  Digest8 d;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d.w[i] = st[i];
+  out[r] = d;
+}
 // TruncatedPermutation<Perm, 2, 8, 16>: parent = permute(left || right)[..8]; with injection of a shorter matrix's
 // row digest: parent = compress(parent, inject[i])
 __global__ __launch_bounds__(256) void compress_k(const Digest8* __restrict__ prev, size_t n_out, const Digest8* __restrict__ inject,
@@ -566,14 +586,17 @@ void bb_commit(Ctx& ctx, const Poseidon2* d_perm, std::vector<BMat>&& ldes, unsi
   build_upper_layers(ctx, d_perm, t, order, pos);
 }
 void bb_commit_pairs(Ctx& ctx, const Poseidon2* d_perm, const E4* d_vec, size_t rows, unsigned cap_height, BTree& t, DevChallenger* d_ch,
-                     FriBeta* d_beta_out) {
+                     FriBeta* d_beta_out, unsigned log_arity) {
+  if (log_arity < 1 || log_arity > BB_FRI_MAX_LOG_ARITY) throw std::runtime_error("FRI: round arity out of range");
   t = BTree();
   t.cap_height = cap_height;
   t.layers.emplace_back(ctx, rows);
   t.sizes.push_back(rows);
   {
-    ProfScope prof(ctx, msamd::K_LEAF_HASH, 64.0 * double(rows), double(rows));
-    if (rows <= COOP_MAX)
+    ProfScope prof(ctx, msamd::K_LEAF_HASH, (32.0 + 16.0 * double(1u << log_arity)) * double(rows), double(rows) * double(1u << (log_arity - 1)));
+    if (log_arity > 1)
+      leaf_hash_wide_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, 1u << (log_arity - 1), d_perm, t.layers[0].p);
+    else if (rows <= COOP_MAX)
       leaf_hash8_coop_k<<<blocks_for(rows * 16, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);
     else
       leaf_hash8_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>((const u32*)d_vec, rows, d_perm, t.layers[0].p);

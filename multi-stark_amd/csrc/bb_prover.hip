@@ -173,7 +173,7 @@ std::unique_ptr<BSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
   Params& p = sys->params;
   p.log_blowup = rd.word(), p.cap_height = rd.word(), p.log_final_poly_len = rd.word(), p.max_log_arity = rd.word();
   p.num_queries = rd.word(), p.commit_pow_bits = rd.word(), p.query_pow_bits = rd.word();
-  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 (binary folding) is supported");
+  if (p.max_log_arity < 1 || p.max_log_arity > BB_FRI_MAX_LOG_ARITY) throw std::runtime_error("max_log_arity must be 1 .. 6");
   if (p.log_blowup < 1 || p.log_blowup > 8) throw std::runtime_error("log_blowup out of range");
   if (p.commit_pow_bits > 24 || p.query_pow_bits > 24) throw std::runtime_error("proof-of-work bits out of range");
   for (int r = 0; r < 8; r++)
@@ -641,11 +641,12 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
   // its read-backs, is what spaces them; it needs the launches captured in a graph (or fewer of them) to win.
   // (round 2: the rounds are fused - one launch per round below 2^17 leaves - and the device transcript is the default;
   // MSBB_HOST_FRI=1 restores the host-driven rounds)
-  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && !getenv("MSBB_HOST_FRI");
+  // (rounds of arity above 2, max_log_arity > 1, are host-driven)
+  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && prm.max_log_arity == 1 && !getenv("MSBB_HOST_FRI");
   DBuf<DevChallenger> d_ch;
   DBuf<FriBeta> d_betas;
   size_t n_rounds = 0;
-  for (size_t l = cur_len; l > stop; l /= 2) n_rounds++;
+  for (size_t l = cur_len; l > stop; l /= 2) n_rounds++;  // (binary rounds: only used by the device transcript)
   if (dev_rounds && n_rounds) {
     DevChallenger hc;
     for (int k = 0; k < 16; k++) hc.state[k] = ch.state[k];
@@ -658,14 +659,22 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
   }
   size_t round = 0;
   bool tree_done = false;  // the previous round's fused launch already built this round's tree and ran its challenger step
+  std::vector<unsigned> arities;  // log2 of every round's arity
+  const unsigned log_final_height = (unsigned)(prm.log_blowup + prm.log_final_poly_len);
   while (cur_len > stop) {
-    size_t rows = cur_len / 2;
+    // p3-fri compute_log_arity_for_round: as far as max_log_arity allows without stepping over the next input or the final height
+    const unsigned lh = log2_strict(cur_len);
+    unsigned la = std::min<unsigned>((unsigned)prm.max_log_arity, lh - log_final_height);
+    if (next_in < inputs.size()) la = std::min(la, lh - log2_strict(inputs[next_in].second));
+    if (la < 1) throw std::runtime_error("FRI: two inputs of one height");
+    arities.push_back(la);
+    size_t rows = cur_len >> la;
     if (!tree_done) {
       fri_trees.emplace_back();
       if (dev_rounds)  // the launch that produces the root also observes it and samples beta
         bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back(), d_ch.p, d_betas.p + round);
       else
-        bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back());
+        bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back(), nullptr, nullptr, la);
     }
     tree_done = false;
     const E4* roll = nullptr;
@@ -686,7 +695,18 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
       fri.commits.push_back(cap);
       fri.pow_witnesses.push_back(grind(sys, ch, (unsigned)prm.commit_pow_bits));
       E4 beta = ch.sample_e4();
-      bb_fri_fold(ctx, cur, rows, beta, roll, out.p);
+      // a round of arity 2^la is la binary folds with beta, beta^2, beta^4, ...; the vector rolled in behind it takes
+      // beta^(2^la), the square of the last step's challenge (bb_fri_fold's own roll-in factor)
+      const E4* src = cur;
+      DBuf<E4> step;
+      for (unsigned j = 0; j + 1 < la; j++) {
+        DBuf<E4> nxt(ctx, cur_len >> (j + 1));
+        bb_fri_fold(ctx, src, cur_len >> (j + 1), beta, nullptr, nxt.p);
+        beta = e4_square(beta);
+        step = std::move(nxt);
+        src = step.p;
+      }
+      bb_fri_fold(ctx, src, rows, beta, roll, out.p);
     }
     // keep the folded-from vector alive for the query openings
     if (layers.empty()) {
@@ -778,13 +798,20 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
     }
     fri_opens.emplace_back();
     sib_at.emplace_back();
+    size_t index_i = index;
     for (size_t i = 0; i < fri_trees.size(); i++) {
-      size_t index_i = index >> i, sib = index_i ^ 1, pair = index_i >> 1;
+      const unsigned la = arities[i];
+      const size_t row_i = index_i >> la;
       const E4* vec = i == 0 ? inputs[0].first : layers[i].p;
-      sib_at.back().push_back(add_seg((const u32*)(vec + sib), 4, 1));
+      // binary round: the sibling value; wider: the whole row (the queried position's own value is dropped when the bytes are written)
+      if (la == 1)
+        sib_at.back().push_back(add_seg((const u32*)(vec + (index_i ^ 1)), 4, 1));
+      else
+        sib_at.back().push_back(add_seg((const u32*)(vec + (row_i << la)), 4u << la, 1));
       TreeOpen o;
-      open_tree_path(fri_trees[i], pair, o);
+      open_tree_path(fri_trees[i], row_i, o);
       fri_opens.back().push_back(std::move(o));
+      index_i = row_i;
     }
   }
   std::vector<u32> g_out;
@@ -802,10 +829,20 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
       for (u32 k = 0; k < o.path_len * 8; k++) w.fe(g_out[o.path_at + k]);
     }
     w.u64_(fri_trees.size());
+    size_t index_i = indices[qi];
     for (size_t i = 0; i < fri_trees.size(); i++) {
-      w.u8(1);  // log_arity
-      w.u64_(1);
-      for (u32 k = 0; k < 4; k++) w.fe(g_out[sib_at[qi][i] + k]);
+      const unsigned la = arities[i];
+      w.u8((uint8_t)la);  // log_arity
+      w.u64_((size_t(1) << la) - 1);
+      if (la == 1) {
+        for (u32 k = 0; k < 4; k++) w.fe(g_out[sib_at[qi][i] + k]);
+      } else {
+        const size_t own = index_i & ((size_t(1) << la) - 1);
+        for (size_t j = 0; j < (size_t(1) << la); j++)
+          if (j != own)
+            for (u32 k = 0; k < 4; k++) w.fe(g_out[sib_at[qi][i] + 4 * j + k]);
+      }
+      index_i >>= la;
       const TreeOpen& o = fri_opens[qi][i];
       w.u64_(o.path_len);
       for (u32 k = 0; k < o.path_len * 8; k++) w.fe(g_out[o.path_at + k]);
@@ -1066,7 +1103,8 @@ struct VBatchOpening {
   std::vector<Digest8> path;
 };
 struct VFriStep {
-  E4 sibling;
+  unsigned log_arity = 1;
+  std::vector<E4> siblings;  // the opened row without the queried position's own value
   std::vector<Digest8> path;
 };
 struct VQuery {
@@ -1116,9 +1154,11 @@ VProof parse_proof(const uint8_t* bytes, size_t len) {
     }
     q.steps.resize(r.count(8));
     for (auto& st : q.steps) {
-      if (r.u8() != 1) throw Malformed();    // log_arity
-      if (r.u64_() != 1) throw Malformed();  // one sibling value
-      st.sibling = r.ext();
+      st.log_arity = r.u8();
+      if (st.log_arity < 1 || st.log_arity > BB_FRI_MAX_LOG_ARITY) throw Malformed();
+      st.siblings.resize(r.count(16));
+      if (st.siblings.size() != (size_t(1) << st.log_arity) - 1) throw Malformed();
+      for (auto& e : st.siblings) e = r.ext();
       st.path.resize(r.count(32));
       for (auto& d : st.path) d = r.digest();
     }
@@ -1221,7 +1261,17 @@ bool pcs_verify(const BSystem& sys, const std::vector<RoundClaim>& rounds, const
   const E4 alpha = ch.sample_e4();
   const size_t nrounds = proof.commits.size();
   if (proof.pow.size() != nrounds) return false;
-  const unsigned log_gmax = (unsigned)(nrounds + lb + prm.log_final_poly_len);
+  // every query repeats the rounds' arities; the first one's place the tallest input, each is checked against the schedule below
+  std::vector<unsigned> arities(nrounds, 1);
+  if (!proof.queries.empty()) {
+    if (proof.queries[0].steps.size() != nrounds) return false;
+    for (size_t i = 0; i < nrounds; i++) arities[i] = proof.queries[0].steps[i].log_arity;
+  }
+  unsigned log_gmax = (unsigned)(lb + prm.log_final_poly_len);
+  for (unsigned a : arities) {
+    if (a > prm.max_log_arity) return false;
+    log_gmax += a;
+  }
   if (log_gmax > BB_TWO_ADICITY) return false;
   std::vector<E4> betas;
   for (size_t i = 0; i < nrounds; i++) {
@@ -1283,29 +1333,68 @@ bool pcs_verify(const BSystem& sys, const std::vector<RoundClaim>& rounds, const
     E4 folded = it->second.second;
     ++it;
     size_t idx = index;
+    unsigned log_height = log_gmax;
     for (size_t i = 0; i < nrounds; i++) {
-      const unsigned log_folded_height = log_gmax - 1 - (unsigned)i;
       const VFriStep& st = qp.steps[i];
-      const size_t sib = idx ^ 1, pair = idx >> 1;
-      E4 evals[2];
-      evals[idx % 2] = folded;
-      evals[sib % 2] = st.sibling;
+      const unsigned la = st.log_arity;
+      if (la != arities[i] || log_height <= log_final_height) return false;
+      {  // the schedule: as far as max_log_arity allows without stepping over the next input or below the final height
+        unsigned want = std::min<unsigned>((unsigned)prm.max_log_arity, log_height - log_final_height);
+        if (it != ro.rend()) want = std::min(want, log_height - it->first);
+        if (la != want) return false;
+      }
+      const unsigned log_folded_height = log_height - la;
+      const size_t m = size_t(1) << la, own = idx & (m - 1), row = idx >> la;
+      std::vector<E4> evals(m);
+      for (size_t j = 0, k = 0; j < m; j++) evals[j] = j == own ? folded : st.siblings[k++];
       VBatchOpening bo;
       bo.rows.emplace_back();
-      for (int e = 0; e < 2; e++)
-        for (int k = 0; k < 4; k++) bo.rows[0].push_back(evals[e].c[k]);  // ExtensionMmcs: flattened row
+      for (auto& e : evals)
+        for (int k = 0; k < 4; k++) bo.rows[0].push_back(e.c[k]);  // ExtensionMmcs: flattened row
       bo.path = st.path;
-      if (!mmcs_verify_batch(perm, proof.commits[i], {Dim{8, size_t(1) << log_folded_height}}, pair, bo)) return false;
-      idx = pair;
-      // fold_row: the line through (x0, e0), (-x0, e1) evaluated at beta; x0 = w^bitrev(idx) on the subgroup
-      const u32 x0 = bb_pow(bb_two_adic_generator(log_folded_height + 1), bitrev_host(idx, log_folded_height));
-      const u32 x1 = bb_neg(x0);
-      const E4 slope = e4_mul_base(e4_sub(evals[1], evals[0]), bb_inv(bb_sub(x1, x0)));
-      E4 bx = betas[i];
-      bx.c[0] = bb_sub(bx.c[0], x0);
-      folded = e4_add(evals[0], e4_mul(bx, slope));
+      if (!mmcs_verify_batch(perm, proof.commits[i], {Dim{4 * m, size_t(1) << log_folded_height}}, row, bo)) return false;
+      idx = row;
+      if (la == 1) {
+        // fold_row: the line through (x0, e0), (-x0, e1) evaluated at beta; x0 = w^bitrev(idx) on the subgroup
+        const u32 x0 = bb_pow(bb_two_adic_generator(log_folded_height + 1), bitrev_host(idx, log_folded_height));
+        const u32 x1 = bb_neg(x0);
+        const E4 slope = e4_mul_base(e4_sub(evals[1], evals[0]), bb_inv(bb_sub(x1, x0)));
+        E4 bx = betas[i];
+        bx.c[0] = bb_sub(bx.c[0], x0);
+        folded = e4_add(evals[0], e4_mul(bx, slope));
+      } else {
+        // position j of the row holds the value at h_j = x w^bitrev(j), w of order m = 2^la, x = w_{2^log_height}^bitrev(row); fold_row
+        // is the polynomial of degree < m through them at beta, in barycentric form over the coset x <w>:
+        // p(beta) = (beta^m - x^m) / (m x^m) * sum_j e_j h_j / (beta - h_j)
+        const u32 x = bb_pow(bb_two_adic_generator(log_height), bitrev_host(row, log_folded_height));
+        const u32 wm = bb_two_adic_generator(la);
+        E4 sum = e4_zero();
+        bool hit = false;
+        for (size_t j = 0; j < m && !hit; j++) {
+          const u32 h = bb_mul(x, bb_pow(wm, bitrev_host(j, la)));
+          E4 d = betas[i];
+          d.c[0] = bb_sub(d.c[0], h);
+          if (e4_is_zero(d)) {  // beta is one of the row's points
+            folded = evals[j];
+            hit = true;
+          } else {
+            sum = e4_add(sum, e4_mul(e4_mul_base(evals[j], h), e4_inv(d)));
+          }
+        }
+        if (!hit) {
+          const u32 xm = bb_pow(x, m);
+          E4 z = betas[i];
+          for (unsigned k = 0; k < la; k++) z = e4_square(z);
+          z.c[0] = bb_sub(z.c[0], xm);
+          folded = e4_mul(e4_mul_base(z, bb_inv(bb_mul(xm, bb_to_monty((u32)m)))), sum);
+        }
+      }
+      log_height = log_folded_height;
       if (it != ro.rend() && it->first == log_folded_height) {
-        folded = e4_add(folded, e4_mul(e4_square(betas[i]), it->second.second));  // roll-in factor beta^2
+        // roll-in factor: the next power of beta after the 2^la the fold used (beta^2 for a binary round)
+        E4 f = betas[i];
+        for (unsigned k = 0; k < la; k++) f = e4_square(f);
+        folded = e4_add(folded, e4_mul(f, it->second.second));
         ++it;
       }
     }

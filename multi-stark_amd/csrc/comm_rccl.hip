@@ -124,6 +124,11 @@ struct ms_comm_rccl {
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   uint64_t groups_issued = 0;
   bool failed = false;
+  // MSAMD_RCCL_SELF=1 (diagnostics, one-GPU boxes): a single rank still creates a communicator and sends its own block to
+  // itself through ncclSend / ncclRecv / ncclAllGather instead of copying it, so that every RCCL entry point this file
+  // binds - the dlsym'd signatures, the groups, the stream and event ordering around RCCL's kernels - runs on a box where
+  // RCCL refuses a second rank on the same device
+  bool self_peer = false;
   // An RCCL call of this rank has failed: the peers are waiting for operations that will never be issued. Abort the
   // communicator so that they get an error instead of a hang, and refuse further use of this transport.
   void fail() {
@@ -156,11 +161,11 @@ struct ms_comm_rccl {
   void exchange(const uint8_t* send, size_t send_stride, uint8_t* recv, size_t recv_stride, size_t n) {
     bytes_moved += n * (size_t)world;
     if (n == 0) return;
-    if (world > 1) {
+    if (world > 1 || self_peer) {
       try {
         GroupGuard grp;
         for (int k = 0; k < world; k++) {
-          if (k == rank) continue;
+          if (k == rank && !self_peer) continue;
           nccl_check(rccl().Send(send + (size_t)k * send_stride, n, ncclUint8, k, comm, stream), "ncclSend");
           nccl_check(rccl().Recv(recv + (size_t)k * recv_stride, n, ncclUint8, k, comm, stream), "ncclRecv");
         }
@@ -170,6 +175,7 @@ struct ms_comm_rccl {
         throw;
       }
     }
+    if (self_peer) return;
     // this rank's own block never leaves the device
     HIP_CHECK(hipMemcpyAsync(recv + (size_t)rank * recv_stride, send + (size_t)rank * send_stride, n, hipMemcpyDeviceToDevice, stream));
   }
@@ -179,18 +185,19 @@ struct ms_comm_rccl {
                      bool skip_self = false) {
     bytes_moved += seg * ncols * (size_t)(skip_self ? world - 1 : world);
     if (seg == 0 || ncols == 0) return;
-    if (world > 1) {
+    const bool self = self_peer && !skip_self;
+    if (world > 1 || self) {
       // every rank cuts the columns into the same groups, and inside a group every send has its receive on the peer: the
       // groups complete one after the other on all ranks. Group size bounded (7 peers x 7 columns x 2 = 98 operations for a
       // quarter of the stage-2 LDE at world 8; wider circuits would otherwise grow the group without limit).
-      const size_t per_col = 2 * (size_t)(world - 1);
+      const size_t per_col = 2 * (size_t)std::max(1, world - 1);
       const size_t cols_per_group = std::max<size_t>(1, max_group_ops() / per_col);
       try {
         for (size_t c0 = 0; c0 < ncols; c0 += cols_per_group) {
           const size_t c1 = std::min(ncols, c0 + cols_per_group);
           GroupGuard grp;
           for (int k = 0; k < world; k++) {
-            if (k == rank) continue;
+            if (k == rank && !self) continue;
             for (size_t c = c0; c < c1; c++) {
               nccl_check(rccl().Send(send + (size_t)k * sps + c * scs, seg, ncclUint8, k, comm, stream), "ncclSend");
               nccl_check(rccl().Recv(recv + (size_t)k * rps + c * rcs, seg, ncclUint8, k, comm, stream), "ncclRecv");
@@ -204,7 +211,7 @@ struct ms_comm_rccl {
         throw;
       }
     }
-    if (!skip_self)
+    if (!skip_self && !self)
       HIP_CHECK(hipMemcpy2DAsync(recv + (size_t)rank * rps, rcs, send + (size_t)rank * sps, scs, seg, ncols, hipMemcpyDeviceToDevice, stream));
   }
   // one rank's matrix handed out by row ranges (ms_comm.scatter_cols_start): the root sends ncols segments to every other
@@ -239,7 +246,7 @@ struct ms_comm_rccl {
   void gather(const void* send, void* recv, size_t n) {
     bytes_moved += n * (size_t)world;
     if (n == 0) return;
-    if (world > 1) {
+    if (world > 1 || self_peer) {
       try {
         nccl_check(rccl().AllGather(send, recv, n, ncclUint8, comm, stream), "ncclAllGather");
       } catch (...) {
@@ -352,7 +359,8 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
     c->world = world;
     HIP_CHECK(hipSetDevice(c->ctx->device));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (world > 1) {
+    c->self_peer = world == 1 && getenv("MSAMD_RCCL_SELF") != nullptr;
+    if (world > 1 || c->self_peer) {
       ncclUniqueId id;
       memcpy(&id, unique_id, sizeof(id));
       nccl_check(rccl().CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");

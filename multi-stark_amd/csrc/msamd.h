@@ -454,7 +454,10 @@ void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /
 // Merkle tree of one FRI layer: leaf i = BLAKE3 of the 32-byte row (cur[2i], cur[2i+1]) (ExtensionMmcs flattening)
 // With fc, the launch that produces the root also runs the challenger step of that round (see challenge_dev.h);
 // cur == nullptr means the leaf layer of t (already allocated) was written by fri_fold_dev.
-void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriChallenge* fc = nullptr);
+// log_arity: the round commits rows of 2^log_arity values (FriParameters::max_log_arity, src/types.rs:189-190); a row is hashed
+// as one BLAKE3 chunk, which bounds the arity at 64
+static const unsigned FRI_MAX_LOG_ARITY = 6;
+void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriChallenge* fc = nullptr, unsigned log_arity = 1);
 // gather: rows of column-major matrices and digest siblings for the query phase
 struct GatherReq {
   const void* base;   // matrix (u64) or digest layer
@@ -470,7 +473,7 @@ struct GatherSeg {
   const void* base;   // matrix (u64, column-major), digest layer, or FRI layer (E2)
   uint64_t stride;    // column stride for matrices
   uint32_t count;     // columns of a matrix row; ignored otherwise
-  uint32_t kind;      // 0 = matrix row, 1 = digest, 2 = one E2 value
+  uint32_t kind;      // 0 = matrix row, 1 = digest, 2 = one E2 value, 3 = `count` consecutive u64 words at element * count
   uint32_t shift;     // element index = (query_index >> shift) ^ flip
   uint32_t flip;
   uint64_t out_off;   // byte offset inside one query's block

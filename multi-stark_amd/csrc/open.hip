@@ -412,6 +412,28 @@ __global__ __launch_bounds__(256) void fri_leaf_hash_k(const E2* __restrict__ cu
   q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+// the same for a round of arity 2^log_arity >= 4 (FriParameters::max_log_arity > 1): row i is the 2^log_arity consecutive
+// values cur[i 2^a ..], 16 bytes each - whole 64-byte blocks of ONE chunk (a <= 6, checked by the caller)
+__global__ __launch_bounds__(256) void fri_leaf_hash_wide_k(const E2* __restrict__ cur, size_t rows, unsigned log_arity, Digest* __restrict__ out) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (i >= rows) return;
+  const u32 nb = 1u << (log_arity - 2);
+  const uint4* src = reinterpret_cast<const uint4*>(cur + (i << log_arity));
+  u32 cv[8];
+  b3_iv(cv);
+  for (u32 b = 0; b < nb; b++) {
+    u32 m[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint4 v = src[4 * b + k];
+      m[4 * k] = v.x, m[4 * k + 1] = v.y, m[4 * k + 2] = v.z, m[4 * k + 3] = v.w;
+    }
+    b3_compress(cv, m, 0, 64, (b == 0 ? B3_CHUNK_START : 0u) | (b == nb - 1 ? (B3_CHUNK_END | B3_ROOT) : 0u));
+  }
+  uint4* q = reinterpret_cast<uint4*>(out + i);
+  q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+  q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
 
 // Fold with the challenge still on the device (rec->beta written by the previous round's challenger step) and,
 // when LEAF, the next round's leaf digests in the same pass: thread j produces out[2j], out[2j+1] (one FRI row of
@@ -742,6 +764,10 @@ __global__ void gather_queries_k(const GatherSeg* __restrict__ segs, const u64* 
   } else if (s.kind == 1) {
     const u32* d = (const u32*)((const Digest*)s.base + e);
     if (threadIdx.x < 8) ((u32*)o)[threadIdx.x] = d[threadIdx.x];
+  } else if (s.kind == 3) {
+    const u64* m = (const u64*)s.base + e * s.count;
+    u64* ow = (u64*)o;
+    for (u32 c = threadIdx.x; c < s.count; c += blockDim.x) ow[c] = m[c];
   } else {
     const u32* d = (const u32*)((const E2*)s.base + e);
     if (threadIdx.x < 4) ((u32*)o)[threadIdx.x] = d[threadIdx.x];
@@ -896,12 +922,16 @@ void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in, 
   HIP_CHECK(hipGetLastError());
 }
 
-void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriChallenge* fc) {
+void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriChallenge* fc, unsigned log_arity) {
+  if (log_arity < 1 || log_arity > FRI_MAX_LOG_ARITY) throw std::runtime_error("FRI: round arity out of range");
   if (!t.digests.p) merkle_alloc(ctx, t, rows);  // already allocated when the fold wrote the leaf layer
   if (cur) {
     hipEvent_t ev = ctx.prof_begin(K_LEAF_HASH);
-    hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.base());
-    ctx.prof_end(K_LEAF_HASH, ev, 64.0 * rows);
+    if (log_arity == 1)
+      hipLaunchKernelGGL(fri_leaf_hash_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, t.base());
+    else
+      hipLaunchKernelGGL(fri_leaf_hash_wide_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, log_arity, t.base());
+    ctx.prof_end(K_LEAF_HASH, ev, (32.0 + 16.0 * double(1u << log_arity)) * rows);
     HIP_CHECK(hipGetLastError());
   }
   merkle_compress_plain(ctx, t, fc);

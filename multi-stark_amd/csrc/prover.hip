@@ -213,7 +213,7 @@ std::unique_ptr<HSystem> system_from_blob(Ctx& ctx, const uint8_t* blob, size_t 
   p.num_queries = rd.word();
   p.commit_pow_bits = rd.word();
   p.query_pow_bits = rd.word();
-  if (p.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 (binary folding) is supported");
+  if (p.max_log_arity < 1 || p.max_log_arity > FRI_MAX_LOG_ARITY) throw std::runtime_error("max_log_arity must be 1 .. 6 (a FRI row is hashed as one BLAKE3 chunk)");
   if (p.log_blowup < 1 || p.log_blowup > 8) throw std::runtime_error("log_blowup out of range");
   if (p.commit_pow_bits > 40 || p.query_pow_bits > 40) throw std::runtime_error("proof-of-work bits out of range");
   {
@@ -1052,7 +1052,7 @@ void add_gather_seg(std::vector<GatherSeg>& segs, size_t& out_off, const void* b
   q.flip = flip;
   q.out_off = out_off;
   segs.push_back(q);
-  out_off += kind == 0 ? size_t(count) * 8 : kind == 1 ? 32 : 16;
+  out_off += kind == 0 || kind == 3 ? size_t(count) * 8 : kind == 1 ? 32 : 16;
 }
 // Commit-phase rounds that ran BEFORE fri_prove on row shards spread over ranks (prover_sharded.inc): their commitments
 // and proof-of-work witnesses go in front of fri_prove's own, the query indices keep the full height, and each query's
@@ -1341,7 +1341,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       HIP_CHECK(hipMemsetAsync(ro.p, 0, h * sizeof(E2), ctx.stream));
     } else {
       Digest* leaves = nullptr;
-      if (inputs.empty() && h >= 8192 && !getenv("MSAMD_NO_DEEP_LEAVES")) {
+      if (inputs.empty() && h >= 8192 && prm.max_log_arity == 1 && !getenv("MSAMD_NO_DEEP_LEAVES")) {
         merkle_alloc(ctx, fri_round0, h / 2);
         leaves = fri_round0.base();
       }
@@ -1400,6 +1400,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   std::vector<DBuf<E2>> layer_bufs;   // owners of the folded vectors kept for the query phase
   std::vector<const E2*> layers;      // input vector of every commit-phase round
   std::vector<DTree> trees;
+  std::vector<unsigned> arities;      // log2 of every round's arity (1 on every path but the host-driven one)
   std::vector<std::vector<Digest>> commits;
   std::vector<u64> pow_w;
   DBuf<E2> folded = std::move(inputs[0]);
@@ -1412,8 +1413,9 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   // (true right after the alpha sample) every round's challenger step runs on the device (challenge_dev.h), so the
   // whole commit phase is submitted without a host synchronisation. The host then replays the transcript from
   // the returned roots / witnesses on its own challenger; the device values are checked, not trusted.
+  // (rounds of arity above 2, max_log_arity > 1, are host-driven: no call site of the reference folds wider, src/types.rs:189-190)
   const bool dev_rounds = folded.n > stop && prm.cap_height == 0 && ch.input.size() == 32 && prm.commit_pow_bits <= 16 &&
-                          !getenv("MSAMD_HOST_FRI");
+                          prm.max_log_arity == 1 && !getenv("MSAMD_HOST_FRI");
   // With a one-coefficient final polynomial the query phase's challenger work (observe the final polynomial, grind,
   // sample every index) also runs on the device and the openings are gathered from the device-side indices, so
   // the whole of FRI costs one host synchronisation; the host replay below checks witness and indices.
@@ -1526,16 +1528,22 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     }
     folded = DBuf<E2>();
   }
-  while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, or MSAMD_HOST_FRI)
-    size_t rows = folded.n / 2;
-    const bool prehashed = round0 && round0->digests.p && trees.empty() && layers.empty() && round0->layer_len[0] == rows;
+  const unsigned log_final_height = lb + (unsigned)prm.log_final_poly_len;
+  while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, max_log_arity > 1, or MSAMD_HOST_FRI)
+    // p3-fri compute_log_arity_for_round: as far as max_log_arity allows without stepping over the next input or the final height
+    const unsigned lh = log2_strict(folded.n);
+    unsigned la = std::min<unsigned>((unsigned)prm.max_log_arity, lh - log_final_height);
+    if (next_in < inputs.size()) la = std::min(la, lh - log2_strict(inputs[next_in].n));
+    if (la < 1) throw std::runtime_error("FRI: two inputs of one height");
+    size_t rows = folded.n >> la;
+    const bool prehashed = la == 1 && round0 && round0->digests.p && trees.empty() && layers.empty() && round0->layer_len[0] == rows;
     if (prehashed)
       trees.push_back(std::move(*round0));
     else
       trees.emplace_back();
     DTree& t = trees.back();
     t.cap_height = (unsigned)prm.cap_height;
-    fri_tree_build(ctx, t, prehashed ? nullptr : folded.p, rows);
+    fri_tree_build(ctx, t, prehashed ? nullptr : folded.p, rows, nullptr, la);
     bool found = false;
     u64 wit = 0;
     std::vector<Digest> cap = cap_and_grind(ctx, t, ch.input, (unsigned)prm.commit_pow_bits, &found, &wit);
@@ -1549,14 +1557,25 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
       pow_w.push_back(grind(ctx, ch, (unsigned)prm.commit_pow_bits));
     }
     E2 beta = ch.sample_ext();
-    DBuf<E2> nxt(ctx, rows);
+    // a round of arity 2^la is la binary folds with beta, beta^2, beta^4, ... (the value at beta of the polynomial of degree
+    // < 2^la through a row); the vector rolled in behind it takes beta^(2^la) - the square of the last step's challenge
     const E2* roll = nullptr;
     if (next_in < inputs.size() && inputs[next_in].n == rows) roll = inputs[next_in].p;
-    fri_fold(ctx, folded.p, rows, beta, roll, nxt.p);
+    const E2* src = folded.p;
+    DBuf<E2> step;
+    for (unsigned j = 0; j < la; j++) {
+      const size_t out_rows = folded.n >> (j + 1);
+      DBuf<E2> nxt(ctx, out_rows);
+      fri_fold(ctx, src, out_rows, beta, j + 1 == la ? roll : nullptr, nxt.p);
+      beta = e2_sqr(beta);
+      step = std::move(nxt);  // (the previous intermediate vector is released behind the launch that read it: stream-ordered pool)
+      src = step.p;
+    }
     if (roll) next_in++;
     layers.push_back(folded.p);
+    arities.push_back(la);
     layer_bufs.push_back(std::move(folded));
-    folded = std::move(nxt);
+    folded = std::move(step);
   }
   if (next_in != inputs.size()) throw std::runtime_error("FRI: an input was never rolled in");
 
@@ -1568,12 +1587,21 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     out_off = input_qbytes;
   }
   auto n_siblings = [](const DTree& t) { return t.cap_layer(); };
-  for (size_t i = 0; i < trees.size(); i++) {
-    // sibling value of round i sits at element (index >> i) ^ 1 of that round's vector (rounds count from the head's)
-    const uint32_t gr = (uint32_t)i + head_rounds;
-    add_gather_seg(segs, out_off, layers[i], 0, 1, 2, gr, 1);
-    const DTree& t = trees[i];
-    for (size_t l = 0; l < n_siblings(t); l++) add_gather_seg(segs, out_off, t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(gr + 1 + l), 1);
+  arities.resize(trees.size(), 1);
+  {
+    uint32_t gr = head_rounds;  // index bits consumed by the rounds before this one (rounds count from the head's)
+    for (size_t i = 0; i < trees.size(); i++) {
+      const unsigned la = arities[i];
+      // binary round: the sibling value sits at element (index >> gr) ^ 1 of the round's vector; wider: the whole row
+      // (index >> gr) >> la is fetched and the queried position's own value dropped when the bytes are written
+      if (la == 1)
+        add_gather_seg(segs, out_off, layers[i], 0, 1, 2, gr, 1);
+      else
+        add_gather_seg(segs, out_off, layers[i], 0, 2u << la, 3, gr + la, 0);
+      const DTree& t = trees[i];
+      for (size_t l = 0; l < n_siblings(t); l++) add_gather_seg(segs, out_off, t.base() + t.layer_off[l], 0, 1, 1, (uint32_t)(gr + la + l), 1);
+      gr += la;
+    }
   }
   const size_t qbytes = out_off;
   const size_t nq = (size_t)prm.num_queries;
@@ -1721,11 +1749,21 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
       w.raw(ip, head->nsib[hr] * 32);
       ip += head->nsib[hr] * 32;
     }
+    uint64_t index_i = indices[qi] >> head_rounds;
     for (size_t i = 0; i < trees.size(); i++) {
-      w.u8(1);  // log_arity
-      w.u64_(1);
-      w.raw(&g[pos], 16);
-      pos += 16;
+      const unsigned la = arities[i];
+      w.u8((uint8_t)la);  // log_arity
+      w.u64_((size_t(1) << la) - 1);
+      if (la == 1) {
+        w.raw(&g[pos], 16);
+        pos += 16;
+      } else {  // the row without the queried position's own value
+        const size_t own = index_i & ((size_t(1) << la) - 1);
+        w.raw(&g[pos], own * 16);
+        w.raw(&g[pos + (own + 1) * 16], ((size_t(1) << la) - 1 - own) * 16);
+        pos += size_t(16) << la;
+      }
+      index_i >>= la;
       size_t ns = n_siblings(trees[i]);
       w.u64_(ns);
       w.raw(&g[pos], ns * 32);
@@ -2287,7 +2325,7 @@ void pcs_open_standalone(Ctx& ctx, const Params& prm, const std::vector<PcsData*
   HSystem sys;  // carries the context and the parameters only
   sys.ctx = &ctx;
   sys.params = prm;
-  if (prm.max_log_arity != 1) throw std::runtime_error("only max_log_arity = 1 (binary folding) is supported");
+  if (prm.max_log_arity < 1 || prm.max_log_arity > FRI_MAX_LOG_ARITY) throw std::runtime_error("max_log_arity must be 1 .. 6 (a FRI row is hashed as one BLAKE3 chunk)");
   if (prm.log_blowup < 1 || prm.log_blowup > 8) throw std::runtime_error("log_blowup out of range");
   if (prm.commit_pow_bits > 40 || prm.query_pow_bits > 40) throw std::runtime_error("proof-of-work bits out of range");
   std::vector<OpenRound> rounds;

@@ -88,7 +88,8 @@ struct BatchOpening {
   std::vector<Digest> path;
 };
 struct FriStep {
-  E2 sibling;
+  unsigned log_arity = 1;
+  std::vector<E2> siblings;  // the opened row without the queried position's own value: 2^log_arity - 1 values
   std::vector<Digest> path;
 };
 struct QueryProof {
@@ -131,9 +132,11 @@ void parse_fri(Reader& r, FriProofV& f) {
     }
     q.steps.resize(r.count(8));
     for (auto& st : q.steps) {
-      if (r.u8() != 1) throw Malformed();  // log_arity
-      if (r.u64_() != 1) throw Malformed();  // one sibling value
-      st.sibling = r.ext();
+      st.log_arity = r.u8();
+      if (st.log_arity < 1 || st.log_arity > FRI_MAX_LOG_ARITY) throw Malformed();
+      st.siblings.resize(r.count(16));
+      if (st.siblings.size() != (size_t(1) << st.log_arity) - 1) throw Malformed();
+      for (auto& e : st.siblings) e = r.ext();
       st.path.resize(r.count(32));
       for (auto& d : st.path) d = r.digest();
     }
@@ -250,7 +253,18 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
   const E2 alpha = ch.sample_ext();
   const size_t nrounds = proof.commits.size();
   if (proof.pow.size() != nrounds) return false;
-  const unsigned log_gmax = (unsigned)(nrounds + lb + prm.log_final_poly_len);
+  // every query repeats the rounds' arities; the first one's place the tallest input, and each is checked below against
+  // what the prover had to choose (p3-fri compute_log_arity_for_round) once the input heights are known
+  std::vector<unsigned> arities(nrounds, 1);
+  if (!proof.queries.empty()) {
+    if (proof.queries[0].steps.size() != nrounds) return false;
+    for (size_t i = 0; i < nrounds; i++) arities[i] = proof.queries[0].steps[i].log_arity;
+  }
+  unsigned log_gmax = (unsigned)(lb + prm.log_final_poly_len);
+  for (unsigned a : arities) {
+    if (a > prm.max_log_arity) return false;
+    log_gmax += a;
+  }
   if (log_gmax > GL_TWO_ADICITY) return false;  // no subgroup of that order: gl_two_adic_generator is defined up to 2^32
   std::vector<E2> betas;
   for (size_t i = 0; i < nrounds; i++) {
@@ -308,25 +322,70 @@ bool pcs_verify(const Params& prm, const std::vector<RoundClaim>& rounds, const 
     E2 folded = it->second.second;
     ++it;
     size_t idx = index;
+    unsigned log_height = log_gmax;
     for (size_t i = 0; i < nrounds; i++) {
-      const unsigned log_folded_height = log_gmax - 1 - (unsigned)i;
       const FriStep& st = qp.steps[i];
-      const size_t sib = idx ^ 1, pair = idx >> 1;
-      E2 evals[2];
-      evals[idx % 2] = folded;
-      evals[sib % 2] = st.sibling;
-      BatchOpening bo;
-      bo.rows.push_back({evals[0].c0, evals[0].c1, evals[1].c0, evals[1].c1});  // ExtensionMmcs: flattened row
-      bo.path = st.path;
-      if (!mmcs_verify_batch(proof.commits[i], {Dim{4, size_t(1) << log_folded_height}}, pair, bo)) return false;
-      idx = pair;
-      // fold_row: the line through (x0, e0), (-x0, e1) evaluated at beta; x0 = w^bitrev(idx) on the subgroup
-      const u64 x0 = gl_pow(gl_two_adic_generator(log_folded_height + 1), bitrev64(idx, log_folded_height));
-      const u64 x1 = gl_neg(x0);
-      const E2 slope = e2_mul_base(e2_sub(evals[1], evals[0]), gl_inv(gl_sub(x1, x0)));
-      folded = e2_add(evals[0], e2_mul(e2_sub(betas[i], e2(x0)), slope));
+      const unsigned la = st.log_arity;
+      if (la != arities[i] || log_height <= log_final_height) return false;
+      {  // the schedule: as far as max_log_arity allows without stepping over the next input or below the final height
+        unsigned want = std::min<unsigned>((unsigned)prm.max_log_arity, log_height - log_final_height);
+        if (it != ro.rend()) want = std::min(want, log_height - it->first);
+        if (la != want) return false;
+      }
+      const unsigned log_folded_height = log_height - la;
+      if (la == 1) {
+        const size_t sib = idx ^ 1, pair = idx >> 1;
+        E2 evals[2];
+        evals[idx % 2] = folded;
+        evals[sib % 2] = st.siblings[0];
+        BatchOpening bo;
+        bo.rows.push_back({evals[0].c0, evals[0].c1, evals[1].c0, evals[1].c1});  // ExtensionMmcs: flattened row
+        bo.path = st.path;
+        if (!mmcs_verify_batch(proof.commits[i], {Dim{4, size_t(1) << log_folded_height}}, pair, bo)) return false;
+        idx = pair;
+        // fold_row: the line through (x0, e0), (-x0, e1) evaluated at beta; x0 = w^bitrev(idx) on the subgroup
+        const u64 x0 = gl_pow(gl_two_adic_generator(log_folded_height + 1), bitrev64(idx, log_folded_height));
+        const u64 x1 = gl_neg(x0);
+        const E2 slope = e2_mul_base(e2_sub(evals[1], evals[0]), gl_inv(gl_sub(x1, x0)));
+        folded = e2_add(evals[0], e2_mul(e2_sub(betas[i], e2(x0)), slope));
+      } else {
+        // a row of 2^la values: position j holds the value at x w^bitrev(j), w of order 2^la, x = w_{2^log_height}^bitrev(row);
+        // fold_row is the polynomial of degree < 2^la through them at beta - barycentric form over the coset x <w>:
+        // p(beta) = (beta^m - x^m) / (m x^m) * sum_j e_j h_j / (beta - h_j)
+        const size_t m = size_t(1) << la, own = idx & (m - 1), row = idx >> la;
+        std::vector<E2> evals(m);
+        for (size_t j = 0, k = 0; j < m; j++) evals[j] = j == own ? folded : st.siblings[k++];
+        BatchOpening bo;
+        bo.rows.emplace_back();
+        for (auto& e : evals) bo.rows[0].push_back(e.c0), bo.rows[0].push_back(e.c1);
+        bo.path = st.path;
+        if (!mmcs_verify_batch(proof.commits[i], {Dim{2 * m, size_t(1) << log_folded_height}}, row, bo)) return false;
+        idx = row;
+        const u64 x = gl_pow(gl_two_adic_generator(log_height), bitrev64(row, log_folded_height));
+        const u64 wm = gl_two_adic_generator(la);
+        const E2 beta = betas[i];
+        E2 sum = e2(0);
+        bool hit = false;
+        for (size_t j = 0; j < m && !hit; j++) {
+          const u64 h = gl_mul(x, gl_pow(wm, bitrev64(j, la)));
+          const E2 d = e2_sub(beta, e2(h));
+          if (e2_is_zero(d)) {  // beta is one of the row's points
+            folded = evals[j];
+            hit = true;
+          } else {
+            sum = e2_add(sum, e2_mul(e2_mul_base(evals[j], h), e2_inv(d)));
+          }
+        }
+        if (!hit) {
+          const u64 xm = gl_pow(x, m);
+          const E2 z = e2_sub(e2_exp_pow2(beta, la), e2(xm));
+          folded = e2_mul(e2_mul_base(z, gl_inv(gl_mul(xm, (u64)m))), sum);
+        }
+      }
+      log_height = log_folded_height;
       if (it != ro.rend() && it->first == log_folded_height) {
-        folded = e2_add(folded, e2_mul(e2_sqr(betas[i]), it->second.second));  // roll-in factor beta^2
+        // roll-in factor: the next power of beta after the 2^la the fold used (beta^2 for a binary round)
+        folded = e2_add(folded, e2_mul(e2_exp_pow2(betas[i], la), it->second.second));
         ++it;
       }
     }
@@ -353,7 +412,7 @@ void mul2e(E2 a0, E2 a1, E2 b0, E2 b1, E2& c0, E2& c1) {
 bool pcs_verify_standalone(const Params& prm, const std::vector<std::vector<Digest>>& commits, const std::vector<std::vector<unsigned>>& log_n,
                            const std::vector<std::vector<size_t>>& widths, const std::vector<std::vector<std::vector<E2>>>& points,
                            const std::vector<E2>& opened_flat, const uint8_t* fri, size_t fri_len, Challenger& ch) {
-  if (prm.max_log_arity != 1 || prm.log_blowup < 1 || prm.log_blowup > 8) return false;
+  if (prm.max_log_arity < 1 || prm.max_log_arity > FRI_MAX_LOG_ARITY || prm.log_blowup < 1 || prm.log_blowup > 8) return false;
   FriProofV proof;
   try {
     Reader r{fri, fri_len};

@@ -13,6 +13,9 @@
 // Proof::to_bytes layout: the reference holds no golden vectors for them (src/types.rs:246-319 only
 // prints). Pinned here: BLAKE3 round function (reference KATs), the four identity pins of the reference
 // test-suite (restated in tests/), and prove -> verify self-consistency incl. tamper rejection.
+// FRI rounds of arity above 2 (FriParameters::max_log_arity > 1, src/types.rs:189-190: set by no call site of the reference) are
+// restated too - fri_log_arity_for_round, fri_fold_matrix_arity, fri_roll_in_factor in oracle_prove.cpp - equally unpinned; the
+// fold itself is checked against Lagrange interpolation by tests/test_oracle_fri_arity.py.
 #pragma once
 #include <array>
 #include <cstring>

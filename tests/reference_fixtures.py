@@ -25,6 +25,8 @@ TEST_PARAMS = [1, 0, 0, 1, 64, 0, 0]
 KNOWN_PARAMS = {
     "simple_proof_bench_params": [2, 0, 0, 1, 100, 10, 10],   # benches/multi_stark.rs:244-258
     "simple_proof_cap2_final4": [2, 2, 2, 1, 20, 3, 5],
+    "simple_proof_arity4": [1, 0, 0, 2, 20, 0, 0],            # FRI rounds of arity 4 / 8 (src/types.rs:189-190): no call site of the
+    "simple_proof_arity8_pow": [2, 1, 1, 3, 20, 3, 5],        # reference sets them; these two pin the restated wide rounds
 }
 
 
@@ -209,6 +211,10 @@ def emulate(path, oracle, oracle_bb, fe):
                [fe.pythagorean_trace(1024)], [], oracle)
     proof_case("fixture_dump::tests::simple_proof_cap2_final4", g, fe.pythagorean_inputs(), fe.Params(*KNOWN_PARAMS["simple_proof_cap2_final4"]),
                [fe.pythagorean_trace(256)], [], oracle)
+    proof_case("fixture_dump::tests::simple_proof_arity4", g, fe.pythagorean_inputs(), fe.Params(*KNOWN_PARAMS["simple_proof_arity4"]),
+               [fe.pythagorean_trace(256)], [], oracle)
+    proof_case("fixture_dump::tests::simple_proof_arity8_pow", g, fe.pythagorean_inputs(), fe.Params(*KNOWN_PARAMS["simple_proof_arity8_pow"]),
+               [fe.pythagorean_trace(512)], [], oracle)
     proof_case("lookup::tests::lookup_test", g, fe.even_odd_inputs(), fe.test_params(), fe.even_odd_traces(), [[0, 4, 1]], oracle)
     tr, cl = fe.u32_add_witness([(10, 5), (30, 20), (100, 100), (8000, 10000)])
     proof_case("test_circuits::u32_add::tests::u32_add_proof", g, fe.u32_add_system_inputs(), fe.test_params(), tr, [list(map(int, c)) for c in cl], oracle)

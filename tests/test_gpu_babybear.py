@@ -276,3 +276,32 @@ def test_config4_full_size(ctx):
     for _ in range(3):
         assert g.prove_multiple_claims(hw).to_bytes() == proof.to_bytes()
     assert g.prove_multiple_claims(w).to_bytes() == proof.to_bytes()  # and the device-resident one again on the same context
+
+
+@pytest.mark.parametrize("kw", [dict(log_blowup=1, max_log_arity=2), dict(log_blowup=2, max_log_arity=3, commit_proof_of_work_bits=3, query_proof_of_work_bits=2),
+                                dict(log_blowup=1, max_log_arity=4, log_final_poly_len=1, cap_height=1), dict(log_blowup=1, max_log_arity=6)])
+def test_wide_fri_folds(ctx, kw):
+    """FRI rounds of arity up to 2^max_log_arity (src/types.rs:189-190; baby_bear_config.rs:63,79 passes the field through):
+    mixed heights (the byte table's roll-in bounds a round's arity), lookups + claims, the MulAir; bytes == oracle, both
+    verifiers accept and agree on corrupted proofs; a binary-fold system refuses the bytes"""
+    params = fe.Params(num_queries=20, **kw)
+    with fe.field(fe.BABYBEAR):
+        inputs = fe.u32_add_system_inputs()
+        traces, claims = fe.u32_add_bench_witness(1 << 9)
+        verdict, g, o, packed, proof = _prove_both(ctx, params, inputs, traces, claims)
+        assert verdict == 0
+        rng = np.random.default_rng(17)
+        rejected = 0
+        for pos in [int(x) for x in rng.integers(0, len(proof), 40)]:
+            bad = bytearray(proof)
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            v = o.verify(packed, bytes(bad))
+            assert (v != 0) == (g.verify(packed, bytes(bad)) != 0), pos
+            rejected += v != 0
+        assert rejected >= 36  # (a proof-of-work witness is not read at zero bits: a flip there is accepted by both)
+        other = bb.System.new(ctx, fe.Params(num_queries=20, **dict(kw, max_log_arity=1)), inputs, K)
+        assert other.verify(packed, proof) != 0
+        assert _prove_both(ctx, params, fe.even_odd_inputs(), fe.even_odd_traces(), [[0, 4, 1]])[0] == 0
+        assert _prove_both(ctx, params, fe.mul_air_inputs(), [fe.mul_air_trace(1 << 11)], [])[0] == 0
+        with pytest.raises(pkg.MstarkError):
+            bb.System.new(ctx, fe.Params(max_log_arity=7), fe.mul_air_inputs(), K)

@@ -273,7 +273,7 @@ def test_pcs_open_error_paths(ctx, pkg):
     with pytest.raises(pkg.MstarkError):  # non-canonical point
         pkg.pcs_open(ctx, params, [(c, [[(P, 0)]])], pkg.Challenger(params))
     with pytest.raises(pkg.MstarkError):  # unsupported folding arity
-        pkg.pcs_open(ctx, _fe.Params(1, 0, 0, 2, 10, 0, 0), [(c, [[z]])], pkg.Challenger(params))
+        pkg.pcs_open(ctx, _fe.Params(1, 0, 0, 7, 10, 0, 0), [(c, [[z]])], pkg.Challenger(params))
     with pytest.raises(pkg.MstarkError):
         ch.observe([P])
     # a matrix that is not taller than blowup * final polynomial length is refused (p3 prove_fri precondition)

@@ -235,6 +235,47 @@ def test_native_rccl_transport_world_1(pkg, ctx, oracle, fe, var, log_adds, monk
         sharded.RcclComm(ctx, None, 3, 2)  # rank out of range
 
 
+_RCCL_SELF_SCRIPT = r"""
+import importlib, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from __graft_entry__ import load_package
+pkg = load_package(); fe = pkg.frontend
+sharded = importlib.import_module("multi_stark_amd.sharded")
+ctx = pkg.Context(0)
+for params, log_adds in ((fe.bench_params(), 12), (fe.Params(log_blowup=2, cap_height=0, log_final_poly_len=2, num_queries=20, commit_proof_of_work_bits=3,
+                                                             query_proof_of_work_bits=5), 10), (fe.bench_params(), 16)):
+    system = pkg.System.new(ctx, params, fe.multi_u32_add_system_inputs(1))
+    traces, claims = fe.multi_u32_add_witness(1, 1 << log_adds)
+    packed = fe.pack_claims(claims)
+    w = system.witness(traces, packed)
+    want = system.prove_multiple_claims(w).to_bytes()
+    comm = sharded.RcclComm(ctx, sharded.RcclComm.unique_id(), 0, 1)
+    for _ in range(3):
+        assert system.prove_sharded(w, comm, sharded.u32_add_owners(1)).to_bytes() == want
+    hw = system.host_witness(traces, packed)
+    assert system.prove_sharded(hw, comm, sharded.u32_add_owners(1)).to_bytes() == want
+    assert comm.bytes_moved > 0
+    comm.close()
+    print("rccl-self ok", log_adds, flush=True)
+"""
+
+
+@pytest.mark.parametrize("var", ["", "MSAMD_SHARDED_HOST_SYNC", "MSAMD_SHARDED_PACK", "MSAMD_SHARDED_GENERAL"])
+def test_native_rccl_transport_real_calls_to_self(var):
+    """MSAMD_RCCL_SELF=1: the single rank creates a real communicator (ncclCommInitRank) and every exchange of the joint prover
+    goes through ncclSend / ncclRecv to ITSELF and ncclAllGather - the only way to execute the RCCL transport's calls (dlsym'd
+    signatures, groups of up to 128 operations, stream / event ordering around RCCL's kernels) on a box with one GPU, where
+    RCCL refuses a second rank on the same device. In a child process under a hard time limit: a hang must not reach the box's."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MSAMD_RCCL_SELF="1", MSAMD_SHARDED_WORLD1_TRANSPORT="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if var:
+        env[var] = "1"
+    r = subprocess.run([sys.executable, "-c", _RCCL_SELF_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.count("rccl-self ok") == 3, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_native_rccl_unique_id(pkg):
     import importlib
 
@@ -251,6 +292,8 @@ def _params_for(fe, variant):
     if variant.startswith("cap"):  # commitments are 2^k-digest caps, 4-coefficient final polynomial, host-driven FRI rounds
         return fe.Params(log_blowup=2, cap_height=int(variant[3:]), log_final_poly_len=2, num_queries=20, commit_proof_of_work_bits=3,
                          query_proof_of_work_bits=5)
+    if variant.startswith("arity"):  # FRI rounds of arity 2^k (max_log_arity = k): no row-sharded FRI head, host-driven rounds
+        return fe.Params(log_blowup=2, max_log_arity=int(variant[5:]), num_queries=20, commit_proof_of_work_bits=3, query_proof_of_work_bits=5)
     return fe.bench_params()
 
 
@@ -294,7 +337,7 @@ def _thread_rank(pkg, fe, sharded, oracle, rank, group, log_adds, variant, share
 
 @pytest.mark.parametrize("world,log_adds,variant", [
     (8, 8, "bench"), (8, 10, "bench"), (8, 8, "cap3"), (8, 10, "cap3"), (8, 9, "cap1"), (8, 9, "pack"), (8, 9, "host-sync"),
-    (8, 9, "no-overlap"), (8, 9, "full-fri"), (2, 9, "bench"), (4, 10, "bench"), (4, 9, "pack"), (1, 9, "bench")])
+    (8, 9, "no-overlap"), (8, 9, "full-fri"), (2, 9, "bench"), (4, 10, "bench"), (4, 9, "pack"), (1, 9, "bench"), (4, 9, "arity3"), (8, 8, "arity2")])
 def test_thread_ranks_proof_equals_single_gpu_proof(pkg, fe, oracle, world, log_adds, variant, monkeypatch):
     import importlib
 

@@ -224,3 +224,29 @@ def test_claims_and_lookups_over_babybear():
         assert o.verify(packed, proof) == 0
         assert o.verify(fe.pack_claims([[0, 4, 0]]), proof) != 0
         assert o.verify(fe.pack_claims([]), proof) != 0
+
+
+@pytest.mark.parametrize("kw", [dict(log_blowup=1, max_log_arity=2), dict(log_blowup=2, max_log_arity=3, commit_proof_of_work_bits=3, cap_height=1),
+                                dict(log_blowup=1, max_log_arity=5, log_final_poly_len=1)])
+def test_wide_fri_folds_over_babybear(kw):
+    """max_log_arity > 1 (src/types.rs:189-190; baby_bear_config.rs:63,79 hands the field to p3-fri): prove -> verify, the step
+    arities in the proof, tamper rejection (the fold itself is pinned by tests/test_oracle_fri_arity.py on the other field)"""
+    import proof_codec as pc
+
+    params = fe.Params(num_queries=16, **kw)
+    with fe.field(fe.BABYBEAR):
+        o = _system(params, fe.u32_add_system_inputs())
+        traces, claims = fe.u32_add_bench_witness(1 << 7)
+        packed = fe.pack_claims(claims)
+        proof = o.prove(traces, packed)
+        assert o.verify(packed, proof) == 0
+        steps = [st["log_arity"] for st in pc.parse(proof, 4, 4)["opening_proof"]["query_proofs"][0]["commit_phase_openings"]]
+        assert max(steps) == min(params.max_log_arity, max(steps)) and max(steps) > 1 and len(steps) < 7 + 1 + params.log_blowup
+        rng = np.random.default_rng(9)
+        rejected = 0
+        for _ in range(40):
+            bad = bytearray(proof)
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            rejected += o.verify(packed, bytes(bad)) != 0
+        assert rejected >= 36  # (a proof-of-work witness is not read at zero bits: a flip there is accepted)
+        assert _system(fe.Params(num_queries=16, **dict(kw, max_log_arity=1)), fe.u32_add_system_inputs()).verify(packed, proof) != 0

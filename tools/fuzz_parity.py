@@ -88,7 +88,9 @@ def random_circuit(rng, fe, log_blowup):
 
 def one_case(pkg, fe, oracle, ctx, rng, case):
     lb = int(rng.integers(1, 4))
-    params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, 3)), log_final_poly_len=int(rng.choice([0, 0, 0, 1, 2])),
+    # FUZZ_ARITY=1: FRI rounds of arity up to 2^6 (drawn from the case number, so the rest of the case is the same system)
+    mla = 1 + int(np.random.default_rng(1000 + int(case)).integers(0, 6)) if os.environ.get("FUZZ_ARITY") and not os.environ.get("FUZZ_FIELD") else 1
+    params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, 3)), log_final_poly_len=int(rng.choice([0, 0, 0, 1, 2])), max_log_arity=mla,
                        num_queries=int(rng.integers(1, 24)), commit_proof_of_work_bits=int(rng.integers(0, 7)),
                        query_proof_of_work_bits=int(rng.integers(0, 7)))
     circuits, traces = [], []
