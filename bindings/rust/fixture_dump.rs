@@ -25,7 +25,8 @@
 //! `baby_bear_poseidon2_smoke_test` (`src/test_circuits/baby_bear_config.rs:159-206`), the Blake3 circuit
 //! (`src/test_circuits/blake3.rs:2215-2613`), `byte_test`, the verifier's cases ... plus the tests at the end of this file:
 //! the `gen_pcs_refs` / `gen_challenger_refs` scenarios of `src/types.rs:246-319` as JSON, `examples/simple_proof.rs` at
-//! 4 and 4096 rows and under the bench parameters (`benches/multi_stark.rs:244-258`: the proof-of-work path), and the
+//! 4 and 4096 rows, under the bench parameters (`benches/multi_stark.rs:244-258`: the proof-of-work path) and with
+//! `max_log_arity` 2 / 3 (FRI rounds of arity 4 / 8), and the
 //! Poseidon2 constants of the BabyBear configuration.
 //!
 //! A field element is written as its "serde word": the little-endian integer of the bytes `serde` gives it under the

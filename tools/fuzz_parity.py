@@ -5,6 +5,7 @@ is irrelevant for parity: both provers must still emit the same bytes, and both 
 
 usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips the hiprtc compile of every new circuit)
        FUZZ_BIG=1 ... wider and taller systems;  FUZZ_CLAIMS=1 ... more than 8192 claim words (device-side outer transcript)
+       FUZZ_ARITY=1 ... FriParameters::max_log_arity drawn from 1..6 (FRI rounds of arity up to 64)
        FUZZ_FIELD=babybear python3 tools/fuzz_parity.py ...   the same systems over the reference's second configuration
        (BabyBear / Poseidon2, include/mstark_bb.h) against oracle/libms_oracle_bb.so
 The oracle is used only as the checker."""
@@ -89,7 +90,7 @@ def random_circuit(rng, fe, log_blowup):
 def one_case(pkg, fe, oracle, ctx, rng, case):
     lb = int(rng.integers(1, 4))
     # FUZZ_ARITY=1: FRI rounds of arity up to 2^6 (drawn from the case number, so the rest of the case is the same system)
-    mla = 1 + int(np.random.default_rng(1000 + int(case)).integers(0, 6)) if os.environ.get("FUZZ_ARITY") and not os.environ.get("FUZZ_FIELD") else 1
+    mla = 1 + int(np.random.default_rng(1000 + int(case)).integers(0, 6)) if os.environ.get("FUZZ_ARITY") else 1
     params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, 3)), log_final_poly_len=int(rng.choice([0, 0, 0, 1, 2])), max_log_arity=mla,
                        num_queries=int(rng.integers(1, 24)), commit_proof_of_work_bits=int(rng.integers(0, 7)),
                        query_proof_of_work_bits=int(rng.integers(0, 7)))
