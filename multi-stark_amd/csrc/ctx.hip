@@ -335,11 +335,24 @@ void Ctx::trim() {
   pool_free_side.clear();
 }
 
+// MSAMD_SIDE_DELAY_US=n (diagnostics): every fork starts the side stream n microseconds late (one thread watching the
+// constant 100 MHz clock; it ends by itself). The side stream normally finishes well before the main stream, which hides a
+// missing join; with the delay a consumer on the main stream that does not wait for the side stream reads stale data every
+// time (tests/test_gpu_prove.py::test_side_stream_results_are_awaited).
+namespace {
+__global__ void side_delay_k(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
 void Ctx::side_config() {
   side_enabled = !getenv("MSAMD_NO_SIDE_STREAM");
   const char* v = getenv("MSAMD_SIDE_MAX_LOG");
   side_max_log = v ? (unsigned)atoi(v) : 12u;
   if (side_max_log > 40) side_max_log = 40;
+  const char* d = getenv("MSAMD_SIDE_DELAY_US");
+  side_delay_us = d ? (unsigned)std::min(atoi(d), 20000) : 0u;
 }
 
 void Ctx::side_fork() {
@@ -348,6 +361,10 @@ void Ctx::side_fork() {
   HIP_CHECK(hipEventRecord(side_ev[0], main_stream));
   HIP_CHECK(hipStreamWaitEvent(side_stream, side_ev[0], 0));
   side_forked = true;
+  if (side_delay_us) {
+    hipLaunchKernelGGL(side_delay_k, dim3(1), dim3(1), 0, side_stream, (unsigned long long)side_delay_us * 100ull);
+    HIP_CHECK(hipGetLastError());
+  }
 }
 
 void Ctx::side_join() {
@@ -462,10 +479,20 @@ void Ctx::h2d(void* dst, const void* src, size_t n) {
   HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
 }
 
+// A read-back that is issued at once (long segments, pageable destinations) is a copy on the CURRENT stream: queued on the main
+// stream while the side stream is still producing part of the source - the opened values of the short circuits beside the
+// long ones', pcs_open - it would read those values before they exist (seen as wrong opened values of exactly the side-stream
+// matrices in the FIRST proof of a wide system, when fresh allocations delay the side stream's launches; short segments are
+// copied by sync_and_deliver, which joins first). The main stream therefore waits for the side stream here.
+void Ctx::join_side_for_copy() {
+  if (side_forked && side_depth == 0) side_join();
+}
+
 void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   if (n == 0) return;
   size_t need = (n + 63) & ~size_t(63);
   if (!pinned || need > pinned_half) {
+    join_side_for_copy();
     HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));  // pageable: staged by the runtime
     down_direct = true;  // the next synchronisation has to be a real stream synchronisation
     return;
@@ -477,6 +504,7 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
     bool view_pending = false;
     for (auto& d : down_pending) view_pending = view_pending || d.dst == nullptr;
     if (view_pending) {
+      join_side_for_copy();
       HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
       down_direct = true;
       return;
@@ -492,6 +520,7 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   pd.n = n;
   pd.copied = false;
   if (!flag_host || n > (size_t(64) << 10)) {
+    join_side_for_copy();
     HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
     pd.copied = true;
     down_direct = true;
@@ -511,6 +540,7 @@ const uint8_t* Ctx::d2h_queue_staged(const void* src, size_t n) {
   pd.n = n;
   pd.copied = false;
   if (!flag_host || n > (size_t(64) << 10)) {
+    join_side_for_copy();
     HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
     pd.copied = true;
     down_direct = true;
