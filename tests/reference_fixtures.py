@@ -218,6 +218,13 @@ def emulate(path, oracle, oracle_bb, fe):
     proof_case("lookup::tests::lookup_test", g, fe.even_odd_inputs(), fe.test_params(), fe.even_odd_traces(), [[0, 4, 1]], oracle)
     tr, cl = fe.u32_add_witness([(10, 5), (30, 20), (100, 100), (8000, 10000)])
     proof_case("test_circuits::u32_add::tests::u32_add_proof", g, fe.u32_add_system_inputs(), fe.test_params(), tr, [list(map(int, c)) for c in cl], oracle)
+    # the reference's largest scenario (src/test_circuits/blake3.rs:2215-2340): nine circuits, one compression claim
+    import importlib
+
+    b3 = importlib.import_module("multi_stark_amd.blake3_circuit")
+    b3_claims = [b3.compression_claim(b3.blake3_compressions(bytes([0x54] * 64))[0][0])]
+    proof_case("test_circuits::blake3::tests::test_compression_reference_compatibility", g, b3.blake3_system_inputs(), fe.test_params(),
+               b3.blake3_witness(b3_claims), b3_claims, oracle)
     # an unknown test with proof-of-work: the consumer has to infer every parameter
     proof_case("somewhere::else::unknown_case", g, fe.pythagorean_inputs(), fe.Params(1, 1, 1, 1, 9, 2, 3), [fe.pythagorean_trace(64)], [], oracle)
     # BabyBear / Poseidon2: the constants line, then the reference's smoke test (baby_bear_config.rs:159-206)

@@ -167,6 +167,10 @@ def _frontend_inputs(fe, name):
         return fe.mul_air_inputs()
     if name == "byte_test":
         return fe.byte_operations_inputs()
+    if name in ("test_compression_reference_compatibility", "test_all_claims"):  # src/test_circuits/blake3.rs:2215-2613
+        import importlib
+
+        return importlib.import_module("multi_stark_amd.blake3_circuit").blake3_system_inputs()
     return None
 
 
