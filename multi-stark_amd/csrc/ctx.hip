@@ -338,7 +338,8 @@ void Ctx::trim() {
 // MSAMD_SIDE_DELAY_US=n (diagnostics): every fork starts the side stream n microseconds late (one thread watching the
 // constant 100 MHz clock; it ends by itself). The side stream normally finishes well before the main stream, which hides a
 // missing join; with the delay a consumer on the main stream that does not wait for the side stream reads stale data every
-// time (tests/test_gpu_prove.py::test_side_stream_results_are_awaited).
+// time (tests/test_blake3_circuit.py::test_side_stream_results_are_awaited). MSAMD_MAIN_DELAY_US=n delays the MAIN stream
+// behind every fork instead: a side-stream launch that reads what the main stream was given after the fork then fails.
 namespace {
 __global__ void side_delay_k(unsigned long long ticks) {
   const unsigned long long t0 = wall_clock64();
@@ -353,6 +354,8 @@ void Ctx::side_config() {
   if (side_max_log > 40) side_max_log = 40;
   const char* d = getenv("MSAMD_SIDE_DELAY_US");
   side_delay_us = d ? (unsigned)std::min(atoi(d), 20000) : 0u;
+  d = getenv("MSAMD_MAIN_DELAY_US");
+  main_delay_us = d ? (unsigned)std::min(atoi(d), 20000) : 0u;
 }
 
 void Ctx::side_fork() {
@@ -363,6 +366,10 @@ void Ctx::side_fork() {
   side_forked = true;
   if (side_delay_us) {
     hipLaunchKernelGGL(side_delay_k, dim3(1), dim3(1), 0, side_stream, (unsigned long long)side_delay_us * 100ull);
+    HIP_CHECK(hipGetLastError());
+  }
+  if (main_delay_us) {  // the other direction: the side stream runs ahead of what the main stream is given AFTER the fork
+    hipLaunchKernelGGL(side_delay_k, dim3(1), dim3(1), 0, main_stream, (unsigned long long)main_delay_us * 100ull);
     HIP_CHECK(hipGetLastError());
   }
 }

@@ -175,12 +175,13 @@ def test_gpu_joint_proof_over_thread_ranks(pkg, fe, b3, compiled, oracle):
 
 
 @pytest.mark.gpu
-def test_side_stream_results_are_awaited(pkg, ctx, fe, b3, compiled, oracle, monkeypatch):
+@pytest.mark.parametrize("which", ["MSAMD_SIDE_DELAY_US", "MSAMD_MAIN_DELAY_US"])
+def test_side_stream_results_are_awaited(pkg, ctx, fe, b3, compiled, oracle, monkeypatch, which):
     """MSAMD_SIDE_DELAY_US: the side stream (short circuits beside long ones) starts 2 ms late at every fork, so a consumer on
     the main stream that does not wait for it reads stale data every time. Found with this system: more than 64 KB of opened
     values are read back by a copy issued at once on the main stream, which did not wait for the side stream's barycentric sums
     (the first proof of a new shape, slowed by fresh allocations, opened the short circuits at wrong values)."""
-    monkeypatch.setenv("MSAMD_SIDE_DELAY_US", "2000")
+    monkeypatch.setenv(which, "2000")  # (the second switch delays the main stream behind every fork: the other direction)
     # two witnesses in turn: a stale buffer of the previous proof must not pass for this proof's values
     sets = []
     for data in (bytes(range(256)) * 11 + bytes(184), bytes((7 * i + 1) & 255 for i in range(3000))):
