@@ -5,6 +5,7 @@ is irrelevant for parity: both provers must still emit the same bytes, and both 
 
 usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips the hiprtc compile of every new circuit)
        FUZZ_BIG=1 ... wider and taller systems;  FUZZ_CLAIMS=1 ... more than 8192 claim words (device-side outer transcript)
+       FUZZ_MANY=1 ... systems of 4 .. 40 circuits
        FUZZ_ARITY=1 ... FriParameters::max_log_arity drawn from 1..6 (FRI rounds of arity up to 64)
        FUZZ_FIELD=babybear python3 tools/fuzz_parity.py ...   the same systems over the reference's second configuration
        (BabyBear / Poseidon2, include/mstark_bb.h) against oracle/libms_oracle_bb.so
@@ -95,7 +96,9 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
                        num_queries=int(rng.integers(1, 24)), commit_proof_of_work_bits=int(rng.integers(0, 7)),
                        query_proof_of_work_bits=int(rng.integers(0, 7)))
     circuits, traces = [], []
-    for _ in range(int(rng.integers(1, 4))):
+    # FUZZ_MANY=1: systems of 4 .. 40 circuits (many trace heights, many FRI inputs, long matrix lists) instead of 1 .. 3
+    n_circuits = int(np.random.default_rng(2000 + int(case)).integers(4, 41)) if os.environ.get("FUZZ_MANY") else int(rng.integers(1, 4))
+    for _ in range(n_circuits):
         ci, w, fixed_h = random_circuit(rng, fe, lb)
         circuits.append(ci)
         h = fixed_h if fixed_h else 1 << int(rng.integers(0, 16 if BIG else 11))
