@@ -374,6 +374,13 @@ struct DProgram {
   DBuf<uint32_t> lookup_slots;   // per lookup: mult slot, nargs, arg slots...
   size_t n_zeros = 0, n_lookups = 0, constraint_count = 0;
   size_t main_w = 0, pre_w = 0, s2_w = 0;
+  // the same program scheduled by dependency level for ONE WAVE PER ROW (quotient.hip::quotient_wave_k; large programs
+  // only): 64 nodes of a level per step, slot = position, levels padded to whole steps
+  DBuf<uint32_t> wave_code;      // 4 words per position: kind, 1 on the last step of a level, operand a, operand b
+  DBuf<uint32_t> wave_zero_pos;  // position of each user constraint root
+  DBuf<uint32_t> wave_lookups;   // per lookup: mult position, nargs, arg positions...
+  DBuf<uint32_t> wave_lookup_off;  // where each lookup starts in wave_lookups
+  size_t wave_steps = 0, wave_leaf_steps = 0;
 };
 struct QDyn;  // quotient_params.h: the challenge-dependent part of a quotient launch, in device memory
 struct QuotientArgs {

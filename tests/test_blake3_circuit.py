@@ -204,3 +204,20 @@ def test_side_stream_results_are_awaited(pkg, ctx, fe, b3, compiled, oracle, mon
         want = oracle.System(g.blob).prove(tr, pk)
         assert g.prove_multiple_claims(g.witness(tr, pk)).to_bytes() == want
         assert g.prove_multiple_claims(g.host_witness(tr, pk)).to_bytes() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [(), ("MSAMD_NO_WAVE_QUOTIENT",), ("MSAMD_NO_WAVE_QUOTIENT", "MSAMD_NO_FEW_LANES")])
+def test_interpreter_forms_give_the_same_proof(pkg, ctx, fe, b3, compiled, oracle, monkeypatch, env):
+    """the compression circuit's 6952-node program is above the hiprtc limit: a short circuit takes the wave-per-row kernel over the
+    level-scheduled program (quotient_wave_k); without it few lanes per workgroup with the slot files in LDS; without that the
+    thread-per-row interpreter over a global slot file - and a 2^14-row trace of the same circuit takes the last by itself"""
+    for e in env:
+        monkeypatch.setenv(e, "1")
+    infos, dig = b3.blake3_compressions(bytes((5 * i + 2) & 255 for i in range(4000)))
+    claims = [b3.compression_claim(i) for i in infos]
+    traces = b3.blake3_witness(claims)
+    packed = fe.pack_claims(claims)
+    for params in (fe.test_params(), fe.Params(log_blowup=2, cap_height=1, num_queries=12, commit_proof_of_work_bits=3)):
+        g = pkg.System.new(ctx, params, compiled[0])
+        assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == oracle.System(g.blob).prove(traces, packed)
