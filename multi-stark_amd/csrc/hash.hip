@@ -193,6 +193,80 @@ __global__ __launch_bounds__(256) void leaf_hash_single_k(const u64* __restrict_
   store_digest(out + row, cv);
 }
 
+// ---- rows far longer than one BLAKE3 chunk on FEW rows (the 2625-column matrix of the reference's BLAKE3 system injected at a
+// 1024-row level: 21 chunks per row): a thread per row hashes its 328 blocks one after the other - 390 us of latency on a
+// thousand threads. BLAKE3 is a tree hash: one thread per (row, chunk) computes the chunk's chaining value, one thread per
+// row then merges them (the stack discipline of hash_row<true>), and the tree kernels read the finished row digests.
+__global__ __launch_bounds__(256) void wide_rows_chunk_k(const MatRef* __restrict__ g, size_t H, size_t rows, u32 total_w, u32 nchunks,
+                                                         Digest* __restrict__ cvs) {
+  const size_t id = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (id >= rows * nchunks) return;
+  const size_t row = id / nchunks;
+  const u32 chunk = (u32)(id % nchunks);
+  const u32 e0 = chunk * 128, e1 = min(total_w, e0 + 128);
+  RowIter it{g, H, row, 0, 0, nullptr, 0, 0};
+  it.init();
+  {  // seek to element e0 of the concatenated row
+    u32 skip = e0;
+    while (skip >= it.w) {
+      skip -= it.w;
+      it.mi++;
+      it.cur = g[it.mi].d + row;
+      it.w = g[it.mi].w;
+      it.stride = g[it.mi].stride;
+    }
+    it.c = skip;
+    it.cur += size_t(skip) * it.stride;
+  }
+  u32 cv[8];
+  b3_iv(cv);
+  const u32 nblocks = (e1 - e0 + 7) >> 3;
+  for (u32 b = 0; b < nblocks; b++) {
+    const u32 nv = min(8u, e1 - e0 - 8 * b);
+    u32 m[16];
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+      const u64 v = j < nv ? it.next() : 0;
+      m[2 * j] = (u32)v;
+      m[2 * j + 1] = (u32)(v >> 32);
+    }
+    b3_compress(cv, m, chunk, nv * 8, (b == 0 ? B3_CHUNK_START : 0u) | (b + 1 == nblocks ? B3_CHUNK_END : 0u));
+  }
+  store_digest(cvs + id, cv);
+}
+__global__ __launch_bounds__(256) void wide_rows_merge_k(const Digest* __restrict__ cvs, size_t rows, u32 nchunks, Digest* __restrict__ out) {
+  const size_t row = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (row >= rows) return;
+  u32 stack[8 * 12];  // sub-tree roots of the chunks so far (2^12 chunks = 4 MiB rows)
+  u32 stack_len = 0, cv[8];
+  for (u32 c = 0; c + 1 < nchunks; c++) {
+    load_digest(cvs + row * nchunks + c, cv);
+    for (u32 total = c + 1; (total & 1) == 0; total >>= 1) {
+      u32 l[8], t[8];
+      stack_len--;
+#pragma unroll
+      for (int i = 0; i < 8; i++) l[i] = stack[stack_len * 8 + i];
+      parent_cv(l, cv, 0, t);
+#pragma unroll
+      for (int i = 0; i < 8; i++) cv[i] = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) stack[stack_len * 8 + i] = cv[i];
+    stack_len++;
+  }
+  load_digest(cvs + row * nchunks + (nchunks - 1), cv);
+  while (stack_len > 0) {
+    u32 l[8], t[8];
+    stack_len--;
+#pragma unroll
+    for (int i = 0; i < 8; i++) l[i] = stack[stack_len * 8 + i];
+    parent_cv(l, cv, stack_len == 0 ? B3_ROOT : 0, t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = t[i];
+  }
+  store_digest(out + row, cv);
+}
+
 // next[i] = compress(prev[2i], prev[2i+1]); with an injected group: compress(that, hash(rows i))
 template <bool INJECT, bool MULTI>
 __global__ __launch_bounds__(256) void compress_layer_k(const Digest* __restrict__ prev, Digest* __restrict__ next, size_t n,
@@ -370,6 +444,7 @@ struct SubtreeParams {
   FriChallenge fc;
   FoldArgs fold;            // FOLD: out has 2 * len elements, cur 4 * len
   const FriTailRound* prev; // FOLD: the round whose beta folds
+  const Digest* inj_hashed; // the injected group's row digests, already computed (wide_rows_*_k); null = hash the rows here
 };
 
 // one level of a sub-tree held in LDS: n nodes from 2n children at sh (digest i at sh + 8 i), results back to sh[0 .. n)
@@ -385,7 +460,9 @@ __device__ __forceinline__ void tree_level(u32* sh, u32 n, Digest* gout, const S
       lds_load_digest(sh, 2 * t, l);
       lds_load_digest(sh, 2 * t + 1, r);
       b3_compress_pair_root(l, r, e);
-      if (p.inj_multi)
+      if (p.inj_hashed)
+        load_digest(p.inj_hashed + (gfirst + t), rh);
+      else if (p.inj_multi)
         hash_row<true>(p.g, glen, gfirst + t, p.inj_w, rh);
       else
         hash_row<false>(p.g, glen, gfirst + t, p.inj_w, rh);
@@ -445,7 +522,9 @@ __global__ __launch_bounds__(1024) void subtree_k(SubtreeParams p) {
     b3_compress_pair_root(l, r, d);
     if (INJ && p.inj_len == glen) {
       u32 rh[8], e[8];
-      if (p.inj_multi)
+      if (p.inj_hashed)
+        load_digest(p.inj_hashed + (size_t(b) * 1024 + t), rh);
+      else if (p.inj_multi)
         hash_row<true>(p.g, glen, size_t(b) * 1024 + t, p.inj_w, rh);
       else
         hash_row<false>(p.g, glen, size_t(b) * 1024 + t, p.inj_w, rh);
@@ -745,6 +824,21 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
         sp.g = n_inj ? drefs + inj[inj_li].first : nullptr;
         sp.inj_w = n_inj ? inj[inj_li].total_w : 0u;
         sp.inj_multi = n_inj && inj[inj_li].total_w > 128 ? 1u : 0u;
+        // few rows of many chunks each: the row digests are computed chunk-parallel in front of the tree launch
+        DBuf<Digest> wide_cvs, wide_rows;
+        if (sp.inj_multi && sp.inj_len <= 16384 && sp.inj_w >= 512 && !getenv("MSAMD_NO_WIDE_PREHASH")) {
+          const size_t rows = sp.inj_len;
+          const u32 nchunks = (sp.inj_w + 127) / 128;
+          wide_cvs = DBuf<Digest>(ctx, rows * nchunks);
+          wide_rows = DBuf<Digest>(ctx, rows);
+          hipEvent_t evw = ctx.prof_begin(K_LEAF_HASH);
+          hipLaunchKernelGGL(wide_rows_chunk_k, dim3((unsigned)((rows * nchunks + 255) / 256)), dim3(256), 0, ctx.stream, sp.g, rows, rows, sp.inj_w,
+                             nchunks, wide_cvs.p);
+          hipLaunchKernelGGL(wide_rows_merge_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx.stream, wide_cvs.p, rows, nchunks, wide_rows.p);
+          ctx.prof_end(K_LEAF_HASH, evw, 8.0 * sp.inj_w * rows);
+          HIP_CHECK(hipGetLastError());
+          sp.inj_hashed = wide_rows.p;
+        }
         sp.counter = tree_counter_slot(ctx);
         sp.fc = fc ? *fc : FriChallenge{};
         const unsigned nb = (unsigned)(child_len / sp.sub);

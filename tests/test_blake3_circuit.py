@@ -207,11 +207,12 @@ def test_side_stream_results_are_awaited(pkg, ctx, fe, b3, compiled, oracle, mon
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [(), ("MSAMD_NO_WAVE_QUOTIENT",), ("MSAMD_NO_WAVE_QUOTIENT", "MSAMD_NO_FEW_LANES")])
+@pytest.mark.parametrize("env", [(), ("MSAMD_NO_WAVE_QUOTIENT",), ("MSAMD_NO_WAVE_QUOTIENT", "MSAMD_NO_FEW_LANES"), ("MSAMD_NO_WIDE_PREHASH",)])
 def test_interpreter_forms_give_the_same_proof(pkg, ctx, fe, b3, compiled, oracle, monkeypatch, env):
     """the compression circuit's 6952-node program is above the hiprtc limit: a short circuit takes the wave-per-row kernel over the
     level-scheduled program (quotient_wave_k); without it few lanes per workgroup with the slot files in LDS; without that the
-    thread-per-row interpreter over a global slot file - and a 2^14-row trace of the same circuit takes the last by itself"""
+    thread-per-row interpreter over a global slot file. MSAMD_NO_WIDE_PREHASH: the 2625-column rows injected into the commitment
+    trees are hashed by one thread each inside the tree kernel instead of chunk-parallel in front of it (hash.hip)"""
     for e in env:
         monkeypatch.setenv(e, "1")
     infos, dig = b3.blake3_compressions(bytes((5 * i + 2) & 255 for i in range(4000)))

@@ -88,6 +88,12 @@ def test_blake3_stream(ctx, oracle, n):
     [(4096, 1), (1, 3)],
     [(1 << 15, 1), (1 << 13, 2), (4, 1)],
     [(1 << 17, 2), (1 << 9, 5)],
+    # few rows of many BLAKE3 chunks each, injected: chunk-parallel row digests in front of the tree launch (wide_rows_*_k) -
+    # one matrix, a group of three whose chunks straddle the matrices, a last chunk of one element, the first level
+    [(1 << 12, 3), (1 << 8, 700)],
+    [(1 << 13, 2), (1 << 7, 300), (1 << 7, 129), (1 << 7, 212)],
+    [(1 << 11, 1), (1 << 10, 513)],
+    [(1 << 14, 1), (4, 2625)],
 ])
 @pytest.mark.parametrize("cap_height", [0, 2])
 def test_mmcs_commit_open(pkg, ctx, oracle, shapes, cap_height):
