@@ -620,15 +620,18 @@ __global__ void transpose_in_k(const u64* __restrict__ in, u64* __restrict__ out
 // rr = (A : mid : B), A the top and B the low four bits, i.e. natural rows (rev B : rev mid : rev A): for each of the 16
 // values of B the 16 values of A are CONSECUTIVE input rows (one run of 16 w words), and for each A the 16 values of B
 // are consecutive storage rows (128-byte runs per column). Columns go through LDS 16 at a time.
+// (blockIdx.y: a short, wide matrix - 512 rows x 2625 columns in the reference's BLAKE3 system - gives only h / 256 row blocks, so
+// the columns are dealt out over a second grid dimension, cols_per_block at a time, instead of one block walking all of them)
 __global__ __launch_bounds__(256) void transpose_in_br_k(const u64* __restrict__ in, u64* __restrict__ out, size_t h, size_t w,
-                                                         unsigned logh) {
+                                                         unsigned logh, u32 cols_per_block) {
   __shared__ u64 tile[256][17];
   const u32 mid = blockIdx.x;
   const size_t rmid = size_t(bitrev32(mid, logh - 8)) << 4;
   const u32 t = threadIdx.x;
   const u32 lo = t & 15, hi = t >> 4;
-  for (size_t c0 = 0; c0 < w; c0 += 16) {
-    const u32 cols = (u32)((w - c0) < 16 ? (w - c0) : 16);
+  const size_t c_begin = size_t(blockIdx.y) * cols_per_block, c_end = min(w, c_begin + cols_per_block);
+  for (size_t c0 = c_begin; c0 < c_end; c0 += 16) {
+    const u32 cols = (u32)((c_end - c0) < 16 ? (c_end - c0) : 16);
     // read: thread (hi = natural low bits a, lo = column), 16 runs u = natural top bits
     if (lo < cols) {
       const u32 A = bitrev32(hi, 4);
@@ -773,7 +776,14 @@ void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t
   hipEvent_t ev = ctx.prof_begin(K_TRANSPOSE);
   const unsigned logh = log2_strict(h);
   if (bitrev_rows && logh >= 8 && (size_t(1) << logh) == h && !getenv("MSAMD_OLD_TRANSPOSE"))
-    hipLaunchKernelGGL(transpose_in_br_k, dim3((unsigned)(h >> 8)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh);
+  {
+    const size_t bx = h >> 8, col_tiles = (w + 15) / 16;
+    size_t by = bx < 1024 ? std::min(col_tiles, (1024 + bx - 1) / bx) : 1;  // about a thousand workgroups at least
+    const size_t tiles_per_block = (col_tiles + by - 1) / by;
+    by = (col_tiles + tiles_per_block - 1) / tiles_per_block;
+    hipLaunchKernelGGL(transpose_in_br_k, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
+                       (u32)(tiles_per_block * 16));
+  }
   else
     hipLaunchKernelGGL(transpose_in_k, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
                        bitrev_rows ? 1 : 0);
