@@ -356,6 +356,82 @@ __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64*
   }
 }
 
+// ---- strided passes of 1 .. 6 bits entirely in registers (heights that are not 12 + 8 k bits: 2^13 .. 2^19 rows, the last
+// strided pass of 2^26). Every root of unity of order <= 64 is a power of two (w_64 = 2^39, w_32 = 2^78, w_16 = 2^156, ... ;
+// 2 has order 192), so a 2^K-point sub-transform costs additions and SHIFTS only: a thread owns the 2^K values of one position
+// l (stride S apart; the lanes of a wave own consecutive l: every access is a 512-byte run), runs the K radix-2 stages in
+// registers without any exchange, and multiplies by the inter-pass twiddle w_B^(l bitrev_K(h)) - the same arithmetic as
+// ntt_strided_k's K barrier-separated LDS stages, which this replaces (37 -> us per launch on the reference's BLAKE3 system).
+template <int K, bool DIT, bool INV>
+__device__ __forceinline__ void reg_stages_small(u64 (&x)[1 << K]) {
+  // exponent e with w_{2^K} = 2^e for the forward transform (the inverse root is 2^(192 - e))
+  constexpr unsigned EF = K == 1 ? 96u : K == 2 ? 48u : K == 3 ? 120u : K == 4 ? 156u : K == 5 ? 78u : 39u;
+  constexpr unsigned E = INV ? 192u - EF : EF;
+  constexpr int N = 1 << K;
+#pragma unroll
+  for (int s = 0; s < K; s++) {
+    const int loghalf = DIT ? s : K - 1 - s;
+    const int half = 1 << loghalf;
+#pragma unroll
+    for (int jl = 0; jl < half; jl++) {
+      // twiddle w_{2 half}^jl = w_{2^K}^(jl 2^(K-1) / half), a signed power of two
+      const unsigned kk = (E * (unsigned)(jl * ((N / 2) / half))) % 192u;
+      const bool neg = kk >= 96;
+      const unsigned k = neg ? kk - 96 : kk;
+#pragma unroll
+      for (int g = 0; g < (N / 2) / half; g++) {
+        const int j0 = g * 2 * half + jl, j1 = j0 + half;
+        const u64 a = x[j0], b = x[j1];
+        if (DIT) {
+          const u64 t = gl_mul_2exp(b, k);
+          x[j0] = neg ? gl_sub(a, t) : gl_add(a, t);
+          x[j1] = neg ? gl_add(a, t) : gl_sub(a, t);
+        } else {
+          x[j0] = gl_add(a, b);
+          x[j1] = gl_mul_2exp(neg ? gl_sub(b, a) : gl_sub(a, b), k);
+        }
+      }
+    }
+  }
+}
+
+template <int K, bool DIT, bool INV>
+__global__ __launch_bounds__(256) void ntt_small_strided_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logS, unsigned logn,
+                                                           const u64* __restrict__ t0, const u64* __restrict__ t1, unsigned src_div,
+                                                           const u64* __restrict__ scale, u64 out_mul) {
+  constexpr int N = 1 << K;
+  const size_t n = size_t(1) << logn;
+  const unsigned logB = K + logS;
+  const size_t gid = blockIdx.x * size_t(blockDim.x) + threadIdx.x;  // (block of 2^logB positions, l)
+  if (gid >= (n >> K)) return;
+  const size_t col = blockIdx.y;
+  const u32 lg = (u32)(gid & ((size_t(1) << logS) - 1));
+  const size_t base = (gid >> logS) << logB;
+  const u64* s = src + (col / src_div) * n + base;
+  const u64* sc = scale ? scale + (col % src_div) * n + base : nullptr;
+  u64* d = dst + col * n + base;
+  const unsigned esh = TW_LOG - logB;
+  u64 x[N];
+#pragma unroll
+  for (int h = 0; h < N; h++) x[h] = s[(size_t(h) << logS) + lg];
+  if (sc) {
+#pragma unroll
+    for (int h = 0; h < N; h++) x[h] = gl_mul(x[h], sc[(size_t(h) << logS) + lg]);
+  }
+  if (DIT) {
+#pragma unroll
+    for (int h = 1; h < N; h++) x[h] = gl_mul(x[h], tw_lookup(t0, t1, (lg * bitrev32((u32)h, K)) << esh));
+  }
+  reg_stages_small<K, DIT, INV>(x);
+#pragma unroll
+  for (int h = 0; h < N; h++) {
+    u64 v = x[h];
+    if (!DIT && h) v = gl_mul(v, tw_lookup(t0, t1, (lg * bitrev32((u32)h, K)) << esh));
+    if (out_mul != 1) v = gl_mul(v, out_mul);
+    d[(size_t(h) << logS) + lg] = v;
+  }
+}
+
 // 8-bit strided pass: sub-transforms of 256 points at stride S = 2^logS inside blocks of 2^(8 + logS); a tile is
 // 256 (h) x 16 (l) with l contiguous in memory. Includes the four-step inter-pass twiddle w_B^{l * bitrev8(h)}.
 // The forward branch issues its 16 raw loads first and the 16 scale loads + multiplications after them: the strided pass
@@ -542,6 +618,26 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
                          ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, ctx.tw0, ctx.tw1, ttab, src_div, scale, out_mul, (u32)gx8,
                          (u32)ncols);
     ctx.prof_end(id, ev8, 16.0 * double(ncols) * double(size_t(1) << logn));
+    return;
+  }
+  if (k >= 1 && k <= 6 && logS >= 8 && !getenv("MSAMD_NO_NTT_SMALL")) {
+    // a sub-transform of at most 64 points: shifts and additions in registers (ntt_small_strided_k)
+    const size_t threads_total = (size_t(1) << logn) >> k;
+    const dim3 grid((unsigned)((threads_total + 255) / 256), (unsigned)ncols);
+    const u64 *t0 = inverse ? ctx.tw0i : ctx.tw0, *t1 = inverse ? ctx.tw1i : ctx.tw1;
+    hipEvent_t ev = ctx.prof_begin(K_NTT_STRIDED);
+#define MS_SMALL(KK)                                                                                                                     \
+  case KK:                                                                                                                               \
+    if (inverse)                                                                                                                         \
+      hipLaunchKernelGGL((ntt_small_strided_k<KK, (DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logS, logn, t0, t1, src_div, scale, out_mul); \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL((ntt_small_strided_k<KK, (DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logS, logn, t0, t1, src_div, scale, out_mul); \
+    break;
+    switch (k) {
+      MS_SMALL(1) MS_SMALL(2) MS_SMALL(3) MS_SMALL(4) MS_SMALL(5) MS_SMALL(6)
+    }
+#undef MS_SMALL
+    ctx.prof_end(K_NTT_STRIDED, ev, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
   unsigned logT = 12 - k;

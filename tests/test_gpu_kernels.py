@@ -39,6 +39,33 @@ def test_dft_batch(ctx, oracle, log_h, w):
     assert np.array_equal(back, m)
 
 
+# heights of 12 + k bits, k = 1 .. 7: the strided pass of k <= 6 bits runs in registers on shifts alone (ntt_small_strided_k: every
+# root of order <= 64 is a power of two), k = 7 and MSAMD_NO_NTT_SMALL=1 take the LDS kernel; 2^26 = 12 + 8 + 6 has the same last pass
+@pytest.mark.parametrize("log_h", [13, 14, 15, 16, 17, 18, 19, 26])
+@pytest.mark.parametrize("small", [True, False])
+def test_dft_batch_small_strided_passes(ctx, oracle, log_h, small, monkeypatch):
+    if not small:
+        monkeypatch.setenv("MSAMD_NO_NTT_SMALL", "1")
+    if log_h == 26 and not small:
+        pytest.skip("one 2^26 case is enough")
+    rng = np.random.default_rng(300 + log_h)
+    m = rand_field(rng, (1 << log_h, 1 if log_h == 26 else 2))
+    got = ctx.dft_batch(m)
+    if log_h <= 19:
+        assert np.array_equal(got, oracle.dft_batch(m))
+    else:  # (the oracle at 2^26 would take a minute: a size-independent property instead - linearity against a shifted input, and the round trip)
+        m2 = m.copy()
+        m2[12345, 0] = np.uint64((int(m[12345, 0]) + 1) % P)
+        g2 = ctx.dft_batch(m2)
+        w = int(oracle.lib().mso_gl_two_adic_generator(log_h))
+        for k in (0, 1, 2, 77, (1 << 25) + 3, (1 << 26) - 1):
+            assert (int(g2[k, 0]) - int(got[k, 0])) % P == pow(w, 12345 * k, P)
+    assert np.array_equal(ctx.dft_batch(got, inverse=True), m)
+    if log_h <= 17:
+        for lb in (1, 2):
+            assert np.array_equal(ctx.coset_lde_batch(m, lb), oracle.coset_lde_bitrev(m, lb))
+
+
 # the reference's layout pin: src/prover.rs:975-999 (h in {1,2,4,32,256}, B in {2,4,8}, w in {1,2,7})
 @pytest.mark.parametrize("log_h", [0, 1, 2, 5, 8, 12, 14])
 @pytest.mark.parametrize("log_blowup", [1, 2, 3])
