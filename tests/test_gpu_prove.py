@@ -409,7 +409,8 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
 # the hiprtc-compiled ones (the library reads these variables at call time)
 @pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE",
                                  "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC", "MSAMD_NO_SIDE_STREAM", "MSAMD_OLD_TRANSPOSE", "MSAMD_GENERIC_LEAF_HASH", "MSAMD_NO_DEEP_LEAVES",
-                                 "MSAMD_HOST_TRANSCRIPT", "MSAMD_NO_NEXT_SHIFT", "MSAMD_OLD_CLAIMS_TREE", "MSAMD_CLAIMS_ACC_MAIN", "MSAMD_NO_BARY_BATCH"])
+                                 "MSAMD_HOST_TRANSCRIPT", "MSAMD_NO_NEXT_SHIFT", "MSAMD_OLD_CLAIMS_TREE", "MSAMD_CLAIMS_ACC_MAIN", "MSAMD_NO_BARY_BATCH", "MSAMD_NO_NTT_SMALL",
+                                 "MSAMD_NO_WIDE_PREHASH", "MSAMD_NO_WAVE_QUOTIENT"])
 def test_alternative_paths_give_the_same_proof(pkg, ctx, oracle, fe, var):
     import os
 
