@@ -372,6 +372,126 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
   }
 }
 
+// The same for FEW rows of VERY wide matrices (the reference's BLAKE3 system: a 1024-row LDE of 2625 + 146 + 2 columns): with a
+// thread per row pair a few hundred threads walk thousands of columns each, one dependent batch of loads after the other.
+// Here 16 row pairs x 16 column slices form a workgroup: slice s takes the columns c = s (mod 16) of every matrix (a fixed
+// column is still one 256-byte run over the row pairs), the per-point sums are LINEAR in the column sums, so every slice
+// carries partial sums through to the reduced per-point values, LDS adds the 16 partials, and slice 0 finishes the row pair
+// exactly as deep_reduce_k does (same products, same order of the final additions: bit-identical).
+__global__ __launch_bounds__(256) void deep_reduce_wide_k(DeepParams p) {
+  __shared__ u64 part[16][8][16];  // [slice][point * 4 + row * 2 + coordinate][row pair]
+  const u32 rp = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const size_t i = (blockIdx.x * size_t(16) + rp) * 2;
+  const bool live = i < p.height;
+  GlAcc T[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc_init(T[q][j]);
+  const E2* __restrict__ apow = p.apow;
+  if (live) {
+    for (u32 m = 0; m < p.nmats; m++) {
+      const DeepMat& dm = p.mats[m];
+      GlAccS a00, a01, a10, a11;
+      accs_init(a00);
+      accs_init(a01);
+      accs_init(a10);
+      accs_init(a11);
+      typedef unsigned long long Pair __attribute__((ext_vector_type(2)));
+      typedef const Pair __attribute__((address_space(1))) * GlobalPair;
+      const u64* __restrict__ md = dm.d + i;
+      const u32 mw = dm.w;
+      const size_t mstride = dm.stride ? (size_t)dm.stride : p.height;
+      u32 c = slice;
+      for (; c + 16 * 3 < mw; c += 16 * 4) {  // four 16-byte loads in flight per lane
+        Pair v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *(GlobalPair)(md + size_t(c + 16 * u) * mstride);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const E2 a = apow[c + 16 * u];
+          accs_mad(a00, a.c0, v[u].x);
+          accs_mad(a01, a.c1, v[u].x);
+          accs_mad(a10, a.c0, v[u].y);
+          accs_mad(a11, a.c1, v[u].y);
+        }
+      }
+      for (; c < mw; c += 16) {
+        const Pair v = *(GlobalPair)(md + size_t(c) * mstride);
+        const E2 a = apow[c];
+        accs_mad(a00, a.c0, v.x);
+        accs_mad(a01, a.c1, v.x);
+        accs_mad(a10, a.c0, v.y);
+        accs_mad(a11, a.c1, v.y);
+      }
+      const u64 s00 = accs_reduce(a00), s01 = accs_reduce(a01), s10 = accs_reduce(a10), s11 = accs_reduce(a11);
+      for (u32 k = 0; k < dm.npoints; k++) {
+        const u64 c0 = dm.coeff[k].c0, c1 = dm.coeff[k].c1, c7 = dm.coeff7[k];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if (dm.pt[k] == (u32)q) {
+            acc_mad(T[q][0], c0, s00);
+            acc_mad(T[q][0], c7, s01);
+            acc_mad(T[q][1], c0, s01);
+            acc_mad(T[q][1], c1, s00);
+            acc_mad(T[q][2], c0, s10);
+            acc_mad(T[q][2], c7, s11);
+            acc_mad(T[q][3], c0, s11);
+            acc_mad(T[q][3], c1, s10);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) part[slice][q * 4 + j][rp] = acc_reduce(T[q][j]);
+  __syncthreads();
+  if (slice != 0 || !live) return;
+  u64 tot[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    u64 a = part[0][v][rp];
+    for (int sl = 1; sl < 16; sl++) a = gl_add(a, part[sl][v][rp]);
+    tot[v] = a;
+  }
+  E2 r0 = e2(0), r1 = e2(0);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if ((u32)q < p.pts.n) {
+      const E2 K = p.pts.K[q];
+      const E2 t0 = e2(gl_sub(K.c0, tot[q * 4 + 0]), gl_sub(K.c1, tot[q * 4 + 1]));
+      const E2 t1 = e2(gl_sub(K.c0, tot[q * 4 + 2]), gl_sub(K.c1, tot[q * 4 + 3]));
+      const E2* __restrict__ den = p.pts.den[q];
+      const u32 dec = p.pts.shift[q];
+      r0 = e2_add(r0, e2_mul(t0, den[dec ? rev_dec(i, p.log_height, dec) : i]));
+      r1 = e2_add(r1, e2_mul(t1, den[dec ? rev_dec(i + 1, p.log_height, dec) : i + 1]));
+    }
+  }
+  p.ro[i] = r0;
+  p.ro[i + 1] = r1;
+  if (p.leaves) {
+    u32 m[16];
+    m[0] = (u32)r0.c0;
+    m[1] = (u32)(r0.c0 >> 32);
+    m[2] = (u32)r0.c1;
+    m[3] = (u32)(r0.c1 >> 32);
+    m[4] = (u32)r1.c0;
+    m[5] = (u32)(r1.c0 >> 32);
+    m[6] = (u32)r1.c1;
+    m[7] = (u32)(r1.c1 >> 32);
+#pragma unroll
+    for (int k = 8; k < 16; k++) m[k] = 0;
+    u32 cv[8];
+    b3_iv(cv);
+    b3_compress(cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+    uint4* q = reinterpret_cast<uint4*>(p.leaves + (i >> 1));
+    q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+  }
+}
+
 // out[i] = (1/2 + pw) lo + (1/2 - pw) hi, pw = (beta/2) w_{2R}^{-bitrev(i)}; optional roll-in out[i] += f * in[i]
 // (row0 != 0: `cur` / `roll` / `out` are a rank's slice of the layer, which starts at row `row0` of 2^log_rows)
 __global__ __launch_bounds__(256) void fri_fold_k(const E2* __restrict__ cur, size_t rows, unsigned log_rows, E2 half_beta, u64 half,
@@ -904,7 +1024,12 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
   for (auto& m : mats) bytes += 8.0 * m.w * height;
   hipEvent_t ev = ctx.prof_begin(K_DEEP);
   if (height < 2 || (height & 1)) throw std::runtime_error("deep_reduce: LDE height must be even");
-  hipLaunchKernelGGL(deep_reduce_k, dim3((unsigned)((height / 2 + 255) / 256)), dim3(256), 0, ctx.stream, p);
+  size_t total_w = 0;
+  for (auto& m : mats) total_w += m.w;
+  if (height <= 8192 && total_w >= 512 && !getenv("MSAMD_NO_DEEP_WIDE"))  // few rows, very wide: 16 column slices per row pair
+    hipLaunchKernelGGL(deep_reduce_wide_k, dim3((unsigned)((height / 2 + 15) / 16)), dim3(256), 0, ctx.stream, p);
+  else
+    hipLaunchKernelGGL(deep_reduce_k, dim3((unsigned)((height / 2 + 255) / 256)), dim3(256), 0, ctx.stream, p);
   ctx.prof_end(K_DEEP, ev, bytes);
   HIP_CHECK(hipGetLastError());
 }

@@ -207,7 +207,8 @@ def test_side_stream_results_are_awaited(pkg, ctx, fe, b3, compiled, oracle, mon
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [(), ("MSAMD_NO_WAVE_QUOTIENT",), ("MSAMD_NO_WAVE_QUOTIENT", "MSAMD_NO_FEW_LANES"), ("MSAMD_NO_WIDE_PREHASH",)])
+@pytest.mark.parametrize("env", [(), ("MSAMD_NO_WAVE_QUOTIENT",), ("MSAMD_NO_WAVE_QUOTIENT", "MSAMD_NO_FEW_LANES"), ("MSAMD_NO_WIDE_PREHASH",),
+                                 ("MSAMD_NO_DEEP_WIDE",)])
 def test_interpreter_forms_give_the_same_proof(pkg, ctx, fe, b3, compiled, oracle, monkeypatch, env):
     """the compression circuit's 6952-node program is above the hiprtc limit: a short circuit takes the wave-per-row kernel over the
     level-scheduled program (quotient_wave_k); without it few lanes per workgroup with the slot files in LDS; without that the
