@@ -596,26 +596,19 @@ u64 quotient_inj_norm(unsigned log_n) {  // 1 / (n g), src/prover.rs:782-784
 // lanes per workgroup for a short circuit whose slot file does not fit the usual 64 KB at 64 lanes (0 = use the global scratch):
 // the largest of 32 .. 4 whose slots fit the LDS a workgroup may have (160 KB on gfx950, opted into once), as long as the rows
 // make at most a few workgroups per CU - a tall circuit walks the global scratch at full width instead
-static bool wave_lds_ok(size_t bytes) {
-  static const size_t lds_max = [] {
-    const size_t want = 160 * 1024;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&quotient_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) return want;
-    (void)hipGetLastError();
-    return size_t(64) * 1024;
-  }();
-  return bytes <= lds_max;
+// Dynamic LDS above 64 KB has to be opted into per kernel AND per device (a process may drive several GPUs, one context each:
+// the in-process transport's thread ranks), so the attribute is set on the current device in front of every such launch -
+// these are the rare paths of large programs, the call costs microseconds.
+static size_t big_lds_limit(const void* kernel) {
+  const size_t want = 160 * 1024;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) return want;
+  (void)hipGetLastError();
+  return size_t(64) * 1024;
 }
+static bool wave_lds_ok(size_t bytes) { return bytes <= big_lds_limit(reinterpret_cast<const void*>(&quotient_wave_k)); }
 static unsigned few_lanes_per_workgroup(size_t n_slots, size_t nq) {
-  static const size_t lds_max = [] {
-    int dev = 0, v = 0;
-    (void)hipGetDevice(&dev);
-    const size_t want = 160 * 1024;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&quotient_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess)
-      return want;
-    (void)hipGetLastError();
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
-    return (size_t)v;
-  }();
+  if (n_slots * 4 * 8 > 160 * 1024 || (nq + 31) / 32 > 256) return 0;  // cannot apply whatever the limit is
+  const size_t lds_max = big_lds_limit(reinterpret_cast<const void*>(&quotient_k<true>));
   if (getenv("MSAMD_NO_FEW_LANES")) return 0;
   for (unsigned th = 32; th >= 4; th >>= 1)
     if (n_slots * th * 8 <= lds_max && (nq + th - 1) / th <= 256) return th;  // one round of workgroups over the CUs
