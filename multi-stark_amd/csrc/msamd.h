@@ -350,16 +350,18 @@ struct JitKernel {
   void* module = nullptr;    // hipModule_t
   void* function = nullptr;  // hipFunction_t
   bool inline_tables = false;  // quotient kernel: reads zh / zh_inv / alpha powers from the argument block
+  unsigned groups = 0;         // stage-2 terms kernel: waves per workgroup, one per group of 16 lookups (0 = a thread does the whole row)
   JitKernel() {}
   JitKernel(const JitKernel&) = delete;
   JitKernel& operator=(const JitKernel&) = delete;
-  JitKernel(JitKernel&& o) noexcept : module(o.module), function(o.function), inline_tables(o.inline_tables) {
+  JitKernel(JitKernel&& o) noexcept : module(o.module), function(o.function), inline_tables(o.inline_tables), groups(o.groups) {
     o.module = o.function = nullptr;
   }
   JitKernel& operator=(JitKernel&& o) noexcept {
     std::swap(module, o.module);
     std::swap(function, o.function);
     std::swap(inline_tables, o.inline_tables);
+    std::swap(groups, o.groups);
     return *this;
   }
   ~JitKernel();

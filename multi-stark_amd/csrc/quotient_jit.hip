@@ -424,6 +424,62 @@ void load_kernel(const std::vector<char>* co, const char* name, JitKernel& out) 
 // list of argument counts: the row's multiplicities and arguments are loaded up front (16-byte loads where the row
 // stride allows), every fingerprint is an unrolled lazy dot product with the gamma powers, the messages are inverted
 // 16 at a time with one base-field inversion.
+// groups of 16 lookups (one batch inversion each); with three or more of them a WAVE takes a group (stage2_grouped_source)
+static unsigned stage2_groups(size_t n_lookups) {
+  const size_t g = (n_lookups + 15) / 16;
+  return g >= 3 && g <= 16 && !getenv("MSAMD_NO_STAGE2_GROUPS") ? (unsigned)g : 0u;
+}
+
+// Many lookups per row (the reference's BLAKE3 compression circuit: 73, with 729 arguments): one thread per row walks five
+// batches one after the other - 0.36 ms on that circuit's 512 rows. The batches are independent, so a workgroup is 64 rows x G
+// waves and wave g does batch g of its 64 rows (uniform control flow per wave); the row sums meet in LDS (field addition is
+// exact: the order of the partial sums does not matter).
+std::string stage2_grouped_source(const std::vector<uint32_t>& counts, unsigned G) {
+  const size_t L = counts.size();
+  size_t aw = 0;
+  std::vector<size_t> offs;
+  for (auto c : counts) {
+    offs.push_back(aw);
+    aw += c;
+  }
+  std::ostringstream o;
+  o << "#include \"lookup_params.h\"\nusing namespace msamd;\n"
+       "extern \"C\" __global__ __launch_bounds__(" << 64 * G << ") void stage2_terms_jit(Stage2Params p) {\n"
+       "  __shared__ E2 part[" << G << "][64];\n"
+       "  const unsigned lane = threadIdx.x & 63, grp = threadIdx.x >> 6;\n"
+       "  const size_t r = blockIdx.x * size_t(64) + lane;\n"
+       "  const bool live = r < p.n;\n"
+       "  E2 s = e2(0);\n"
+       "  if (live) {\n"
+    << "    const u64* __restrict__ a = p.args + r * " << aw << ";\n"
+    << "    const u64* __restrict__ m = p.mult + r * " << L << ";\n"
+    << "    E2* __restrict__ trow = p.terms + r * " << L << ";\n"
+       "    switch (grp) {\n";
+  for (unsigned g = 0; g < G; g++) {
+    const size_t j0 = size_t(g) * 16, cnt = std::min<size_t>(16, L - j0);
+    o << "    case " << g << ": {\n      E2 msg[16];\n";
+    for (size_t t = 0; t < cnt; t++) {
+      const size_t j = j0 + t;
+      o << "      { GlAcc g0, g1; acc_init(g0); acc_init(g1);\n";
+      for (size_t k = 0; k < counts[j]; k++)
+        o << "        { const u64 v = a[" << offs[j] + k << "]; acc_mad(g0, v, p.ch->gp.g[" << k << "].c0); acc_mad(g1, v, p.ch->gp.g[" << k << "].c1); }\n";
+      o << "        msg[" << t << "] = e2(gl_add(acc_reduce(g0), p.ch->beta.c0), gl_add(acc_reduce(g1), p.ch->beta.c1)); }\n";
+    }
+    o << "      e2_batch_inverse<16>(msg, " << cnt << ");\n";
+    for (size_t t = 0; t < cnt; t++) {
+      const size_t j = j0 + t;
+      o << "      { const E2 v = e2_mul_base(msg[" << t << "], m[" << j << "]); trow[" << j << "] = v; s = e2_add(s, v); }\n";
+    }
+    o << "    } break;\n";
+  }
+  o << "    default: break;\n    }\n  }\n"
+       "  part[grp][lane] = s;\n  __syncthreads();\n"
+       "  if (grp == 0 && live) {\n    E2 t = part[0][lane];\n";
+  for (unsigned g = 1; g < G; g++) o << "    t = e2_add(t, part[" << g << "][lane]);\n";
+  o << "    p.rowsum[r] = t;\n  }\n}\n";
+  return o.str();
+}
+
 std::string stage2_source(const std::vector<uint32_t>& counts) {
   const size_t L = counts.size();
   size_t aw = 0;
@@ -592,7 +648,9 @@ void stage2_jit_build(const std::vector<uint32_t>& arg_counts, JitKernel& out) {
     aw += c;
   }
   if (aw > 1024) return;
-  load_kernel(code_object(stage2_source(arg_counts)), "stage2_terms_jit", out);
+  const unsigned G = stage2_groups(arg_counts.size());
+  load_kernel(code_object(G ? stage2_grouped_source(arg_counts, G) : stage2_source(arg_counts)), "stage2_terms_jit", out);
+  out.groups = out.function ? G : 0u;
 }
 
 void stage2_trace_jit_build(const std::vector<PNode>& nodes, const std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& lookups,
@@ -620,7 +678,10 @@ void stage2_jit_launch(Ctx& ctx, const JitKernel& k, const Stage2Params& p) {
   Stage2Params copy = p;
   size_t size = sizeof(Stage2Params);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((p.n + 255) / 256), 1, 1, 256, 1, 1, 0, ctx.stream, nullptr, config));
+  if (k.groups)  // 64 rows x `groups` waves per workgroup
+    HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((p.n + 63) / 64), 1, 1, 64 * k.groups, 1, 1, 0, ctx.stream, nullptr, config));
+  else
+    HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)k.function, (unsigned)((p.n + 255) / 256), 1, 1, 256, 1, 1, 0, ctx.stream, nullptr, config));
 }
 
 void quotient_jit_launch(Ctx& ctx, const JitKernel& k, const QParams& p, size_t nq) {
