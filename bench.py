@@ -66,8 +66,13 @@ def parse_args():
                     "(round-1 definition) instead of the host-resident one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL on ROCm; gloo only to "
                     "rehearse the multi-rank path with several ranks sharing one GPU: the exchanges then go through TorchComm)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"], help="N > 1: who runs the joint proof's exchanges: "
-                    "the library's own RCCL transport (default) or torch.distributed callbacks")
+    ap.add_argument("--transport", default=None, choices=["local", "rccl", "torch"], help="N > 1: who runs the joint proof's exchanges. "
+                    "local (default without a launcher): N thread ranks of THIS process, one device each, on the library's in-process "
+                    "transport (ms_comm_local_*: peer copies ordered by HIP events) - the reference is one process driving the box "
+                    "(Cargo.toml:45); rccl (default under torch.distributed.run): the library's own RCCL transport, one process per GPU; "
+                    "torch: torch.distributed callbacks")
+    ap.add_argument("--share-devices", action="store_true", help="N > 1, --transport local: REHEARSAL only - place the N thread ranks on "
+                    "the devices there are (round-robin) instead of refusing to run on fewer than N; the line says so (config.ranks)")
     ap.add_argument("--joint", action="store_true", help="(default for N > 1) the joint proof is the primary figure")
     ap.add_argument("--replicas-primary", action="store_true", help="N > 1: one independent proof per rank as the primary figure")
     ap.add_argument("--no-replicas-leg", action="store_true", help="N > 1: skip the secondary independent-proof measurement")
@@ -259,12 +264,15 @@ def single_gpu(args, pkg, fe, ctx, torch):
     ctx.set_profile([dominant])
     ctx.reset_stats()
     sync()
+    per = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proof = step()
+        t1 = time.perf_counter()
+        proof = step()  # (returns with the proof bytes in host memory: a step is complete when it returns)
+        per.append(1e3 * (time.perf_counter() - t1))
     sync()
     elapsed = time.perf_counter() - t0
-    log("timed region done: %.3f ms per step" % (1e3 * elapsed / args.steps))
+    log("timed region done: %.3f ms per step (min %.3f, median %.3f, max %.3f)" % (1e3 * elapsed / args.steps, min(per), float(np.median(per)), max(per)))
     dom = ctx.kernel_stats()[dominant]
     ctx.set_profile([])
     stage = system.prove_multiple_claims(witness, want_times=True).stage_ms
@@ -324,8 +332,9 @@ def single_gpu(args, pkg, fe, ctx, torch):
         try:
             in_flight = two_in_flight(pkg, fe, system, witness, traces, packed, proof.to_bytes(), rows, max(5, min(args.steps, 20)))
             log("two proofs in flight: %.3f ms per proof (%.1f M rows/s)" % (in_flight["ms_per_proof"], in_flight["rows_per_s"] / 1e6))
-        except Exception as e:  # noqa: BLE001  (a secondary figure must not void the run)
-            log("two-in-flight leg skipped: %r" % (e,))
+        except Exception as e:  # noqa: BLE001  (a secondary figure must not void the run, but its failure is part of the record)
+            log("two-in-flight leg failed: %r" % (e,))
+            in_flight = {"error": "two-in-flight leg failed: %r" % (e,)}
     trace_bytes = int(sum(t.nbytes for t in traces))
     narrow = [int(t.nbytes // 8 * (1 if int(t.max(initial=0)) < 256 else 2 if int(t.max(initial=0)) < 65536 else 4 if int(t.max(initial=0)) < (1 << 32) else 8))
               if t.nbytes >= (4 << 20) else int(t.nbytes) for t in traces]
@@ -337,6 +346,7 @@ def single_gpu(args, pkg, fe, ctx, torch):
         "verified": True,
         "parallelism": "single GPU",
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+        "step_ms_min_median_max": [round(min(per), 3), round(float(np.median(per)), 3), round(max(per), 3)],  # box noise: the narrowing runs on shared host cores
         "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows / (elapsed / args.steps) / 1e9,
         "hbm_resident_ms": hbm_ms,
         "pipelined_ms_per_proof": pipe_ms,
@@ -424,17 +434,31 @@ def babybear(args, pkg, fe, ctx, torch):
     proof, dominant = profile_first_step(ctx, step, 0)
     for _ in range(max(args.warmup, 1) - 1):
         proof = step()
+    # ---- timed region: exactly K steps, NO HIP events (this configuration's dominant class is ~150 short launches per proof:
+    # events around each of them cost about a millisecond per proof, which is not the prover's time)
+    ctx.set_profile([])
+    ctx.sync()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        proof = step()
+        per.append(1e3 * (time.perf_counter() - t1))
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    log("timed region done: %.3f ms per step (min %.3f, median %.3f, max %.3f)" % (1e3 * elapsed / args.steps, min(per), float(np.median(per)), max(per)))
+    # ---- the dominant class's launch times: a separate pass with events around that class only, outside the timed region
+    prof_steps = max(2, min(args.steps, 5))
     ctx.set_profile([dominant])
     ctx.reset_stats()
     ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = step()
+    t1 = time.perf_counter()
+    for _ in range(prof_steps):
+        step()
     ctx.sync()
-    elapsed = time.perf_counter() - t0
+    prof_ms = 1e3 * (time.perf_counter() - t1) / prof_steps
     dom = ctx.kernel_stats()[dominant]
     ctx.set_profile([])
-    log("timed region done: %.3f ms per step" % (1e3 * elapsed / args.steps))
     assert system.verify(packed, proof.to_bytes()) == 0, "the library's own verifier rejects the proof"
     stage = system.prove_multiple_claims(witness, want_times=True).stage_ms
     hbm_ms = None
@@ -461,10 +485,14 @@ def babybear(args, pkg, fe, ctx, torch):
         "verified": True,
         "parallelism": "single GPU",
         "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+        "step_ms_min_median_max": [round(min(per), 3), round(float(np.median(per)), 3), round(max(per), 3)],
         "hbm_resident_ms": hbm_ms,
     }
     rl = roofline_of(dominant, dom, full_size=False)
     rl["traffic"], rl["traffic_source"] = None, "not collected for this configuration"
+    rl["timed_how"] = ("HIP events around every launch of this class in a SEPARATE pass of %d steps after the timed region (%.3f ms per step "
+                       "with the events, %.3f without): the class is %d launches per proof, and events around them inside the timed region "
+                       "would add their own cost to ms_per_step" % (prof_steps, prof_ms, 1e3 * elapsed / args.steps, dom["launches"] // prof_steps))
     if dom.get("units"):
         perms_per_s = dom["units"] / max(dom["ms"], 1e-12) * 1e3
         rl["valu"] = {"what": "Poseidon2 permutations of this kernel class priced at %.0f VALU instructions each against the integer "
@@ -755,6 +783,11 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
                        else "1 proof per GPU (replicas)",
         "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows * (1 if joint_primary else n_gpus) / (info["ms_per_step"] / 1e3) / 1e9,
     }
+    devs = [None] * n_gpus
+    dist.all_gather_object(devs, int(local_rank))
+    result["config"]["ranks"] = {"n": n_gpus, "devices": devs, "transport": info.get("transport") if joint_primary else None,
+                                 "rccl_world": dist.get_world_size() if args.backend == "nccl" else None,
+                                 "launcher": "torch.distributed.run (one process per GPU), backend %s" % args.backend}
     if joint_primary:
         result["config"]["stage_ms"] = info["stage_ms"]
         result["config"]["bytes_exchanged_per_rank_per_proof"] = info["bytes_exchanged_per_rank_per_proof"]
@@ -779,13 +812,249 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
     return result
 
 
+def fail_line(args, why, code=2):
+    """a run that cannot measure what the command names: say why (stderr and the JSON line) and end with a non-zero status"""
+    log("bench.py: " + why)
+    line = base_line(args, args.gpus, None, None)
+    line["error"] = why
+    print(json.dumps(line), flush=True)
+    sys.exit(code)
+
+
+# ------------------------------------------------------------------------------------------------ N > 1, one process
+def local_multi_gpu(args):
+    """`python3 bench.py --gpus N` without a launcher: ONE joint proof of [ByteTable, U32Add x N] per step by N thread ranks of
+    this process, rank k on device k with its own ms_ctx, exchanges on the library's in-process transport (ms_comm_local_*:
+    the receiving rank pulls its blocks out of the peers' buffers - peer copies over xGMI - ordered by HIP events). This is the
+    reference's own process model (one process with a thread pool driving the box, Cargo.toml:45) and needs no rendezvous, no
+    RCCL and no torch. Fewer than N visible devices is an ERROR (exit status 2), never a smaller measurement; --share-devices
+    turns that into a labelled rehearsal. Timing: the ranks meet at a barrier, every rank synchronises its device, K steps,
+    synchronise, barrier; the step time is the MAX over ranks."""
+    import importlib
+
+    pkg = load_package()
+    fe = pkg.frontend
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    mgpu_seeds = lambda r: (0xDEADBEEF ^ ((r * 0x9E3779B9) & 0xFFFFFFFF), 0xCAFEBABE ^ ((r * 0x85EBCA6B) & 0xFFFFFFFF))  # noqa: E731
+    N = args.gpus
+    if N & (N - 1):
+        fail_line(args, "the joint proof needs a power-of-two number of ranks (--gpus %d)" % N)
+    ndev = pkg.device_count()
+    if ndev < N and not args.share_devices:
+        fail_line(args, "--gpus %d needs %d HIP devices, this process sees %d: refusing to measure fewer GPUs than the command names "
+                        "(--share-devices rehearses the N-rank code path on the devices there are)" % (N, N, ndev))
+    if ndev < 1:
+        fail_line(args, "no HIP device visible")
+    devices = [k % ndev for k in range(N)] if ndev < N else list(range(N))
+    shared = len(set(devices)) < N
+    log("in-process ranks: %d thread ranks on devices %s%s" % (N, devices, " (REHEARSAL: ranks share devices)" if shared else ""))
+    num_adds = 1 << args.log_adds
+    t = time.time()
+    # setup (untimed, criterion's setup closure): rank k's witness from its own seeds; the byte table's multiplicities are the
+    # sum over ranks; every rank holds all claims (the transcript absorbs them in order)
+    byte = np.zeros((256, 1), dtype=np.uint64)
+    adders, claims = [], []
+    for r in range(N):
+        (bt, add), cl = fe.u32_add_bench_witness(num_adds, *mgpu_seeds(r))
+        byte += bt
+        adders.append(add)
+        claims.append(cl)
+    packed = fe.pack_claims(np.concatenate(claims, axis=0))
+    owners = sharded.u32_add_owners(N)
+    rows = 256 + N * adders[0].shape[0]
+    log("witness generated in %.1fs: %d adders x 2^%d rows, %d claims" % (time.time() - t, N, args.log_adds, len(packed[0]) - 1))
+    # pre-flight reference (before any rank starts): the single-GPU proof of the same system at 2^12 additions per rank
+    k = min(args.log_adds, 12)
+    ptr, pcl = fe.multi_u32_add_witness(N, 1 << k)
+    ppacked = fe.pack_claims(pcl)
+    ctx0 = pkg.Context(devices[0])
+    sys0 = pkg.System.new(ctx0, fe.bench_params(), fe.multi_u32_add_system_inputs(N))
+    want_small = sys0.prove_multiple_claims(sys0.witness(ptr, ppacked)).to_bytes()
+    small_ok = sys0.verify_multiple_claims(ppacked, want_small) == 0
+    del sys0
+    ctx0.trim()
+    del ctx0
+    barrier = threading.Barrier(N)
+    out = {}
+    ctxs = [None] * N
+    state = {"leg": "setup"}
+
+    def partial():
+        line = base_line(args, N, None, None)
+        if "replicas" in out:
+            line["replicas"] = out["replicas"]
+        return line
+
+    class _Progress:  # what the watchdog prints: the exchange rank 0 is in
+        def comm_progress(self):
+            return ctxs[0].comm_progress() if ctxs[0] is not None else ("", 0, False)
+
+    wd = Watchdog(0, "the multi-GPU bench (thread ranks)", args.primary_timeout, partial, _Progress())
+
+    def timed(ctx, step, rank):
+        """W warm-up steps (the first one profiled), then exactly K steps between barrier + device synchronisation"""
+        proof, dominant = profile_first_step(ctx, step, rank)
+        for _ in range(max(args.warmup, 1) - 1):
+            proof = step()
+        ctx.set_profile([dominant])
+        ctx.reset_stats()
+        ctx.sync()
+        barrier.wait()
+        t0 = time.perf_counter()
+        per = []
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            proof = step()
+            per.append(1e3 * (time.perf_counter() - t1))
+        ctx.sync()
+        barrier.wait()  # every rank has synchronised its device: the slowest rank closes the region
+        elapsed = time.perf_counter() - t0
+        dom = ctx.kernel_stats()[dominant]
+        ctx.set_profile([])
+        return proof, elapsed, dominant, dom, per
+
+    def rank_body(rank, group):
+        ctx = ctxs[rank] = pkg.Context(devices[rank])
+        res = {}
+        # ---- secondary leg first (as under the launcher): one independent [ByteTable, U32Add] proof per rank per step
+        if not args.no_replicas_leg:
+            if rank == 0:
+                wd.leg = "replicas (one independent proof per rank)"
+            one = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+            (bt, add), cl = fe.u32_add_bench_witness(num_adds, *mgpu_seeds(rank))
+            opacked = fe.pack_claims(cl)
+            ow = one.host_witness([bt, add], opacked)
+            proof, elapsed, _, _, _ = timed(ctx, lambda: one.prove_multiple_claims(ow), rank)
+            res["replicas"] = (elapsed, len(proof.to_bytes()), ow.rows, hashlib.sha256(proof.to_bytes()).hexdigest())
+            del ow, one
+            ctx.trim()
+        # ---- the joint proof
+        system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(N))
+        comm = group.comm(ctx, rank)
+        try:
+            if rank == 0:
+                wd.leg = "joint proof, pre-flight at 2^%d additions per rank" % k
+            mine = [t_ if owners[i] in (-1, rank) else None for i, t_ in enumerate(ptr)]
+            remote = {i: ptr[i].shape[0] for i in range(len(ptr)) if owners[i] not in (-1, rank)}
+            got = system.prove_sharded(system.host_witness(mine, ppacked, remote_heights=remote), comm, owners).to_bytes()
+            again = system.prove_sharded(system.witness(mine, ppacked, remote_heights=remote), comm, owners).to_bytes()
+            res["preflight"] = (got == want_small, again == got, hashlib.sha256(got).hexdigest(), len(got))
+            barrier.wait()
+            if not (got == want_small and again == got):
+                return res  # (every rank leaves here or none does: all hold the same bytes or the check below reports it)
+            tr = [byte] + [adders[r] if r == rank else None for r in range(N)]
+            remote = {1 + r: adders[r].shape[0] for r in range(N) if r != rank}
+            witness = system.host_witness(tr, packed, remote_heights=remote)
+            if rank == 0:
+                wd.leg = "joint proof, first full-size proof (fills the pool, enables peer access)"
+            step = lambda: system.prove_sharded(witness, comm, owners)  # noqa: E731
+            step()
+            moved0 = comm.bytes_moved
+            if rank == 0:
+                wd.leg = "joint proof, warm-up and timed steps"
+            proof, elapsed, dominant, dom, per = timed(ctx, step, rank)
+            moved = (comm.bytes_moved - moved0) // (args.steps + max(args.warmup, 1))
+            stage = system.prove_sharded(witness, comm, owners, want_times=True).stage_ms
+            data = proof.to_bytes()
+            res["joint"] = {"elapsed": elapsed, "per_step_ms": per, "dominant": dominant, "dom": dom, "moved": moved, "stage": stage,
+                            "sha": hashlib.sha256(data).hexdigest(), "bytes": len(data),
+                            "verdict": system.verify_multiple_claims(packed, data) if rank == 0 else 0}
+            del witness
+        finally:
+            comm.close()
+        return res
+
+    group = sharded.LocalGroup(N)
+    try:
+        results = group.run(rank_body)
+    except Exception as e:  # noqa: BLE001  (a failing rank aborts the group: its peers return with an error, nobody hangs)
+        where = wd.where()
+        wd.finish()
+        line = partial()
+        line["error"] = "joint proof by thread ranks failed (%s): %s" % (where, e)
+        log(line["error"])
+        return line
+    finally:
+        group.close()
+    wd.finish()
+    ranks_info = {"n": N, "devices": devices, "transport": "local (ms_comm_local_*: N thread ranks of one process, peer copies ordered by HIP events)",
+                  "rccl_world": None, "launcher": "none (in-process)", "devices_visible": ndev, "ranks_share_devices": shared}
+    pre = [r["preflight"] for r in results]
+    preflight = {"log_adds": k, "proof_bytes": pre[0][3], "proof_sha256": pre[0][2],
+                 "ok": bool(small_ok and all(p[0] and p[1] for p in pre) and len({p[2] for p in pre}) == 1),
+                 "what": "joint proof of [ByteTable, U32Add x %d] at 2^%d additions per rank == System::prove_multiple_claims of the full system on "
+                         "device %d, byte for byte, from host- and device-resident witnesses; same bytes on every rank; verifier accepts" % (N, k, devices[0])}
+    replicas = None
+    if not args.no_replicas_leg:
+        el = max(r["replicas"][0] for r in results)
+        replicas = {"what": "one independent [ByteTable, U32Add @ 2^%d] proof per rank per step (thread ranks, host-resident witnesses)" % args.log_adds,
+                    "value": results[0]["replicas"][2] * N * args.steps / el, "unit": "rows/s", "ms_per_step": 1e3 * el / args.steps,
+                    "rows_per_proof": results[0]["replicas"][2], "proofs_per_step": N, "proof_bytes": results[0]["replicas"][1]}
+        out["replicas"] = replicas
+    if not preflight["ok"]:
+        line = partial()
+        line["error"] = "joint proof pre-flight failed: the joint proof differs from the single-GPU proof of the same system (or between ranks)"
+        line["preflight"] = preflight
+        line["config"] = {"ranks": ranks_info}
+        return line
+    joint = [r["joint"] for r in results]
+    elapsed = max(j["elapsed"] for j in joint)
+    same = len({j["sha"] for j in joint}) == 1
+    j0 = joint[0]
+    per = np.max(np.array([j["per_step_ms"] for j in joint]), axis=0)  # a step ends when its slowest rank has the bytes
+    result = base_line(args, N, rows * args.steps / elapsed, 1e3 * elapsed / args.steps)
+    result["config"] = {
+        "workload": WORKLOAD % (args.log_adds, "rank", "each rank's witness (its trace and all claims) in pinned host memory at step start: the rank uploads "
+                                "its trace and its slice of the claims inside the step, as at N = 1"),
+        "rows_per_proof": rows, "proof_bytes": j0["bytes"],
+        "parallelism": "one joint proof over %d %s (ms_prove_sharded, transport local)" % (N, "thread ranks SHARING %d device(s): rehearsal" % len(set(devices)) if shared else "GPUs"),
+        "ranks": ranks_info,
+        "whole_path_alg_GBps": ALG_BYTES_PER_ROW * rows / (elapsed / args.steps) / 1e9,
+        "stage_ms": {k_: round(v, 3) for k_, v in j0["stage"].items()},
+        "step_ms_min_median_max": [round(float(np.min(per)), 3), round(float(np.median(per)), 3), round(float(np.max(per)), 3)],
+        "bytes_exchanged_per_rank_per_proof": j0["moved"], "proof_sha256": j0["sha"], "verified": j0["verdict"] == 0 and same,
+        "preflight": preflight,
+    }
+    if j0["verdict"] != 0 or not same:
+        result["error"] = ("the joint proof is REJECTED by the verifier (code %d)" % j0["verdict"]) if j0["verdict"] else "the ranks hold different proof bytes"
+    result["roofline"] = roofline_of(j0["dominant"], j0["dom"], full_size=False)
+    if not args.no_cpu_baseline:
+        ctx = pkg.Context(devices[0])
+        one = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+        result["cpu_baseline"] = cpu_baseline(fe, one.blob, args.cpu_log_adds)
+        result["cpu_baseline"]["sample"] += "; measured after the GPU legs, all ranks idle"
+        del one, ctx
+    if replicas is not None:
+        result["replicas"] = replicas
+    return result
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if world > 1 and world != args.gpus:
+        # never measure another number of GPUs than the command names
+        fail_line(args, "launched with WORLD_SIZE=%d but --gpus %d: the two must agree" % (world, args.gpus))
+    if world > 1 and args.transport == "local":
+        fail_line(args, "--transport local runs the N ranks as threads of ONE process: start it without a launcher (python3 bench.py --gpus N)")
+    if world == 1 and args.gpus > 1:
+        if args.transport in ("rccl", "torch"):
+            fail_line(args, "--transport %s needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node %d "
+                            "(or leave --transport out: the ranks then run as threads of this process)" % (args.transport, args.gpus))
+        if args.config == "babybear":
+            fail_line(args, "--config babybear is a single-GPU measurement")
+        # no launcher environment: ONE process drives the N devices itself, as the reference's prover does
+        result = local_multi_gpu(args)
+        print(json.dumps(result), flush=True)
+        if result.get("error"):
+            sys.exit(4)
+        return
+    if args.transport is None:
+        args.transport = "rccl"
     n_gpus = world if world > 1 else 1
     # rehearsal of the collective path with a single rank (RCCL initialises and gathers with world size 1)
     force_dist = world == 1 and bool(os.environ.get("MSAMD_BENCH_FORCE_DIST")) and "RANK" in os.environ
@@ -836,12 +1105,14 @@ def main():
                     "value": r4["value"], "unit": r4["unit"], "ms_per_step": r4["ms_per_step"], "steps": a4.steps,
                     "hbm_resident_ms": r4["config"]["hbm_resident_ms"], "stage_ms": r4["config"]["stage_ms"],
                     "proof_bytes": r4["config"]["proof_bytes"], "verified": r4["config"]["verified"],
-                    "note": "timed with HIP events around every launch of its dominant kernel class (%s: %d launches), which adds about a "
-                            "millisecond per proof; hbm_resident_ms is timed without events" % (r4["roofline"]["kernel"], r4["roofline"]["launches"] // max(a4.steps, 1))}
+                    "step_ms_min_median_max": r4["config"]["step_ms_min_median_max"],
+                    "note": "timed without HIP events; the dominant kernel class (%s) is timed in a separate pass (`--config babybear` "
+                            "prints the full line with roofline and CPU baseline)" % r4["roofline"]["kernel"]}
                 log("config 4 (BabyBear / Poseidon2) secondary leg: %.3f ms per step, %.3f ms HBM-resident" % (
                     r4["ms_per_step"], r4["config"]["hbm_resident_ms"] or float("nan")))
-            except Exception as e:  # noqa: BLE001  (a secondary figure must not void the run)
-                log("config 4 secondary leg skipped: %r" % (e,))
+            except Exception as e:  # noqa: BLE001  (a secondary figure must not void the run, but its failure is part of the record)
+                log("config 4 secondary leg failed: %r" % (e,))
+                result["config4_babybear"] = {"error": "config 4 secondary leg failed: %r" % (e,)}
     else:
         result = multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus)
         dist.barrier()

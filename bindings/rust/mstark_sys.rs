@@ -37,6 +37,8 @@ pub const MS_VERDICT_UNBALANCED: i32 = 6;
 /// Exchanges `ms_prove_sharded` calls back for (device pointers of the context's device; 0 = ok).
 #[repr(C)]
 pub struct ms_comm {
+    /// `core::mem::size_of::<ms_comm>() as u32`: the library treats members beyond it as not offered
+    pub size: u32,
     pub rank: i32,
     pub world: i32,
     pub user: *mut c_void,
@@ -49,11 +51,20 @@ pub struct ms_comm {
                                                            recv_dev: *mut c_void, recv_peer_stride: usize, recv_col_stride: usize, ncols: usize,
                                                            seg_bytes: usize) -> i32>,
     pub set_stream_ordered: Option<unsafe extern "C" fn(user: *mut c_void, hip_stream: *mut c_void) -> i32>,
+    pub all_to_all_cols_start2: Option<unsafe extern "C" fn(user: *mut c_void, send_dev: *const c_void, send_peer_stride: usize, send_col_stride: usize,
+                                                            recv_dev: *mut c_void, recv_peer_stride: usize, recv_col_stride: usize, ncols: usize,
+                                                            seg_bytes: usize, flags: u32) -> i32>,
+    pub scatter_cols_start: Option<unsafe extern "C" fn(user: *mut c_void, root: i32, send_dev: *const c_void, send_peer_stride: usize,
+                                                        send_col_stride: usize, recv_dev: *mut c_void, recv_col_stride: usize, ncols: usize,
+                                                        seg_bytes: usize) -> i32>,
+    pub abort: Option<unsafe extern "C" fn(user: *mut c_void, why: *const c_char)>,
 }
+pub const MS_COMM_SKIP_SELF: u32 = 1;
 
 extern "C" {
     // ---- include/mstark.h (GoldilocksBlake3Config)
     pub fn ms_last_error() -> *const c_char;
+    pub fn ms_device_count() -> i32;
     pub fn ms_ctx_create(device: i32, out: *mut *mut ms_ctx) -> i32;
     pub fn ms_ctx_destroy(ctx: *mut ms_ctx);
     pub fn ms_ctx_sync(ctx: *mut ms_ctx) -> i32;

@@ -58,6 +58,9 @@ enum {
 const char* ms_last_error(void);
 
 /* ---- context */
+/* HIP devices visible to this process (0 when there is none or no driver); never an error. A host that spreads one proof
+ * over N devices (ms_prove_sharded with ms_comm_local_*) checks this first instead of running on fewer. */
+int32_t ms_device_count(void);
 int32_t ms_ctx_create(int32_t device, ms_ctx** out);
 void ms_ctx_destroy(ms_ctx* ctx);
 int32_t ms_ctx_sync(ms_ctx* ctx);
@@ -167,6 +170,10 @@ int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets
  *               opened values, reduced openings, query openings).
  * With torch.distributed these are all_to_all_single / all_gather_into_tensor on RCCL (multi-stark_amd/sharded.py). */
 typedef struct ms_comm {
+  /* sizeof(ms_comm) as the HOST compiled it. Members are only ever appended: the library reads the first `size` bytes and
+   * treats every member beyond them as NULL (not offered), so a host built against an older header stays valid. A size that
+   * does not even cover all_gather is refused. */
+  uint32_t size;
   int32_t rank, world;
   void* user;
   int32_t (*all_to_all)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
@@ -207,6 +214,12 @@ typedef struct ms_comm {
    * rank makes the same sequence of calls. */
   int32_t (*scatter_cols_start)(void* user, int32_t root, const void* send_dev, size_t send_peer_stride, size_t send_col_stride,
                                 void* recv_dev, size_t recv_col_stride, size_t ncols, size_t seg_bytes);
+  /* Optional (NULL = not offered): this rank cannot go on - a validation that fails on ONE rank, an allocation failure, a
+   * failed exchange - while its peers have entered, or are about to enter, the next exchange. ms_prove_sharded calls it on
+   * every error path before it returns, so that the peers' pending and future calls FAIL instead of waiting for operations
+   * that will never be issued (RCCL: ncclCommAbort; threads: ms_comm_local_group_abort). The transport is unusable
+   * afterwards. Without it only the host's watchdog ends a proof one rank has left. Must not fail and must not throw. */
+  void (*abort)(void* user, const char* why);
 } ms_comm;
 #define MS_COMM_SKIP_SELF 1u
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,

@@ -41,7 +41,7 @@ def lib():
 
 def exported_symbols():
     """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
-    return ["ms_last_error", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
+    return ["ms_last_error", "ms_device_count", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_witness_prefetch",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_ctx_comm_progress", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
@@ -70,6 +70,11 @@ def _b(a):
 
 def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def device_count() -> int:
+    """HIP devices visible to this process (ms_device_count; 0 without a GPU or driver)"""
+    return int(lib().ms_device_count())
 
 
 class Context:

@@ -120,6 +120,14 @@ extern "C" {
 
 const char* ms_last_error(void) { return g_err.c_str(); }
 
+int32_t ms_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
 int32_t ms_ctx_create(int32_t device, ms_ctx** out) {
   try {
     *out = new ms_ctx(device);
@@ -274,10 +282,25 @@ int32_t ms_prove(ms_system* sys, ms_witness* w, uint8_t* proof_out, size_t cap, 
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms) {
   MS_TRY StageMs st;
-  if (!comm || !owners || !comm->all_to_all || !comm->all_gather) throw std::runtime_error("ms_prove_sharded: incomplete ms_comm");
-  if (comm->rank < 0 || comm->rank >= comm->world) throw std::runtime_error("ms_prove_sharded: rank out of range");
+  if (!comm || !owners) throw std::runtime_error("ms_prove_sharded: null argument");
+  // the host's table may be shorter than this library's (ms_comm.size): members beyond it are "not offered"
+  if (comm->size < offsetof(ms_comm, all_gather) + sizeof(comm->all_gather))
+    throw std::runtime_error("ms_prove_sharded: ms_comm.size is not set (sizeof(ms_comm) of the host's header) or too small");
+  ms_comm table;
+  memset(&table, 0, sizeof(table));
+  memcpy(&table, comm, std::min<size_t>(comm->size, sizeof(table)));
+  table.size = (uint32_t)sizeof(table);
+  if (!table.all_to_all || !table.all_gather) throw std::runtime_error("ms_prove_sharded: incomplete ms_comm");
+  if (table.rank < 0 || table.rank >= table.world) throw std::runtime_error("ms_prove_sharded: rank out of range");
   g_err.clear();  // (a failing transport callback leaves its reason here; prove_sharded quotes it)
-  std::vector<uint8_t> bytes = prove_sharded(*sys->sys, *w->w, comm, owners, stage_ms ? &st : nullptr);
+  std::vector<uint8_t> bytes;
+  try {
+    bytes = prove_sharded(*sys->sys, *w->w, &table, owners, stage_ms ? &st : nullptr);
+  } catch (const std::exception& e) {
+    // this rank leaves the proof: its peers are in, or about to enter, an exchange it will never join
+    if (table.abort && table.world > 1) table.abort(table.user, e.what());
+    throw;
+  }
   if (stage_ms) memcpy(stage_ms, st.v, sizeof(st.v));
   *proof_len = bytes.size();
   if (bytes.size() > cap) return MS_ERR_BUFFER;

@@ -271,6 +271,13 @@ int32_t cb_wait(void* user) {
   ms_comm_local* c = (ms_comm_local*)user;
   return guarded(c, [&] { c->complete(); });
 }
+void cb_abort(void* user, const char* why) {
+  ms_comm_local* c = static_cast<ms_comm_local*>(user);
+  try {
+    c->g->abort(std::string("rank ") + std::to_string(c->rank) + " left the proof: " + (why ? why : "error"));
+  } catch (...) {
+  }
+}
 int32_t cb_set_stream_ordered(void* user, void* hip_stream) {
   ms_comm_local* c = (ms_comm_local*)user;
   return guarded(c, [&] {
@@ -363,6 +370,8 @@ int32_t ms_comm_local_create(ms_comm_local_group* g, ms_ctx* ctx, int32_t rank, 
       }
     }
     memset(&c->table, 0, sizeof(c->table));
+    c->table.size = (uint32_t)sizeof(ms_comm);
+    c->table.abort = cb_abort;
     c->table.rank = rank;
     c->table.world = g->world;
     c->table.user = c;

@@ -319,6 +319,12 @@ int32_t cb_wait(void* user) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
   return guarded(c, [&] { c->complete(); });
 }
+void cb_abort(void* user, const char*) {
+  try {
+    static_cast<ms_comm_rccl*>(user)->fail();  // ncclCommAbort: the peers' pending and future operations return an error
+  } catch (...) {
+  }
+}
 int32_t cb_set_stream_ordered(void* user, void* hip_stream) {
   ms_comm_rccl* c = (ms_comm_rccl*)user;
   return guarded(c, [&] {
@@ -366,6 +372,8 @@ int32_t ms_comm_rccl_create(ms_ctx* ctx, const uint8_t unique_id[MS_RCCL_UNIQUE_
       nccl_check(rccl().CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
     }
     memset(&c->table, 0, sizeof(c->table));
+    c->table.size = (uint32_t)sizeof(ms_comm);
+    c->table.abort = cb_abort;
     c->table.rank = rank;
     c->table.world = world;
     c->table.user = c;

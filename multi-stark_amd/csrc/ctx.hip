@@ -61,18 +61,32 @@ void RoctxRange::next(const char* name) {
 // MSAMD_ABORT_TRACE=1 (diagnostics): a native backtrace on SIGABRT - the runtime's own assertions and std::terminate say
 // nothing about where they were raised
 namespace {
-void abort_trace(int) {
+struct sigaction g_prev_abort;  // the handler the host had installed (Python's faulthandler, a Rust panic hook): chained to
+void abort_trace(int sig) {
   void* frames[64];
-  const int n = backtrace(frames, 64);
+  const int n = backtrace(frames, 64);  // (the unwinder was loaded by install_abort_trace: no dlopen / malloc in here)
   static const char msg[] = "[msamd] SIGABRT, native backtrace of the aborting thread:\n";
   (void)!write(2, msg, sizeof(msg) - 1);
   backtrace_symbols_fd(frames, n, 2);
-  signal(SIGABRT, SIG_DFL);
-  raise(SIGABRT);
+  // hand the signal on: the host's own handler if it had one, the default action (core, exit status) otherwise
+  if (g_prev_abort.sa_handler != SIG_DFL && g_prev_abort.sa_handler != SIG_IGN && g_prev_abort.sa_handler != abort_trace) {
+    sigaction(SIGABRT, &g_prev_abort, nullptr);
+  } else {
+    signal(SIGABRT, SIG_DFL);
+  }
+  raise(sig);
 }
 void install_abort_trace() {
   static const bool once = [] {
-    if (getenv("MSAMD_ABORT_TRACE")) signal(SIGABRT, abort_trace);
+    if (getenv("MSAMD_ABORT_TRACE")) {
+      void* warm[4];
+      (void)backtrace(warm, 4);  // the first call loads libgcc_s and allocates: not something to do inside a signal handler
+      struct sigaction sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.sa_handler = abort_trace;
+      sigemptyset(&sa.sa_mask);
+      sigaction(SIGABRT, &sa, &g_prev_abort);
+    }
     return true;
   }();
   (void)once;
@@ -492,7 +506,12 @@ void Ctx::h2d(void* dst, const void* src, size_t n) {
 // matrices in the FIRST proof of a wide system, when fresh allocations delay the side stream's launches; short segments are
 // copied by sync_and_deliver, which joins first). The main stream therefore waits for the side stream here.
 void Ctx::join_side_for_copy() {
-  if (side_forked && side_depth == 0) side_join();
+  // join, then fork again at once: the session stays open, so the SideScopes that follow in the same phase keep the short
+  // circuits on the side stream (ending the session here serialised them behind every direct read-back)
+  if (side_forked && side_depth == 0) {
+    side_join();
+    side_fork();
+  }
 }
 
 void Ctx::d2h_queue(void* dst, const void* src, size_t n) {

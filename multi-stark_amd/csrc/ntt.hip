@@ -623,31 +623,41 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
   if (k >= 1 && k <= 6 && logS >= 8 && !getenv("MSAMD_NO_NTT_SMALL")) {
     // a sub-transform of at most 64 points: shifts and additions in registers (ntt_small_strided_k)
     const size_t threads_total = (size_t(1) << logn) >> k;
-    const dim3 grid((unsigned)((threads_total + 255) / 256), (unsigned)ncols);
     const u64 *t0 = inverse ? ctx.tw0i : ctx.tw0, *t1 = inverse ? ctx.tw1i : ctx.tw1;
     hipEvent_t ev = ctx.prof_begin(K_NTT_STRIDED);
-#define MS_SMALL(KK)                                                                                                                     \
-  case KK:                                                                                                                               \
-    if (inverse)                                                                                                                         \
-      hipLaunchKernelGGL((ntt_small_strided_k<KK, (DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logS, logn, t0, t1, src_div, scale, out_mul); \
-    else                                                                                                                                 \
-      hipLaunchKernelGGL((ntt_small_strided_k<KK, (DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logS, logn, t0, t1, src_div, scale, out_mul); \
+    // the columns ride in grid.y (at most 65535 per launch): wider matrices take several launches
+    const size_t sd = src_div ? src_div : 1, per_launch = std::max<size_t>(sd, 65535 / sd * sd);  // (whole groups of src_div columns)
+    if (per_launch > 65535) throw std::runtime_error("ntt: too many output columns per source column");
+    for (size_t c0 = 0; c0 < ncols; c0 += per_launch) {
+      const dim3 grid((unsigned)((threads_total + 255) / 256), (unsigned)std::min<size_t>(ncols - c0, per_launch));
+      const u64* s = src + ((c0 / sd) << logn);
+      u64* d = dst + (c0 << logn);
+#define MS_SMALL(KK)                                                                                                                 \
+  case KK:                                                                                                                           \
+    if (inverse)                                                                                                                     \
+      hipLaunchKernelGGL((ntt_small_strided_k<KK, (DIT != 0), true>), grid, dim3(256), 0, ctx.stream, s, d, logS, logn, t0, t1, src_div, scale, out_mul); \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((ntt_small_strided_k<KK, (DIT != 0), false>), grid, dim3(256), 0, ctx.stream, s, d, logS, logn, t0, t1, src_div, scale, out_mul); \
     break;
-    switch (k) {
-      MS_SMALL(1) MS_SMALL(2) MS_SMALL(3) MS_SMALL(4) MS_SMALL(5) MS_SMALL(6)
-    }
+      switch (k) {
+        MS_SMALL(1) MS_SMALL(2) MS_SMALL(3) MS_SMALL(4) MS_SMALL(5) MS_SMALL(6)
+      }
 #undef MS_SMALL
+      HIP_CHECK(hipGetLastError());
+    }
     ctx.prof_end(K_NTT_STRIDED, ev, 16.0 * double(ncols) * double(size_t(1) << logn));
     return;
   }
   unsigned logT = 12 - k;
   if (logT > logS) logT = logS;
   size_t gx = (size_t(1) << (logS - logT)) << (logn - logB);
+  if (ncols > 65535) throw std::runtime_error("ntt: more than 65535 columns in one generic strided pass");
   dim3 grid((unsigned)gx, (unsigned)ncols);
   size_t shmem = (size_t(8) << (k + logT));
   hipEvent_t ev = ctx.prof_begin(K_NTT_STRIDED);
   hipLaunchKernelGGL(ntt_strided_k<DIT>, grid, dim3(256), shmem, ctx.stream, src, dst, k, logS, logT, logn,
                      inverse ? ctx.tw0i : ctx.tw0, inverse ? ctx.tw1i : ctx.tw1, src_div, scale, out_mul);
+  HIP_CHECK(hipGetLastError());
   ctx.prof_end(K_NTT_STRIDED, ev, 16.0 * double(ncols) * double(size_t(1) << logn));
 }
 
@@ -883,6 +893,7 @@ void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t
   else
     hipLaunchKernelGGL(transpose_in_k, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
                        bitrev_rows ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
   ctx.prof_end(K_TRANSPOSE, ev, 16.0 * double(h) * double(w));
 }
 

@@ -15,15 +15,18 @@ _WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 _ORDERED = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
 _COLS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t)
 _SCATTER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t)
+_ABORT = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
 _COLS2 = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32)
 
 
 class MsComm(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB),
+    _fields_ = [("size", C.c_uint32),  # sizeof(ms_comm) as this binding knows it: the library treats members beyond it as NULL
+                ("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _CB), ("all_gather", _CB),
                 ("all_to_all_start", _START), ("all_to_all_wait", _WAIT), ("all_to_all_cols_start", _COLS),
                 ("set_stream_ordered", _ORDERED),  # (TorchComm leaves it NULL: its callbacks synchronise with the host)
                 ("all_to_all_cols_start2", _COLS2),  # (NULL in TorchComm: the library then calls all_to_all_cols_start)
-                ("scatter_cols_start", _SCATTER)]
+                ("scatter_cols_start", _SCATTER),
+                ("abort", _ABORT)]  # (NULL in TorchComm: torch.distributed's own timeout is what ends a proof a rank has left)
 
 
 class _DevBytes:
@@ -57,7 +60,7 @@ class TorchComm:
         self._cols = _COLS(self._all_to_all_cols_start)
         self._pending = []
         self._scatter = _SCATTER(self._scatter_cols_start)
-        self.struct = MsComm(self.rank, self.world, None, self._a2a, self._ag, self._start, self._wait, self._cols)
+        self.struct = MsComm(C.sizeof(MsComm), self.rank, self.world, None, self._a2a, self._ag, self._start, self._wait, self._cols)
         self.struct.scatter_cols_start = self._scatter
 
     def _view(self, ptr, nbytes):

@@ -47,6 +47,43 @@ def test_rust_binding_lists_every_symbol():
     assert declared == want, (sorted(want - declared), sorted(declared - want))
 
 
+def _header_comm_members():
+    txt = open(os.path.join(ROOT, "include", "mstark.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    body = re.search(r"typedef struct ms_comm \{(.*?)\} ms_comm;", txt, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"\w[\w\s\*]*\(\*(\w+)\)\(", decl)  # function pointer member
+        if m:
+            names.append(m.group(1))
+        else:  # plain members, possibly several per declaration ("int32_t rank, world")
+            names += [n.strip(" *") for n in decl.split(" ", 1)[1].split(",")]
+    return names
+
+
+def test_ms_comm_members_agree_across_bindings(pkg):
+    """the callback table of ms_prove_sharded has the same members, in the same order, in include/mstark.h, in the Rust binding
+    and in the ctypes mirror - a binding that ends early makes the library read past the host's struct (ms_comm.size guards
+    that at run time; this guards it at review time)"""
+    import importlib
+
+    header = _header_comm_members()
+    assert header[:4] == ["size", "rank", "world", "user"] and header[-1] == "abort" and len(header) == 13, header
+    rs = open(os.path.join(ROOT, "bindings", "rust", "mstark_sys.rs")).read()
+    body = re.search(r"pub struct ms_comm \{(.*?)\n\}", rs, flags=re.S).group(1)
+    body = re.sub(r"///[^\n]*", "", body)
+    rust = re.findall(r"pub (\w+):", body)
+    assert rust == header, (rust, header)
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    py = [f[0] for f in sharded.MsComm._fields_]
+    assert py == header, (py, header)
+    # and the ctypes layout is the C layout: one u32 + two i32 + padding, then pointers
+    assert sharded.MsComm.user.offset == 16 and ctypes.sizeof(sharded.MsComm) == 16 + 8 * (len(header) - 3)
+
+
 def test_kernel_names_available_without_gpu(pkg):
     L = pkg.lib()
     n = L.ms_kernel_count()

@@ -356,6 +356,51 @@ def test_thread_ranks_proof_equals_single_gpu_proof(pkg, fe, oracle, world, log_
     assert len(set(res)) == 1, res  # every rank holds the same proof bytes
 
 
+def test_config3_full_size_eight_thread_ranks(pkg, fe):
+    """BASELINE config 3 AS SPECIFIED and at FULL size - [ByteTable, U32Add x 8], 2^20 additions per rank, 8.4 M claims,
+    host-resident witnesses, eight ranks - on the one GPU of the test box (thread ranks time-share it): every rank's bytes
+    equal the single-GPU proof of the same nine-circuit system, and the library's verifier accepts (tools/config3_one_gpu.py
+    is the timed form of the same run)."""
+    import importlib
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    world, log_adds = 8, 20
+    traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
+    packed = fe.pack_claims(claims)
+    owners = sharded.u32_add_owners(world)
+    ctx0 = pkg.Context(0)
+    sys0 = pkg.System.new(ctx0, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+    full = sys0.witness(traces, packed)
+    want = sys0.prove_multiple_claims(full).to_bytes()
+    assert sys0.verify_multiple_claims(packed, want) == 0
+    del full
+    ctx0.trim()
+
+    def body(rank, group):
+        ctx = pkg.Context(0)
+        system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+        mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+        remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+        w = system.host_witness(mine, packed, remote_heights=remote)
+        comm = group.comm(ctx, rank)
+        try:
+            got = [system.prove_sharded(w, comm, owners).to_bytes() for _ in range(2)]
+            return got[0] == want and got[1] == want, comm.bytes_moved
+        finally:
+            comm.close()
+            del w
+            ctx.trim()
+
+    group = sharded.LocalGroup(world)
+    try:
+        res = group.run(body)
+    finally:
+        group.close()
+    assert all(ok for ok, _ in res), [ok for ok, _ in res]
+    # 7/8 of each rank's stage-1 and stage-2 LDEs (14 + 26 columns x 2^22 rows) leave it per proof, plus the small gathers
+    assert res[0][1] / 2 > 0.875 * 40 * (1 << 22) * 8
+
+
 def test_thread_ranks_failure_does_not_hang(pkg, fe, monkeypatch):
     """a rank that fails in the middle of a joint proof (injected allocation failure) makes every rank return an error -
     nobody waits for it forever - and the same contexts prove again afterwards"""
