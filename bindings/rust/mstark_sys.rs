@@ -68,6 +68,7 @@ extern "C" {
     pub fn ms_ctx_create(device: i32, out: *mut *mut ms_ctx) -> i32;
     pub fn ms_ctx_destroy(ctx: *mut ms_ctx);
     pub fn ms_ctx_sync(ctx: *mut ms_ctx) -> i32;
+    pub fn ms_ctx_sync_count(ctx: *mut ms_ctx, out: *mut u64) -> i32;
     pub fn ms_ctx_trim(ctx: *mut ms_ctx) -> i32;
     pub fn ms_ctx_set_profile_mask(ctx: *mut ms_ctx, mask: u32) -> i32;
     pub fn ms_ctx_kernel_stats(ctx: *mut ms_ctx, kernel_id: i32, launches: *mut u64, ms: *mut f64, alg_bytes: *mut f64) -> i32;

@@ -64,6 +64,10 @@ int32_t ms_device_count(void);
 int32_t ms_ctx_create(int32_t device, ms_ctx** out);
 void ms_ctx_destroy(ms_ctx* ctx);
 int32_t ms_ctx_sync(ms_ctx* ctx);
+/* Diagnostics: how often the host has waited for the context's stream since the context was created (every read-back that a
+ * proof needs on the host before it can go on, ms_ctx_sync itself included). A proof's count is the difference around it:
+ * two for ms_prove at the bench size (opened values, FRI), and the joint prover is held to that plus two. */
+int32_t ms_ctx_sync_count(ms_ctx* ctx, uint64_t* out);
 /* release pooled device memory back to the driver */
 int32_t ms_ctx_trim(ms_ctx* ctx);
 /* Per-kernel-class timing with HIP events on the library's stream. mask bit i enables class i. */

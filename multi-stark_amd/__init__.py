@@ -41,7 +41,7 @@ def lib():
 
 def exported_symbols():
     """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
-    return ["ms_last_error", "ms_device_count", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_trim", "ms_ctx_set_profile_mask",
+    return ["ms_last_error", "ms_device_count", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_sync_count", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
             "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_witness_prefetch",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_ctx_comm_progress", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
@@ -99,6 +99,12 @@ class Context:
 
     def sync(self):
         _check(lib().ms_ctx_sync(self.h))
+
+    def sync_count(self):
+        """host waits on this context's stream so far (ms_ctx_sync_count): a proof's count is the difference around it"""
+        n = C.c_uint64()
+        _check(lib().ms_ctx_sync_count(self.h, C.byref(n)))
+        return int(n.value)
 
     def trim(self):
         _check(lib().ms_ctx_trim(self.h))

@@ -144,6 +144,11 @@ int32_t ms_ctx_sync(ms_ctx* ctx) {
   return MS_OK;
   MS_CATCH
 }
+int32_t ms_ctx_sync_count(ms_ctx* ctx, uint64_t* out) {
+  if (!ctx || !out) return MS_ERR;
+  *out = ctx->ctx.host_syncs;
+  return MS_OK;
+}
 int32_t ms_ctx_trim(ms_ctx* ctx) {
   MS_TRY ctx->ctx.trim();
   return MS_OK;

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void flag_copy_k(FlagCopyArgs a) {
 }  // namespace
 
 void Ctx::sync_and_deliver() {
+  host_syncs++;
   side_join();  // read-backs and the staging halves are shared: everything the side stream was given completes first
   hipStream_t stream = main_stream;
   bool done = false;

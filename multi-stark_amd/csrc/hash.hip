@@ -1007,6 +1007,38 @@ void merkle_build(Ctx& ctx, DTree& t) {
   HIP_CHECK(hipGetLastError());
 }
 
+// The levels ABOVE n sub-tree roots (n a power of two, one root per rank of a joint proof: prover_sharded.inc) hashed where the
+// roots are - on the device - so that the commitment never has to visit the host before the transcript step that consumes it:
+// out[0 .. n) = the roots, then n / 2 parents, ..., the root (2 n - 1 digests). One workgroup; log2 n dependent compressions.
+namespace {
+__global__ __launch_bounds__(256) void tree_top_k(const Digest* __restrict__ roots, u32 n, Digest* __restrict__ out) {
+  const u32 t = threadIdx.x;
+  for (u32 i = t; i < n; i += blockDim.x) {
+    u32 d[8];
+    load_digest(roots + i, d);
+    store_digest(out + i, d);
+  }
+  __syncthreads();
+  u32 off = 0;
+  for (u32 len = n; len > 1; len >>= 1) {
+    for (u32 i = t; i < len / 2; i += blockDim.x) {
+      u32 l[8], r[8], d[8];
+      load_digest(out + off + 2 * i, l);
+      load_digest(out + off + 2 * i + 1, r);
+      b3_compress_pair_root(l, r, d);
+      store_digest(out + off + len + i, d);
+    }
+    __syncthreads();  // (one workgroup: the barrier also orders its global stores and loads)
+    off += len;
+  }
+}
+}  // namespace
+void merkle_tree_top(Ctx& ctx, const Digest* d_roots, size_t n, Digest* d_out) {
+  if (n == 0 || (n & (n - 1)) || n > (size_t(1) << 20)) throw std::runtime_error("merkle_tree_top: root count must be a power of two");
+  hipLaunchKernelGGL(tree_top_k, dim3(1), dim3(256), 0, ctx.stream, d_roots, (u32)n, d_out);
+  HIP_CHECK(hipGetLastError());
+}
+
 std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t) {
   size_t cl = t.cap_layer();
   std::vector<Digest> cap(t.layer_len[cl]);

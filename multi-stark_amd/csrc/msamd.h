@@ -132,6 +132,7 @@ struct Ctx {
   std::mutex comm_mu;
   std::string comm_what;
   uint64_t comm_seq = 0;
+  uint64_t host_syncs = 0;  // how often the host has waited for this context's stream (ms_ctx_sync_count)
   bool comm_in_flight = false;
 
   explicit Ctx(int dev);
@@ -147,6 +148,7 @@ struct Ctx {
   // the same without the final host copy: the bytes can be read at the returned address of the pinned staging buffer after
   // the next synchronisation and until the next read-back is queued (nullptr: does not fit, use d2h_queue)
   const uint8_t* d2h_queue_staged(const void* src, size_t n);
+  std::vector<uint8_t> host_scratch2;  // the joint prover's query openings (prover_sharded.inc)
   std::vector<uint8_t> host_scratch;  // grows once; large per-proof host buffers that would otherwise be page-faulted in anew
   const u64* lde_scale(unsigned log_n, unsigned log_blowup);
   // profiling hooks around one launch
@@ -281,6 +283,8 @@ void merkle_alloc(Ctx& ctx, DTree& t, size_t max_height);  // layer table + dige
 struct FriChallenge;
 void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc = nullptr);            // layers 1.. from a filled leaf layer, no injection
 std::vector<Digest> merkle_cap(Ctx& ctx, const DTree& t);  // D2H of the cap layer (synchronises)
+// levels above n sub-tree roots, on the device: d_out[0 .. n) = roots, then n / 2 parents, ..., the root (2 n - 1 digests)
+void merkle_tree_top(Ctx& ctx, const Digest* d_roots, size_t n, Digest* d_out);
 // BLAKE3 of the byte stream prefix (prefix_len bytes) || nwords little-endian u64 words; result to host
 Digest blake3_device(Ctx& ctx, const uint8_t* d_prefix, size_t prefix_len, const u64* d_words, size_t nwords);
 // the same in two steps, so that ranks can split the chunk range: chaining values of chunks [c0, c1) into cvs[c0..c1),
@@ -410,6 +414,8 @@ void outer_beta_gamma(Ctx& ctx, const Digest* d_digest, ChallengeBG* d_bg, u32* 
 void outer_alpha(Ctx& ctx, const u32* d_state12, const Digest* d_cap, size_t ncap, const E2* d_tot, size_t na, const ChallengeBG* d_bg,
                  const std::vector<OuterTarget>& targets, E2* d_accs, E2* d_alpha, u32* d_state8, DBuf<uint8_t>& keep);
 void outer_zeta(Ctx& ctx, const u32* d_state8, const Digest* d_cap, size_t ncap, const u32* d_lds, size_t n_ld, E2* d_points);
+// joint proof: d_all = world rows of [circuit totals | claims share] (one all_gather) -> d_tot[0] = claims' sum, d_tot[1 + pos] = circuit totals
+void outer_joint_totals(Ctx& ctx, const E2* d_all, size_t world, size_t na, const std::vector<int>& src_rank, E2* d_tot);
 // writes quotient values in storage order: out[c * nq + t] for c in {0,1}
 void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* out);
 
@@ -419,6 +425,7 @@ void quotient_eval(Ctx& ctx, const DProgram& prog, const QuotientArgs& a, u64* o
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);
 // storage rows [row0, row0 + rows) only (out / xout still point at row 0 of the full arrays)
 void inv_denoms_rows(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0, size_t rows);
+void inv_denoms_rows_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0, size_t rows);  // point in device memory
 void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout = nullptr, size_t n_x = 0);  // the point read from device memory
 // opened values of a column-major matrix at up to two points: y_p[c] = scale_p * sum_{i<h} col_c[i] * x_i * invden_p[i].
 // bary_sums_async only launches (raw sums to device memory, index c * np + p); bary_finish applies scale_p on the host.
@@ -458,7 +465,9 @@ struct DeepPoints {
 // alpha_pows_host (optional): the same powers on the host; short lists then travel inside the kernel's argument block
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro,
                  const E2* alpha_pows_host = nullptr, Digest* fri_leaves = nullptr /* height / 2 leaf digests of FRI's first round */,
-                 const DeepMat* mats_dev = nullptr /* the list already in device memory */);
+                 const DeepMat* mats_dev = nullptr /* the list already in device memory */,
+                 size_t row0 = 0, size_t full_height = 0 /* rows [row0, row0 + height) of a domain of full_height rows (0 = height): pts.den
+                                                            are indexed by the FULL domain's row */);
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
 // row0 / rows_total: `cur`, `roll_in`, `out` are the slice [row0, row0 + rows) of a folded layer of rows_total rows (0 = whole layer)
 void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out, size_t row0 = 0, size_t rows_total = 0);
@@ -492,8 +501,9 @@ struct GatherSeg {
 void gather_queries(Ctx& ctx, const std::vector<GatherSeg>& segs, const std::vector<uint64_t>& indices, size_t bytes_per_query,
                     uint8_t* host_out);
 // launches only: segment list uploaded to segs_dev, indices read from device memory, openings left in out_dev
+// owner != ~0: only queries with (index >> owner_shift) == owner are served, the other blocks of out_dev stay untouched
 void gather_queries_launch(Ctx& ctx, const std::vector<GatherSeg>& segs, GatherSeg* segs_dev, const u64* indices_dev, size_t n_queries,
-                           size_t bytes_per_query, uint8_t* out_dev);
+                           size_t bytes_per_query, uint8_t* out_dev, unsigned owner_shift = 0, uint32_t owner = ~uint32_t(0));
 // query-phase challenger step on the device (one-coefficient final polynomial): out_dev[0] = PoW witness,
 // out_dev[1 + q] = query index q; state_dev is the challenger state the commit phase left
 void fri_query_challenge(Ctx& ctx, const uint32_t* state_dev, const E2* final_dev, unsigned pow_bits, uint32_t n_queries,

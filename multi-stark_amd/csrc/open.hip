@@ -263,6 +263,7 @@ struct DeepParams {
   size_t height;
   Digest* leaves;  // when set: digest of FRI row i / 2 = (ro[i], ro[i + 1]), the leaf layer of the first commit-phase round
   u32 log_height;  // log2 of the FULL domain the rows belong to (only read for shifted points)
+  size_t row0;     // the launch's row i is row row0 + i of that domain: the inverse denominators are indexed by the full domain's row
 };
 // ro[i] = sum_q den_q[i] * (K_q - sum_m coeff_{m,q} * s_m[i]),  s_m[i] = sum_c alpha^c m[i][c]
 // (= sum over matrices and points of coeff * (red_z - s_m[i]) / (z_q - x_i), regrouped by point so that the
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
       const E2 t1 = e2(gl_sub(K.c0, acc_reduce(T[q][2])), gl_sub(K.c1, acc_reduce(T[q][3])));
       const E2* __restrict__ den = p.pts.den[q];
       const u32 dec = p.pts.shift[q];  // 0, or the point is an earlier one times w^dec: read that one's denominators (rev_dec)
-      r0 = e2_add(r0, e2_mul(t0, den[dec ? rev_dec(i, p.log_height, dec) : i]));
-      r1 = e2_add(r1, e2_mul(t1, den[dec ? rev_dec(i + 1, p.log_height, dec) : i + 1]));
+      const size_t g = p.row0 + i;  // row of the full domain (a joint proof reduces a row range: prover_sharded.inc)
+      r0 = e2_add(r0, e2_mul(t0, den[dec ? rev_dec(g, p.log_height, dec) : g]));
+      r1 = e2_add(r1, e2_mul(t1, den[dec ? rev_dec(g + 1, p.log_height, dec) : g + 1]));
     }
   }
   p.ro[i] = r0;
@@ -465,8 +467,9 @@ __global__ __launch_bounds__(256) void deep_reduce_wide_k(DeepParams p) {
       const E2 t1 = e2(gl_sub(K.c0, tot[q * 4 + 2]), gl_sub(K.c1, tot[q * 4 + 3]));
       const E2* __restrict__ den = p.pts.den[q];
       const u32 dec = p.pts.shift[q];
-      r0 = e2_add(r0, e2_mul(t0, den[dec ? rev_dec(i, p.log_height, dec) : i]));
-      r1 = e2_add(r1, e2_mul(t1, den[dec ? rev_dec(i + 1, p.log_height, dec) : i + 1]));
+      const size_t g = p.row0 + i;  // row of the full domain (a joint proof reduces a row range: prover_sharded.inc)
+      r0 = e2_add(r0, e2_mul(t0, den[dec ? rev_dec(g, p.log_height, dec) : g]));
+      r1 = e2_add(r1, e2_mul(t1, den[dec ? rev_dec(g + 1, p.log_height, dec) : g + 1]));
     }
   }
   p.ro[i] = r0;
@@ -872,10 +875,14 @@ __global__ void gather_k(const GatherReq* __restrict__ reqs, size_t n, uint8_t* 
   }
 }
 
+// owner != ~0: only the queries whose index >> owner_shift equals `owner` are served (a rank of a joint proof holds the rows
+// of its own row range only: prover_sharded.inc); the blocks of the other queries are left as they are (zeroed by the caller)
 __global__ void gather_queries_k(const GatherSeg* __restrict__ segs, const u64* __restrict__ indices, size_t qbytes,
-                                 uint8_t* __restrict__ out) {
+                                 uint8_t* __restrict__ out, u32 owner_shift, u32 owner) {
   const GatherSeg s = segs[blockIdx.x];
-  const u64 e = (indices[blockIdx.y] >> s.shift) ^ s.flip;
+  const u64 index = indices[blockIdx.y];
+  if (owner != ~0u && (u32)(index >> owner_shift) != owner) return;
+  const u64 e = (index >> s.shift) ^ s.flip;
   uint8_t* o = out + size_t(blockIdx.y) * qbytes + s.out_off;
   if (s.kind == 0) {
     const u64* m = (const u64*)s.base;
@@ -911,6 +918,9 @@ static void inv_denoms_launch(Ctx& ctx, E2 z, const E2* z_dev, unsigned log_h, E
 }
 void inv_denoms_rows(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0, size_t rows) {
   inv_denoms_launch(ctx, z, nullptr, log_h, out, xout, n_x, row0, rows);
+}
+void inv_denoms_rows_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x, size_t row0, size_t rows) {
+  inv_denoms_launch(ctx, e2(0), z_dev, log_h, out, xout, n_x, row0, rows);
 }
 void inv_denoms(Ctx& ctx, E2 z, unsigned log_h, E2* out, E2* xout, size_t n_x) { inv_denoms_launch(ctx, z, nullptr, log_h, out, xout, n_x); }
 void inv_denoms_dev(Ctx& ctx, const E2* z_dev, unsigned log_h, E2* out, E2* xout, size_t n_x) {
@@ -1000,7 +1010,7 @@ void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npo
 }
 
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* apow_dev, E2* ro,
-                 const E2* apow_host, Digest* fri_leaves, const DeepMat* mats_dev) {
+                 const E2* apow_host, Digest* fri_leaves, const DeepMat* mats_dev, size_t row0, size_t full_height) {
   if (pts.n > 2) throw std::runtime_error("deep_reduce: more than two opening points at one height");
   for (auto& m : mats)
     for (u32 k = 0; k < m.npoints; k++)
@@ -1015,10 +1025,12 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
     ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
     mats_dev = dm.p;
   }
-  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves, 0};
+  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves, 0, row0};
+  if (!full_height) full_height = height;
+  if (row0 > full_height || height > full_height - row0 || (row0 & 1)) throw std::runtime_error("deep_reduce: row range outside the domain");
   if (pts.shift[0] || pts.shift[1]) {
-    if (height & (height - 1)) throw std::runtime_error("deep_reduce: shifted points need the whole (power-of-two) domain");
-    p.log_height = log2_strict(height);
+    if (full_height & (full_height - 1)) throw std::runtime_error("deep_reduce: shifted points need a power-of-two domain");
+    p.log_height = log2_strict(full_height);
   }
   double bytes = 16.0 * height * (1 + pts.n);
   for (auto& m : mats) bytes += 8.0 * m.w * height;
@@ -1187,11 +1199,12 @@ void fri_query_challenge(Ctx& ctx, const uint32_t* state_dev, const E2* final_de
 }
 
 void gather_queries_launch(Ctx& ctx, const std::vector<GatherSeg>& segs, GatherSeg* segs_dev, const u64* indices_dev, size_t n_queries,
-                           size_t bytes_per_query, uint8_t* out_dev) {
+                           size_t bytes_per_query, uint8_t* out_dev, unsigned owner_shift, uint32_t owner) {
   if (segs.empty() || n_queries == 0) return;
+  if (owner_shift > 63) throw std::runtime_error("gather_queries: owner shift out of range");
   ctx.h2d(segs_dev, segs.data(), segs.size() * sizeof(GatherSeg));
   hipLaunchKernelGGL(gather_queries_k, dim3((unsigned)segs.size(), (unsigned)n_queries), dim3(64), 0, ctx.stream,
-                     (const GatherSeg*)segs_dev, indices_dev, bytes_per_query, out_dev);
+                     (const GatherSeg*)segs_dev, indices_dev, bytes_per_query, out_dev, (u32)owner_shift, (u32)owner);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -134,6 +134,44 @@ __global__ __launch_bounds__(256) void outer_zeta_k(const u32* __restrict__ stat
 
 }  // namespace
 
+namespace {
+// A joint proof's logUp totals (prover_sharded.inc): every rank contributed a row [total of circuit 0 .. na - 1 | its share of
+// the claims' sum] to one all_gather. tot[0] = the claims' sum over all ranks, tot[1 + pos] = circuit pos's total from the
+// rank that computed it - the layout outer_alpha_k reads. Field sums are exact, so the order of the additions is immaterial.
+struct JointTotalsArgs {
+  const E2* all;  // world rows of na + 1 values
+  E2* tot;        // na + 1
+  u32 world, na;
+  uint16_t src[OUTER_MAX_NA];  // which rank's row holds circuit pos's total
+};
+__global__ __launch_bounds__(64) void joint_totals_k(JointTotalsArgs a) {
+  const u32 t = threadIdx.x;
+  if (t < a.na) a.tot[1 + t] = a.all[(size_t)a.src[t] * (a.na + 1) + t];
+  if (t == 63) {
+    E2 acc = e2(0);
+    for (u32 r = 0; r < a.world; r++) acc = e2_add(acc, a.all[(size_t)r * (a.na + 1) + a.na]);
+    a.tot[0] = acc;
+  }
+}
+
+}  // namespace
+
+void outer_joint_totals(Ctx& ctx, const E2* d_all, size_t world, size_t na, const std::vector<int>& src_rank, E2* d_tot) {
+  if (na < 1 || na > OUTER_MAX_NA || src_rank.size() != na || world > 65535) throw std::runtime_error("outer_joint_totals: shape");
+  JointTotalsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.all = d_all;
+  a.tot = d_tot;
+  a.world = (u32)world;
+  a.na = (u32)na;
+  for (size_t i = 0; i < na; i++) {
+    if (src_rank[i] < 0 || (size_t)src_rank[i] >= world) throw std::runtime_error("outer_joint_totals: source rank out of range");
+    a.src[i] = (uint16_t)src_rank[i];
+  }
+  hipLaunchKernelGGL(joint_totals_k, dim3(1), dim3(64), 0, ctx.stream, a);
+  HIP_CHECK(hipGetLastError());
+}
+
 bool outer_fits(size_t ncap, size_t na) { return na >= 1 && na <= OUTER_MAX_NA && 48 + 32 * ncap + 16 * na <= 1024 && 32 + 32 * ncap <= 1024; }
 
 void outer_beta_gamma(Ctx& ctx, const Digest* d_digest, ChallengeBG* d_bg, u32* d_state12) {

@@ -1040,7 +1040,13 @@ struct InputShape {
   std::vector<std::vector<size_t>> widths;
   std::vector<size_t> nsib;
 };
-typedef std::function<void(const std::vector<uint64_t>& indices, size_t qbytes, uint8_t* out)> InputGather;
+struct InputGather {
+  // optional: called with the query indices in DEVICE memory as soon as the device has sampled them, before the FRI phase's one
+  // synchronisation - what it queues (gathers, exchanges, read-backs) arrives with that synchronisation
+  std::function<void(const u64* d_indices, size_t nq)> queue;
+  // the openings of the input rounds for the (host-checked) indices, one block of qbytes per query
+  std::function<void(const std::vector<uint64_t>& indices, size_t qbytes, uint8_t* out)> fetch;
+};
 void add_gather_seg(std::vector<GatherSeg>& segs, size_t& out_off, const void* base, u64 stride, uint32_t count, uint32_t kind,
                     uint32_t shift, uint32_t flip) {
   GatherSeg q;
@@ -1620,6 +1626,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
       d_g = DBuf<uint8_t>(ctx, std::max<size_t>(qbytes * nq, 1));
       d_segs = DBuf<GatherSeg>(ctx, std::max<size_t>(segs.size(), 1));
       gather_queries_launch(ctx, segs, d_segs.p, d_q.p + 1, nq, qbytes, d_g.p);
+      if (remote && remote->queue) remote->queue(d_q.p + 1, nq);  // the input rounds' openings travel with this synchronisation too
       ctx.d2h_queue(dq.data(), d_q.p, dq.size() * 8);
       // (not when the input openings are fetched from other ranks afterwards: those read-backs reuse the staging buffer)
       g = remote ? nullptr : ctx.d2h_queue_staged(d_g.p, qbytes * nq);
@@ -1706,7 +1713,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   const size_t remote_qbytes = input_qbytes + (head ? head->qbytes() : 0);
   if (remote) {
     input_g.resize(remote_qbytes * nq);
-    (*remote)(indices, remote_qbytes, input_g.data());
+    remote->fetch(indices, remote_qbytes, input_g.data());
     tr.mark("remote_input_openings");
   }
 

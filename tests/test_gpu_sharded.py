@@ -401,6 +401,55 @@ def test_config3_full_size_eight_thread_ranks(pkg, fe):
     assert res[0][1] / 2 > 0.875 * 40 * (1 << 22) * 8
 
 
+def test_joint_prover_host_synchronisations(pkg, fe):
+    """the joint prover keeps the transcript on the device like the one-GPU prover (the commitments' top levels are hashed there
+    too, the query openings of the input commitments are gathered and exchanged behind the device-sampled indices): per proof
+    at the bench shape it waits for the device as often as ms_prove does at one rank, and at four ranks only the FRI rounds that
+    run on row shards add their transcript steps"""
+    import importlib
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    log_adds = 13
+    for world in (1, 4):
+        traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
+        packed = fe.pack_claims(claims)
+        owners = sharded.u32_add_owners(world)
+        ctx0 = pkg.Context(0)
+        sys0 = pkg.System.new(ctx0, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+        w0 = sys0.host_witness(traces, packed)
+        want = sys0.prove_multiple_claims(w0).to_bytes()
+        a = ctx0.sync_count()
+        assert sys0.prove_multiple_claims(w0).to_bytes() == want
+        plain = ctx0.sync_count() - a
+        assert plain == 2, plain  # the opened values, FRI
+
+        def body(rank, group):
+            ctx = pkg.Context(0)
+            system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+            mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+            remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+            w = system.host_witness(mine, packed, remote_heights=remote)
+            comm = group.comm(ctx, rank)
+            try:
+                assert system.prove_sharded(w, comm, owners).to_bytes() == want
+                b = ctx.sync_count()
+                assert system.prove_sharded(w, comm, owners).to_bytes() == want
+                return ctx.sync_count() - b
+            finally:
+                comm.close()
+
+        group = sharded.LocalGroup(world)
+        try:
+            counts = group.run(body)
+        finally:
+            group.close()
+        # world > 1 adds log2(world) FRI head rounds on row shards, each with a host transcript step (sub-tree roots, grinding)
+        extra = {1: 0, 4: 2 * 2}[world]
+        assert max(counts) <= plain + 2 + extra, (world, counts, plain)
+        if world == 1:
+            assert max(counts) == plain, (counts, plain)  # one rank: exactly the one-GPU prover's two waits
+
+
 def test_thread_ranks_failure_does_not_hang(pkg, fe, monkeypatch):
     """a rank that fails in the middle of a joint proof (injected allocation failure) makes every rank return an error -
     nobody waits for it forever - and the same contexts prove again afterwards"""

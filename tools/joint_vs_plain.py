@@ -47,6 +47,12 @@ for name, w in (("hbm-resident", system.witness(traces, packed)), ("host-residen
     plain = timed(lambda: system.prove_multiple_claims(w))
     j_rccl = timed(lambda: system.prove_sharded(w, rccl, owners))
     j_local = timed(lambda: system.prove_sharded(w, local, owners))
+    n0 = ctx.sync_count()
+    system.prove_multiple_claims(w)
+    n1 = ctx.sync_count()
+    system.prove_sharded(w, local, owners)
+    n2 = ctx.sync_count()
+    print("   host synchronisations per proof: plain %d, joint %d" % (n1 - n0, n2 - n1))
     st = system.prove_sharded(w, rccl, owners, want_times=True).stage_ms
     sp = system.prove_multiple_claims(w, want_times=True).stage_ms
     print("%-14s plain %.3f ms (best %.3f) | joint/rccl %.3f (best %.3f, %+.3f ms, %+.1f %%) | joint/local %.3f (best %.3f, %+.3f ms)" % (
