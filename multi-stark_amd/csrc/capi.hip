@@ -250,6 +250,7 @@ int32_t ms_witness_prefetch(ms_witness* w, int32_t on) {
   wit.prefetch = on != 0;
   if (!wit.prefetch) {
     HIP_CHECK(hipStreamSynchronize(ctx.copy_stream));
+    HIP_CHECK(hipStreamSynchronize(ctx.claims_stream));
     for (auto& st : wit.stage) st.clear();
   }
   return MS_OK;

@@ -102,6 +102,7 @@ void abandon_pending() {
     if (!g_live.count(c)) return;
   }
   (void)hipStreamSynchronize(c->copy_stream);
+  (void)hipStreamSynchronize(c->claims_stream);
   c->side_join();
   (void)hipStreamSynchronize(c->main_stream);
   (void)hipGetLastError();
@@ -160,6 +161,7 @@ Ctx::Ctx(int dev) : device(dev) {
   for (auto& e : side_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   side_config();
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&claims_stream, hipStreamNonBlocking));
   for (auto& e : copy_ev) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   pinned_half = size_t(8) << 20;
   if (hipHostMalloc((void**)&pinned, 2 * pinned_half + 256, hipHostMallocDefault) != hipSuccess) {
@@ -261,6 +263,7 @@ Ctx::~Ctx() {
   }
   (void)hipSetDevice(device);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (claims_stream) (void)hipStreamSynchronize(claims_stream);
   if (side_stream) (void)hipStreamSynchronize(side_stream);
   stream = main_stream;
   (void)hipStreamSynchronize(stream);
@@ -286,6 +289,7 @@ Ctx::~Ctx() {
   for (auto e : copy_ev)
     if (e) (void)hipEventDestroy(e);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  if (claims_stream) (void)hipStreamDestroy(claims_stream);
   (void)hipStreamDestroy(stream);
 }
 

@@ -63,6 +63,7 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // bulk uploads of a host-resident witness, running beside the kernels of `stream`
+  hipStream_t claims_stream = nullptr;  // the claims of a host-resident witness: DMA copies beside the trace's pulling kernels
   // Side stream for the short circuits of a system (prover.hip): between side_fork() and side_join() the launches queued
   // inside a SideScope go to `side_stream` (the scope swaps `stream`) and run beside the long kernels of the main stream
   // instead of in front of them. Blocks allocated inside a scope come from a pool of their own (`pool_free_side`), and a
@@ -246,6 +247,8 @@ void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t
 void transpose_out(Ctx& ctx, const u64* colmajor, u64* rowmajor, size_t h, size_t w, bool bitrev_rows);
 // out[i] = the i-th little-endian `bytes`-byte value of `packed` (bytes = 1, 2, 4), on `stream`
 void widen_words(const uint8_t* packed, unsigned bytes, size_t count, u64* out, hipStream_t stream);
+// the same from PINNED HOST memory, read by the kernel itself (no staging copy): host_packed 16-byte aligned
+void pull_widen_words(const uint8_t* host_packed, unsigned bytes, size_t count, u64* out, hipStream_t stream);
 // coefficients (unscaled inverse DFT output, natural order, column-major n x w) -> bit-reversed coset LDE (Bn x w)
 void lde_from_coeffs(Ctx& ctx, const u64* coef, u64* lde, unsigned logn, unsigned log_blowup, size_t w);
 // evaluations in bit-reversed row order (column-major n x w, destroyed) -> bit-reversed coset LDE (Bn x w)

@@ -706,6 +706,7 @@ HWitness::~HWitness() {
   if (sys && sys->ctx) {
     (void)hipSetDevice(sys->ctx->device);
     (void)hipStreamSynchronize(sys->ctx->copy_stream);  // a prefetch may still be writing into the staged buffers
+    (void)hipStreamSynchronize(sys->ctx->claims_stream);
   }
   for (auto& st : stage)
     for (auto& e : st.ev)
@@ -832,6 +833,24 @@ struct HostUpload {
     HIP_CHECK(hipEventRecord(ctx.copy_ev[3], ctx.stream));
     HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[3], 0));
     std::vector<DBuf<uint8_t>> narrow(C);  // released when the proof's uploads have been waited for (the destructor's sync)
+    // The claims (42 MB at the bench size) are needed when the stage-1 tree is hashed, 0.8 ms after the trace has landed, and
+    // take 0.75 ms of the link: behind the trace's chunks on the copy stream they arrive just in time (kernel-only rocprofv3
+    // timeline: claims_words_k starts with the leaf hashing). MSAMD_CLAIMS_OWN_STREAM=1 starts them at once on a stream of
+    // their own, as DMA copies beside the chunks' pulling kernels - measured WORSE (6.9 against 6.4 ms per step): the link is the
+    // narrow upload's bottleneck, and what the claims take of it early delays the trace, which is on the critical path.
+    const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
+    static const bool claims_own_stream = getenv("MSAMD_CLAIMS_OWN_STREAM") != nullptr;
+    auto upload_claims = [&](hipStream_t s) {
+      st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
+      st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
+      HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, s));
+      if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipEventRecord(st.ev[2], s));
+    };
+    if (!skip_claims && claims_own_stream) {
+      HIP_CHECK(hipStreamWaitEvent(ctx.claims_stream, ctx.copy_ev[3], 0));  // (the pool blocks may still be in use, as above)
+      upload_claims(ctx.claims_stream);
+    }
     for (size_t ci = 0; ci < C; ci++) {
       const HCircuit& c = sys.circuits[ci];
       const size_t h = w.heights[ci];
@@ -843,7 +862,8 @@ struct HostUpload {
       bool sent = false;
       if (pool) {
         // the host threads narrow chunk k + 1 while chunk k crosses the link; the device widens the whole trace afterwards
-        narrow[ci] = DBuf<uint8_t>(ctx, cnt * pb);
+        static const bool pull = !getenv("MSAMD_NO_PULL");  // MSAMD_NO_PULL=1: DMA copy into a staging buffer + widening launch
+        if (!pull) narrow[ci] = DBuf<uint8_t>(ctx, cnt * pb);
         {
           static const size_t n_chunks = getenv("MSAMD_PACK_CHUNKS") ? (size_t)atoi(getenv("MSAMD_PACK_CHUNKS")) : 8;
           PackPool::Job job(*pool, w.h_traces[ci], w.h_packed[ci], pb, cnt, n_chunks);
@@ -855,8 +875,12 @@ struct HostUpload {
             }
             if (k == 0) g_probes.mark("narrow upload: first chunk ready");
             const size_t b = pool->chunk_begin(k), e = pool->chunk_begin(k + 1);
-            HIP_CHECK(hipMemcpyAsync(narrow[ci].p + b * pb, w.h_packed[ci] + b * pb, (e - b) * pb, hipMemcpyHostToDevice, ctx.copy_stream));
-            widen_words(narrow[ci].p + b * pb, pb, e - b, st.traces[ci].p + b, ctx.copy_stream);  // behind its chunk: only the last one is exposed
+            if (pull) {  // ONE launch per chunk: the kernel reads the pinned narrow words over the link and writes 64-bit words
+              pull_widen_words(w.h_packed[ci] + b * pb, pb, e - b, st.traces[ci].p + b, ctx.copy_stream);
+            } else {
+              HIP_CHECK(hipMemcpyAsync(narrow[ci].p + b * pb, w.h_packed[ci] + b * pb, (e - b) * pb, hipMemcpyHostToDevice, ctx.copy_stream));
+              widen_words(narrow[ci].p + b * pb, pb, e - b, st.traces[ci].p + b, ctx.copy_stream);  // behind its chunk: only the last one is exposed
+            }
           }
           g_probes.mark("narrow upload: last chunk queued");
         }
@@ -880,14 +904,8 @@ struct HostUpload {
           HIP_CHECK(hipMemcpyAsync(st.args[ci].p, w.h_args[ci].data(), w.h_args[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
       }
     }
-    const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
-    if (!skip_claims) {
-      st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
-      st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
-      HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, ctx.copy_stream));
-      if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, ctx.copy_stream));
-    }
-    HIP_CHECK(hipEventRecord(st.ev[2], ctx.copy_stream));
+    if (!skip_claims && !claims_own_stream) upload_claims(ctx.copy_stream);
+    if (skip_claims) HIP_CHECK(hipEventRecord(st.ev[2], ctx.copy_stream));
     // SystemWitness::from_stage_1 (src/system.rs:244-328) as one kernel per circuit, from the traces just uploaded, queued on
     // the copy stream behind the copies: it writes 344 MB at config 2 and runs beside the transforms of stage 1 (which are
     // bound by the vector ALU) instead of in front of stage 2
@@ -926,7 +944,11 @@ struct HostUpload {
   }
   // the lookup values (uploaded, or computed on the copy stream from the uploaded traces) are complete
   void lookup_values() {
-    if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[1], 0));
+    if (!on) return;
+    HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[1], 0));
+    // a side stream that is already forked (the claims' logUp sum runs there) does not inherit this wait: the short circuits'
+    // stage-2 kernels queued on it next read the same lookup values
+    if (ctx.side_forked && ctx.stream != ctx.side_stream) HIP_CHECK(hipStreamWaitEvent(ctx.side_stream, w.stage[w.cur].ev[1], 0));
   }
   void wait_claims() {
     if (on) HIP_CHECK(hipStreamWaitEvent(ctx.stream, w.stage[w.cur].ev[2], 0));
@@ -936,6 +958,7 @@ struct HostUpload {
     // this proof's copies may still be in flight when it is abandoned: wait before the blocks return to the pool (a
     // prefetch queued behind them is then complete as well, which costs nothing: it is shorter than the proof)
     (void)hipStreamSynchronize(ctx.copy_stream);
+    (void)hipStreamSynchronize(ctx.claims_stream);
     w.stage[w.cur].narrow.clear();
     for (auto& t : w.traces) t.reset();
     for (auto& lk : w.lookups) {

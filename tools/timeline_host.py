@@ -15,7 +15,7 @@ for r in m:
 ev.sort()
 # the last proof starts at the first H2D copy after the last gather_queries_k of the previous one
 gq = [i for i, e in enumerate(ev) if "gather_queries_k" in e[2]]
-i0 = next(i for i in range(gq[-2], len(ev)) if "HOST_TO_DEVICE" in ev[i][2])
+i0 = next(i for i in range(gq[-2], len(ev)) if "HOST_TO_DEVICE" in ev[i][2] or "pull_widen_k" in ev[i][2])
 t0 = ev[i0][0]
 last = ev[gq[-1]][1]
 n_show = int(sys.argv[2]) if len(sys.argv) > 2 else 46
