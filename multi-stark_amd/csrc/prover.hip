@@ -833,6 +833,8 @@ struct HostUpload {
     HIP_CHECK(hipEventRecord(ctx.copy_ev[3], ctx.stream));
     HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[3], 0));
     std::vector<DBuf<uint8_t>> narrow(C);  // released when the proof's uploads have been waited for (the destructor's sync)
+    bool used_second = false;
+    HIP_CHECK(hipStreamWaitEvent(ctx.claims_stream, ctx.copy_ev[3], 0));  // (pool blocks may still be in use by earlier kernels)
     // The claims (42 MB at the bench size) are needed when the stage-1 tree is hashed, 0.8 ms after the trace has landed, and
     // take 0.75 ms of the link: behind the trace's chunks on the copy stream they arrive just in time (kernel-only rocprofv3
     // timeline: claims_words_k starts with the leaf hashing). MSAMD_CLAIMS_OWN_STREAM=1 starts them at once on a stream of
@@ -863,6 +865,7 @@ struct HostUpload {
       if (pool) {
         // the host threads narrow chunk k + 1 while chunk k crosses the link; the device widens the whole trace afterwards
         static const bool pull = !getenv("MSAMD_NO_PULL");  // MSAMD_NO_PULL=1: DMA copy into a staging buffer + widening launch
+        static const bool two_streams = getenv("MSAMD_PULL_TWO_STREAMS") != nullptr;  // (measured: no difference, 6.03-6.16 ms either way)
         if (!pull) narrow[ci] = DBuf<uint8_t>(ctx, cnt * pb);
         {
           static const size_t n_chunks = getenv("MSAMD_PACK_CHUNKS") ? (size_t)atoi(getenv("MSAMD_PACK_CHUNKS")) : 8;
@@ -876,7 +879,10 @@ struct HostUpload {
             if (k == 0) g_probes.mark("narrow upload: first chunk ready");
             const size_t b = pool->chunk_begin(k), e = pool->chunk_begin(k + 1);
             if (pull) {  // ONE launch per chunk: the kernel reads the pinned narrow words over the link and writes 64-bit words
-              pull_widen_words(w.h_packed[ci] + b * pb, pb, e - b, st.traces[ci].p + b, ctx.copy_stream);
+              // (two streams in turn: the next chunk's first requests leave while this chunk's last ones drain)
+              const bool second = two_streams && (k & 1);
+              pull_widen_words(w.h_packed[ci] + b * pb, pb, e - b, st.traces[ci].p + b, second ? ctx.claims_stream : ctx.copy_stream);
+              used_second = used_second || second;
             } else {
               HIP_CHECK(hipMemcpyAsync(narrow[ci].p + b * pb, w.h_packed[ci] + b * pb, (e - b) * pb, hipMemcpyHostToDevice, ctx.copy_stream));
               widen_words(narrow[ci].p + b * pb, pb, e - b, st.traces[ci].p + b, ctx.copy_stream);  // behind its chunk: only the last one is exposed
@@ -886,6 +892,10 @@ struct HostUpload {
         }
       }
       if (!sent) HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], cnt * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+    }
+    if (used_second) {  // the chunks pulled on the second stream are part of "the traces have arrived"
+      HIP_CHECK(hipEventRecord(ctx.copy_ev[2], ctx.claims_stream));
+      HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[2], 0));
     }
     HIP_CHECK(hipEventRecord(st.ev[0], ctx.copy_stream));
     st.narrow = std::move(narrow);
