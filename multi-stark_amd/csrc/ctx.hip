@@ -374,6 +374,16 @@ void Ctx::side_config() {
   side_delay_us = d ? (unsigned)std::min(atoi(d), 20000) : 0u;
   d = getenv("MSAMD_MAIN_DELAY_US");
   main_delay_us = d ? (unsigned)std::min(atoi(d), 20000) : 0u;
+  d = getenv("MSAMD_COPY_DELAY_US");
+  copy_delay_us = d ? (unsigned)std::min(atoi(d), 20000) : 0u;
+}
+
+// MSAMD_COPY_DELAY_US=n (diagnostics): the copy stream starts n microseconds late at every proof's upload, so that a kernel
+// which reads uploaded data (traces, lookup values, claims) without waiting for the upload's event reads stale data every time
+void Ctx::copy_delay() {
+  if (!copy_delay_us) return;
+  hipLaunchKernelGGL(side_delay_k, dim3(1), dim3(1), 0, copy_stream, (unsigned long long)copy_delay_us * 100ull);
+  HIP_CHECK(hipGetLastError());
 }
 
 void Ctx::side_fork() {

@@ -82,6 +82,8 @@ struct Ctx {
   void side_fork();   // the side stream waits for everything queued on the main stream so far
   void side_join();   // the main stream waits for everything queued on the side stream so far
   unsigned side_delay_us = 0, main_delay_us = 0;  // MSAMD_SIDE_DELAY_US / MSAMD_MAIN_DELAY_US (diagnostics)
+  unsigned copy_delay_us = 0;                     // MSAMD_COPY_DELAY_US (diagnostics)
+  void copy_delay();  // delays the copy stream by copy_delay_us (called where a proof's uploads begin)
   void join_side_for_copy();  // in front of a read-back issued at once on the main stream (its source may be the side stream's work)
   hipEvent_t copy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   u64 *tw0 = nullptr, *tw1 = nullptr, *tw0i = nullptr, *tw1i = nullptr;

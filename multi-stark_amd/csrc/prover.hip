@@ -832,6 +832,8 @@ struct HostUpload {
     // buffers first: pool blocks handed out here may still be in use by kernels queued earlier on ctx.stream
     HIP_CHECK(hipEventRecord(ctx.copy_ev[3], ctx.stream));
     HIP_CHECK(hipStreamWaitEvent(ctx.copy_stream, ctx.copy_ev[3], 0));
+    ctx.side_config();
+    ctx.copy_delay();  // (diagnostics: MSAMD_COPY_DELAY_US)
     std::vector<DBuf<uint8_t>> narrow(C);  // released when the proof's uploads have been waited for (the destructor's sync)
     bool used_second = false;
     HIP_CHECK(hipStreamWaitEvent(ctx.claims_stream, ctx.copy_ev[3], 0));  // (pool blocks may still be in use by earlier kernels)
