@@ -162,8 +162,8 @@ int32_t ms_verify(ms_system* sys, size_t n_claims, const uint64_t* claim_offsets
  * the heights of all circuits, and all claims. owners[i] = rank that computes circuit i, or -1 = replicated on every
  * rank (small tables). A rank may own any number of circuits (none included) of any shapes: the reference's multi-circuit
  * systems (one wide circuit beside tables of other widths and heights, src/test_circuits/blake3.rs:2215-2613) split as they
- * are. Limits: the number of ranks is a power of two; every committed LDE has at least as many rows as there are ranks;
- * cap_height <= log2(ranks). When there is exactly one sharded circuit per rank, all of one shape, the k-th owned by rank k
+ * are. Limits: the number of ranks is a power of two; every committed LDE has at least as many rows as there are ranks
+ * (any cap_height: a cap taller than log2(ranks) is gathered from inside the ranks' sub-trees). When there is exactly one sharded circuit per rank, all of one shape, the k-th owned by rank k
  * (BASELINE config 3) the row ranges travel by one symmetric all-to-all per column group; otherwise every sharded matrix is
  * handed out by its owner (ms_comm.scatter_cols_start, which the transport must then offer).
  * The library calls back for the two exchanges it needs; both take DEVICE pointers of this context's device, are

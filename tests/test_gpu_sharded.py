@@ -337,7 +337,10 @@ def _thread_rank(pkg, fe, sharded, oracle, rank, group, log_adds, variant, share
 
 @pytest.mark.parametrize("world,log_adds,variant", [
     (8, 8, "bench"), (8, 10, "bench"), (8, 8, "cap3"), (8, 10, "cap3"), (8, 9, "cap1"), (8, 9, "pack"), (8, 9, "host-sync"),
-    (8, 9, "no-overlap"), (8, 9, "full-fri"), (2, 9, "bench"), (4, 10, "bench"), (4, 9, "pack"), (1, 9, "bench"), (4, 9, "arity3"), (8, 8, "arity2")])
+    (8, 9, "no-overlap"), (8, 9, "full-fri"), (2, 9, "bench"), (4, 10, "bench"), (4, 9, "pack"), (1, 9, "bench"), (4, 9, "arity3"), (8, 8, "arity2"),
+    # caps TALLER than the ranks' sub-trees are apart (cap_height > log2 ranks: the cap is made of layers inside the sub-trees),
+    # up to a cap that is the byte table's whole leaf layer and beyond the device transcript's one-chunk limit
+    (8, 9, "cap4"), (8, 13, "cap4"), (4, 9, "cap5"), (2, 9, "cap3"), (1, 9, "cap2"), (1, 13, "cap2"), (4, 8, "cap12")])
 def test_thread_ranks_proof_equals_single_gpu_proof(pkg, fe, oracle, world, log_adds, variant, monkeypatch):
     import importlib
 
