@@ -5,7 +5,7 @@
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 find_csv() { find "$1" -name "*$2" | head -1; }
@@ -27,5 +27,13 @@ echo "== config 4"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT
 cp "$(find_csv $OUT/bb kernel_stats.csv)" $OUT/${TAG}_config4_kernel_stats.csv
 python3 $REPO/tools/prof_summary.py $OUT/${TAG}_config4_kernel_stats.csv 14 30 > $OUT/${TAG}_config4_kernel_stats_summary_per_proof.txt
 python3 $REPO/bench.py --config babybear --steps 20 --warmup 5 > $OUT/${TAG}_config4_bench_line.json 2> $OUT/bb_line.log || exit 1
-rm -rf $OUT/stats $OUT/sq $OUT/clk $OUT/fetch $OUT/write $OUT/tl $OUT/bb
+echo "== host-resident timeline"; rocprofv3 --kernel-trace --output-format csv -d $OUT/tlh -- python3 $REPO/tools/trace_host.py > /dev/null 2> $OUT/tlh.log || exit 1
+python3 $REPO/tools/timeline_host.py "$(dirname "$(find_csv $OUT/tlh kernel_trace.csv)")" 60 > $OUT/${TAG}_timeline_host.txt
+echo "== joint vs plain"; python3 $REPO/tools/joint_vs_plain.py > $OUT/${TAG}_joint_vs_plain.txt 2>&1 || exit 1
+python3 $REPO/tools/joint_kernel_diff.py > $OUT/${TAG}_joint_kernel_diff.txt 2>&1 || exit 1
+echo "== micro benchmarks (the source of the integer issue peak and of the field-arithmetic rates)"
+for m in b3_rate gl_sgpr gl_rate acc_rate pull_rate; do
+  if [ -x $REPO/tools/micro/$m ]; then timeout -k 10 120 $REPO/tools/micro/$m > $OUT/${TAG}_micro_$m.txt 2>&1 || echo "micro $m failed" >> $OUT/${TAG}_micro_$m.txt; fi
+done
+rm -rf $OUT/stats $OUT/sq $OUT/clk $OUT/fetch $OUT/write $OUT/tl $OUT/bb $OUT/tlh
 ls -la $OUT

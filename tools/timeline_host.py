@@ -6,7 +6,8 @@ import sys
 
 d = sys.argv[1]
 k = list(csv.DictReader(open(glob.glob(d + "/*_kernel_trace.csv")[0])))
-m = list(csv.DictReader(open(glob.glob(d + "/*_memory_copy_trace.csv")[0])))
+mc = glob.glob(d + "/*_memory_copy_trace.csv")  # (absent from a kernel-only trace: the memory-copy domain stretches the copies' gaps)
+m = list(csv.DictReader(open(mc[0]))) if mc else []
 ev = []
 for r in k:
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "kernel " + r["Kernel_Name"].replace("msamd::(anonymous namespace)::", "").split("(")[0][:44]))
