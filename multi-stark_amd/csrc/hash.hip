@@ -904,6 +904,13 @@ static void build_levels(Ctx& ctx, DTree& t, const std::vector<InjectAt>& inj, c
   HIP_CHECK(hipGetLastError());
 }
 
+void merkle_top_challenge(Ctx& ctx, Digest* layer, size_t len, const FriChallenge& fc) {
+  if (len < 2 || len > 1024 || (len & (len - 1))) throw std::runtime_error("merkle_top_challenge: 2 .. 1024 roots, a power of two");
+  if (!fc.state || !fc.rec) throw std::runtime_error("merkle_top_challenge: challenger state missing");
+  hipLaunchKernelGGL(tree_tail_k<true>, dim3(1), dim3(1024), 0, ctx.stream, layer, (u32)len, fc);
+  HIP_CHECK(hipGetLastError());
+}
+
 void merkle_compress_plain(Ctx& ctx, DTree& t, const FriChallenge* fc) {
   std::vector<InjectAt> inj(t.layer_len.size());
   build_levels(ctx, t, inj, nullptr, fc);

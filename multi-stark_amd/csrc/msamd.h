@@ -543,8 +543,13 @@ bool fri_round_fusable(size_t rows);
 void fri_round_fused(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriTailRound* prev, const E2* roll_in, E2* out,
                      const FriChallenge& fc);
 // fold with beta read from rec (device); next_leaves != nullptr also writes the next layer's leaf digests
+// row0 / rows_total: `cur`, `roll_in`, `out` are the slice [row0, row0 + rows) of a folded layer of rows_total rows (0 = whole layer)
 void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in /*nullable*/, E2* out,
-                  Digest* next_leaves /*nullable*/);
+                  Digest* next_leaves /*nullable*/, size_t row0 = 0, size_t rows_total = 0);
+// A FRI round whose tree is spread over ranks (prover_sharded.inc): `layer` holds the `len` sub-tree roots (2 <= len <= 1024, a
+// power of two) with room for len - 1 more digests behind them; ONE launch hashes the levels above them into that room and runs
+// the round's challenger step (observe the root, grind, sample beta: challenge_dev.h), as the last workgroup of subtree_k does
+void merkle_top_challenge(Ctx& ctx, Digest* layer, size_t len, const FriChallenge& fc);
 // cap of a tree + (when it fits) the PoW witness for transcript prefix || cap, in one host synchronisation
 std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<uint8_t>& prefix, unsigned bits, bool* found,
                                   u64* witness);

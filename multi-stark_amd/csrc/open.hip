@@ -565,7 +565,8 @@ template <bool LEAF>
 __global__ __launch_bounds__(256) void fri_fold_dev_k(const E2* __restrict__ cur, size_t rows, unsigned log_rows,
                                                       const FriTailRound* __restrict__ rec, const E2* __restrict__ roll,
                                                       const u64* __restrict__ t0i, const u64* __restrict__ t1i, E2* __restrict__ out,
-                                                      Digest* __restrict__ leaves) {
+                                                      Digest* __restrict__ leaves, size_t row0) {
+  // (row0: cur / roll / out are the slice [row0, row0 + rows) of a layer of 2^log_rows rows - a rank's row range of a joint proof)
   const size_t j = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (2 * j >= rows) return;
   const u64 half = 0x7FFFFFFF80000001ULL;  // 1/2 mod p
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void fri_fold_dev_k(const E2* __restrict__ cur
     const size_t i = 2 * j + k;
     o[k] = e2(0);
     if (i < rows) {
-      u32 e = bitrev32((u32)i, log_rows) << (TW_LOG - log_rows - 1);
+      u32 e = bitrev32((u32)(row0 + i), log_rows) << (TW_LOG - log_rows - 1);
       u64 gp = gl_mul(t1i[e >> TW_HALF], t0i[e & ((1u << TW_HALF) - 1)]);
       E2 pw = e2_mul_base(hb, gp);
       E2 r = fri_fold_value(cur[2 * i], cur[2 * i + 1], pw);
@@ -1074,18 +1075,20 @@ void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriCha
   merkle_compress_plain(ctx, t, fc);
 }
 
-void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in, E2* out, Digest* next_leaves) {
-  unsigned lr = log2_strict(rows);
+void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in, E2* out, Digest* next_leaves, size_t row0,
+                  size_t rows_total) {
+  unsigned lr = log2_strict(rows_total ? rows_total : rows);
+  if (row0 + rows > (size_t(1) << lr)) throw std::runtime_error("fri_fold_dev: row range outside the layer");
   if (lr + 1 > TW_LOG) throw std::runtime_error("FRI layer above 2^28 is not supported");
   if (next_leaves && rows < 2) throw std::runtime_error("fri_fold_dev: no next layer to hash");
   const size_t threads = (rows + 1) / 2;
   hipEvent_t ev = ctx.prof_begin(K_FRI_FOLD);
   if (next_leaves)
     hipLaunchKernelGGL(fri_fold_dev_k<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, rec, roll_in,
-                       ctx.tw0i, ctx.tw1i, out, next_leaves);
+                       ctx.tw0i, ctx.tw1i, out, next_leaves, row0);
   else
     hipLaunchKernelGGL(fri_fold_dev_k<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, rec,
-                       roll_in, ctx.tw0i, ctx.tw1i, out, next_leaves);
+                       roll_in, ctx.tw0i, ctx.tw1i, out, next_leaves, row0);
   ctx.prof_end(K_FRI_FOLD, ev, (next_leaves ? 64.0 : 48.0) * rows);
   HIP_CHECK(hipGetLastError());
 }

@@ -1104,6 +1104,12 @@ struct FriHead {
   std::vector<std::vector<Digest>> commits;    // per head round
   std::vector<u64> pow;
   std::vector<size_t> nsib;                    // path length of each head round's opening
+  // The head rounds' transcript steps ran on the DEVICE (merkle_top_challenge): d_state is the challenger state they left
+  // (fri_prove goes on from it), d_recs their records (root, witness, beta); fri_prove reads the records back with its own,
+  // replays them on the host challenger and fills `commits` and `pow` - which are empty until then.
+  bool on_device = false;
+  DBuf<uint32_t> d_state;
+  DBuf<FriTailRound> d_recs;
   size_t qbytes() const {
     size_t b = 0;
     for (size_t n : nsib) b += 16 + 32 * n;
@@ -1112,7 +1118,7 @@ struct FriHead {
 };
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
                size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr,
-               const FriHead* head = nullptr, DTree* round0 = nullptr);
+               FriHead* head = nullptr, DTree* round0 = nullptr);
 
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
 void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes,
@@ -1422,7 +1428,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
 // every matrix row, then the sibling digests bottom-up) or, when the committed data is spread over ranks, by
 // `remote`, called with the sampled indices and filling the same layout.
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
-               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr, const FriHead* head,
+               size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr, FriHead* head,
                DTree* round0) {
   Ctx& ctx = *sys.ctx;
   const unsigned head_rounds = head ? head->n_rounds : 0;
@@ -1460,6 +1466,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   // With a one-coefficient final polynomial the query phase's challenger work (observe the final polynomial, grind,
   // sample every index) also runs on the device and the openings are gathered from the device-side indices, so
   // the whole of FRI costs one host synchronisation; the host replay below checks witness and indices.
+  if (head && head->on_device && !dev_rounds) throw std::runtime_error("FRI: head rounds on the device need the device transcript for the rest");
   const bool dev_query = dev_rounds && final_len == 1 && prm.query_pow_bits <= 16 && prm.num_queries <= 4096 && !getenv("MSAMD_HOST_QUERY");
   size_t n_total = 0;
   DBuf<uint32_t> d_state;
@@ -1469,8 +1476,12 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   if (dev_rounds) {
     const bool use_tail = !getenv("MSAMD_NO_FRI_TAIL");
     for (size_t l = folded.n; l > stop; l >>= 1) n_total++;
-    d_state = DBuf<uint32_t>(ctx, 8);
-    ctx.h2d(d_state.p, ch.input.data(), 32);
+    if (head && head->on_device) {
+      d_state = std::move(head->d_state);  // the head rounds' challenger steps have run on the device: go on from their state
+    } else {
+      d_state = DBuf<uint32_t>(ctx, 8);
+      ctx.h2d(d_state.p, ch.input.data(), 32);
+    }
     d_recs = DBuf<FriTailRound>(ctx, n_total);
     d_final = DBuf<E2>(ctx, stop);
     size_t r = 0;
@@ -1671,13 +1682,27 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
         g = g_vec.data();
       }
     }
-    std::vector<FriTailRound> recs(n_total);
+    std::vector<FriTailRound> recs(n_total), hrecs(head && head->on_device ? head_rounds : 0);
     fin.resize(stop);
     ctx.d2h_queue(recs.data(), d_recs.p, n_total * sizeof(FriTailRound));
+    if (!hrecs.empty()) ctx.d2h_queue(hrecs.data(), head->d_recs.p, hrecs.size() * sizeof(FriTailRound));
     g_probes.mark("FRI queued");
     ctx.d2h(fin.data(), fin_src, stop * sizeof(E2));  // the one synchronisation of the FRI phase
     g_probes.mark("sync 5 (FRI)");
     fin_hold.reset();
+    for (size_t k = 0; k < hrecs.size(); k++) {  // the rounds that ran on row shards, replayed first: they come first in the transcript
+      Digest root;
+      memcpy(root.b, hrecs[k].root, 32);
+      std::vector<Digest> cap(1, root);
+      ch.observe_cap(cap);
+      head->commits.push_back(cap);
+      if (prm.commit_pow_bits) {
+        ch.observe(hrecs[k].witness);
+        if (ch.sample_bits((unsigned)prm.commit_pow_bits) != 0) throw std::runtime_error("FRI: device witness rejected by the host challenger");
+      }
+      head->pow.push_back(prm.commit_pow_bits ? hrecs[k].witness : 0);
+      if (!e2_same(ch.sample_ext(), hrecs[k].beta)) throw std::runtime_error("FRI: device challenger diverged from the host transcript");
+    }
     for (size_t k = 0; k < n_total; k++) {
       Digest root;
       memcpy(root.b, recs[k].root, 32);
