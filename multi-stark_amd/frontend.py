@@ -759,12 +759,77 @@ def even_odd_traces():
 
 
 # --------------------------------------------------------------------------- BabyBear / Poseidon2 configuration
-def poseidon2_constants(seed=42):
-    """141 round constants for Poseidon2BabyBear<16> (8 x 16 external, then 13 internal), uniform below p.
-    The reference draws them from rand's SmallRng::seed_from_u64(42) (src/test_circuits/baby_bear_config.rs:54-55), a
-    stream that cannot be reproduced without that crate, so they are an INPUT of this build; this helper is a documented
-    stand-in (numpy PCG64, the same seed number) - not the reference's constants."""
+def poseidon2_constants_stand_in(seed=42):
+    """141 uniform values below p from numpy's PCG64: the stand-in constants of rounds 1-3 (kept for the fuzzers, which want many
+    different permutations, and as the second instantiation the parity tests run under)."""
     return np.random.default_rng(seed).integers(0, BABYBEAR["P"], 141, dtype=np.uint64)
+
+
+class SmallRngXoshiro:
+    """rand's `SmallRng` on a 64-bit target = Xoshiro256++, seeded by `seed_from_u64` through SplitMix64, `next_u32` = the HIGH half
+    of `next_u64` [UPSTREAM-RECALL: rand 0.9 `rngs::xoshiro256plusplus`; the reference pins rand 0.10.2 (Cargo.lock:864-865), whose
+    SmallRng is assumed unchanged - the pinning kit's 141 dumped constants settle it, tests/test_reference_pins.py]. The
+    generator itself is the published xoshiro256++ 1.0 (Blackman / Vigna), checked against its reference vector in
+    tests/test_frontend.py."""
+
+    MASK = (1 << 64) - 1
+
+    def __init__(self, seed_u64):
+        s, st = [], seed_u64 & self.MASK
+        for _ in range(4):  # SplitMix64: one output per 8 seed bytes, little-endian words = the state words in order
+            st = (st + 0x9E3779B97F4A7C15) & self.MASK
+            z = st
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.MASK
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.MASK
+            s.append(z ^ (z >> 31))
+        self.s = s
+
+    @staticmethod
+    def _rotl(x, k):
+        return ((x << k) | (x >> (64 - k))) & SmallRngXoshiro.MASK
+
+    def next_u64(self):
+        s = self.s
+        result = (self._rotl((s[0] + s[3]) & self.MASK, 23) + s[0]) & self.MASK
+        t = (s[1] << 17) & self.MASK
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = self._rotl(s[3], 45)
+        return result
+
+    def next_u32(self):
+        return self.next_u64() >> 32
+
+
+def poseidon2_constants_small_rng(seed=42):
+    """The reference's own instantiation, restated: `Perm::new_from_rng_128(&mut SmallRng::seed_from_u64(42))`
+    (src/test_circuits/baby_bear_config.rs:54-55) [UPSTREAM-RECALL for everything below; nothing in the reference's tree pins it]:
+      * p3-poseidon2 `Poseidon2::new_from_rng_128` -> round numbers for BabyBear, width 16, S-box degree 7: 8 full rounds, 13
+        partial ones; `ExternalLayerConstants::new_from_rng` draws the 4 initial rounds' [F; 16] arrays, then the 4 terminal
+        ones, element by element, and the 13 internal constants follow;
+      * p3-monty-31 `Distribution<MontyField31> for StandardUniform`: `loop { let x = rng.next_u32() >> 1; if x < P { return
+        MontyField31::new_monty(x) } }` - the 31-bit value is taken AS the Montgomery word, so the field element is x * 2^-32.
+    Returned as canonical values in the front-end's order (initial, terminal, internal), which is what the ABI takes."""
+    p = BABYBEAR["P"]
+    rng = SmallRngXoshiro(seed)
+    r_inv = pow(1 << 32, -1, p)
+    out = []
+    while len(out) < 141:
+        x = rng.next_u32() >> 1
+        if x < p:
+            out.append(x * r_inv % p)
+    return np.array(out, dtype=np.uint64)
+
+
+def poseidon2_constants(seed=42):
+    """141 round constants for Poseidon2BabyBear<16> (8 x 16 external: initial then terminal; then 13 internal), canonical values.
+    Default = the restatement of the reference's instantiation (poseidon2_constants_small_rng: SmallRng::seed_from_u64(42) ->
+    new_from_rng_128, labelled UPSTREAM-RECALL and checked by the pinning kit's dumped constants when they arrive); they remain
+    INPUTS of the library (msbb_system_create takes them), so any other instantiation works the same."""
+    return poseidon2_constants_small_rng(seed)
 
 
 def mul_air_inputs():

@@ -88,9 +88,9 @@ def proofs():
 
 
 def babybear_refs():
-    """The reference's second configuration (src/test_circuits/baby_bear_config.rs) on oracle/libms_oracle_bb.so, with the
-    documented stand-in Poseidon2 constants of frontend.poseidon2_constants(42) (the reference's own constants come from
-    an RNG stream that cannot be reproduced here)."""
+    """The reference's second configuration (src/test_circuits/baby_bear_config.rs) on oracle/libms_oracle_bb.so, instantiated
+    as the reference does - Perm::new_from_rng_128(SmallRng::seed_from_u64(42)), restated in frontend.poseidon2_constants_small_rng
+    (UPSTREAM-RECALL: checked by the pinning kit's dumped constants when they arrive)."""
     import oracle_bb as ob
 
     fe = load_package().frontend

@@ -90,3 +90,26 @@ def test_node_vectors_have_not_drifted(fe):
     assert set(got) == set(want)
     for name in want:
         assert got[name] == want[name], "front-end output changed for: %s (regenerate the golden file only if the change is intended)" % name
+
+
+def test_small_rng_restatement_matches_published_vectors(fe):
+    """The generator behind the BabyBear configuration's Poseidon2 constants (SmallRng::seed_from_u64(42),
+    src/test_circuits/baby_bear_config.rs:54-55) is xoshiro256++ seeded through SplitMix64: both are published algorithms with
+    published vectors (xoshiro256plusplus.c from state {1, 2, 3, 4}; SplitMix64 from 0). What stays UPSTREAM-RECALL is how rand
+    and p3 wire them together (frontend.poseidon2_constants_small_rng) - the pinning kit's 141 dumped constants settle that."""
+    r = fe.SmallRngXoshiro.__new__(fe.SmallRngXoshiro)
+    r.s = [1, 2, 3, 4]
+    assert [r.next_u64() for _ in range(10)] == [
+        41943041, 58720359, 3588806011781223, 3591011842654386, 9228616714210784205, 9973669472204895162, 14011001112246962877,
+        12406186145184390807, 15849039046786891736, 10450023813501588000]
+    assert fe.SmallRngXoshiro(0).s == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F, 0xF88BB8A8724C81EC]
+    k = fe.poseidon2_constants()
+    assert len(k) == 141 and int(k.max()) < fe.BABYBEAR["P"] and len(set(int(x) for x in k)) == 141
+    assert (k == fe.poseidon2_constants_small_rng(42)).all() and not (k == fe.poseidon2_constants_stand_in(42)).all()
+    # the Montgomery word of the first constant is the first accepted 31-bit draw
+    first = fe.SmallRngXoshiro(42)
+    while True:
+        x = first.next_u32() >> 1
+        if x < fe.BABYBEAR["P"]:
+            break
+    assert int(k[0]) * (1 << 32) % fe.BABYBEAR["P"] == x
