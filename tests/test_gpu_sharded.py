@@ -550,7 +550,8 @@ def _thread_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
             rng = np.random.default_rng(master.integers(0, 1 << 62))
             lb = int(rng.integers(1, 3))
             lw = world.bit_length() - 1
-            params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 1)), log_final_poly_len=0,
+            # (caps up to two levels taller than log2 ranks: gathered from inside the sub-trees)
+            params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 3)), log_final_poly_len=0,
                                num_queries=int(rng.integers(1, 12)), commit_proof_of_work_bits=int(rng.integers(0, 5)),
                                query_proof_of_work_bits=int(rng.integers(0, 5)))
             shard_ci, shard_w, fixed_h = fz.random_circuit(rng, fe, lb)
@@ -576,6 +577,8 @@ def _thread_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
             if any(t.shape[0] < world for t in traces):
                 continue
             claims = [[int(x) for x in fz.rand_field(rng, int(rng.integers(0, 5)))] for _ in range(int(rng.integers(0, 4)))]
+            if rng.random() < 0.4:  # more than 8192 claim words: the joint prover keeps the outer transcript on the device
+                claims += [[int(x) for x in fz.rand_field(rng, int(rng.integers(2000, 4000)))] for _ in range(int(rng.integers(3, 6)))]
             packed = fe.pack_claims(claims)
             try:
                 compiled = [fe.compile_circuit(c) for c in circuits]
@@ -588,6 +591,8 @@ def _thread_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
             mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
             remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
             proof = system.prove_sharded(system.witness(mine, packed, remote_heights=remote), comm, owners).to_bytes()
+            if case % 3 == 0:  # and from a host-resident witness (this rank's slice of the claims uploaded inside the proof)
+                assert system.prove_sharded(system.host_witness(mine, packed, remote_heights=remote), comm, owners).to_bytes() == proof
             if rank == case % world:  # the single-GPU proof of the same system, checked by a different rank every case
                 want = system.prove_multiple_claims(system.witness(traces, packed)).to_bytes()
                 assert proof == want, "random case %d: sharded proof differs from the single-GPU proof" % case
@@ -750,7 +755,7 @@ def _general_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
             rng = np.random.default_rng(master.integers(0, 1 << 62))
             lb = int(rng.integers(1, 3))
             lw = world.bit_length() - 1
-            params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 1)), log_final_poly_len=0,
+            params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, lw + 3)), log_final_poly_len=0,
                                num_queries=int(rng.integers(1, 12)), commit_proof_of_work_bits=int(rng.integers(0, 5)),
                                query_proof_of_work_bits=int(rng.integers(0, 5)))
             circuits, traces, owners = [], [], []
@@ -763,6 +768,8 @@ def _general_random_rank(pkg, fe, fz, np, rank, group, seed, n_cases):
             if any(t.shape[0] < world for t in traces):
                 continue
             claims = [[int(x) for x in fz.rand_field(rng, int(rng.integers(0, 5)))] for _ in range(int(rng.integers(0, 4)))]
+            if rng.random() < 0.4:  # more than 8192 claim words: the outer transcript on the device
+                claims += [[int(x) for x in fz.rand_field(rng, int(rng.integers(2000, 4000)))] for _ in range(int(rng.integers(3, 6)))]
             packed = fe.pack_claims(claims)
             try:
                 compiled = [fe.compile_circuit(c) for c in circuits]
