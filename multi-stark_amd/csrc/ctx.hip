@@ -425,7 +425,7 @@ struct FlagCopySeg {
   uint32_t dst_off, n;  // byte offset in the staging half, byte count (multiples of 4 take the word path)
 };
 struct FlagCopyArgs {
-  FlagCopySeg seg[12];
+  FlagCopySeg seg[24];
   uint32_t n_seg, seq;
   uint8_t* host_base;   // device-visible address of the staging half
   uint32_t* flag;       // device-visible address of the flag word
@@ -452,18 +452,24 @@ void Ctx::sync_and_deliver() {
   side_join();  // read-backs and the staging halves are shared: everything the side stream was given completes first
   hipStream_t stream = main_stream;
   bool done = false;
-  if (flag_host && !down_pending.empty() && down_pending.size() <= 12 && !down_direct && !getenv("MSAMD_NO_FLAG_SYNC")) {
+  // Segments that were copied into the staging half when they were queued (long ones: a DMA copy on this stream) need nothing
+  // but to have completed - the flag kernel runs behind them in the stream; the short ones are moved by the kernel itself.
+  size_t n_short = 0;
+  for (auto& d : down_pending) n_short += d.copied ? 0 : 1;
+  if (flag_host && !down_pending.empty() && n_short <= 24 && !down_direct && !getenv("MSAMD_NO_FLAG_SYNC")) {
     FlagCopyArgs a;
     memset(&a, 0, sizeof(a));
-    size_t total = 0;
+    size_t total = 0, k = 0;
     for (size_t i = 0; i < down_pending.size(); i++) {
-      a.seg[i].src = (const uint8_t*)down_pending[i].src;
-      a.seg[i].dst_off = (uint32_t)down_pending[i].off;
-      a.seg[i].n = (uint32_t)down_pending[i].n;
+      if (down_pending[i].copied) continue;
+      a.seg[k].src = (const uint8_t*)down_pending[i].src;
+      a.seg[k].dst_off = (uint32_t)down_pending[i].off;
+      a.seg[k].n = (uint32_t)down_pending[i].n;
       total += down_pending[i].n;
+      k++;
     }
     if (total <= (size_t(64) << 10)) {
-      a.n_seg = (uint32_t)down_pending.size();
+      a.n_seg = (uint32_t)k;
       a.seq = ++flag_seq;
       a.host_base = pinned_dev + pinned_half;
       a.flag = flag_dev;
@@ -563,8 +569,8 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   if (!flag_host || n > (size_t(64) << 10)) {
     join_side_for_copy();
     HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
-    pd.copied = true;
-    down_direct = true;
+    pd.copied = true;  // (into the pinned staging half: complete once the stream has passed it - the flag kernel is enough)
+    if (!flag_host) down_direct = true;
   }
   down_pending.push_back(pd);
   down_used += need;
@@ -583,8 +589,8 @@ const uint8_t* Ctx::d2h_queue_staged(const void* src, size_t n) {
   if (!flag_host || n > (size_t(64) << 10)) {
     join_side_for_copy();
     HIP_CHECK(hipMemcpyAsync(pinned + pinned_half + down_used, src, n, hipMemcpyDeviceToHost, stream));
-    pd.copied = true;
-    down_direct = true;
+    pd.copied = true;  // (into the pinned staging half: complete once the stream has passed it - the flag kernel is enough)
+    if (!flag_host) down_direct = true;
   }
   down_pending.push_back(pd);
   const uint8_t* at = pinned + pinned_half + down_used;

@@ -418,7 +418,8 @@ bool outer_fits(size_t ncap, size_t na);  // every transcript piece is a single 
 void outer_beta_gamma(Ctx& ctx, const Digest* d_digest, ChallengeBG* d_bg, u32* d_state12);
 void outer_alpha(Ctx& ctx, const u32* d_state12, const Digest* d_cap, size_t ncap, const E2* d_tot, size_t na, const ChallengeBG* d_bg,
                  const std::vector<OuterTarget>& targets, E2* d_accs, E2* d_alpha, u32* d_state8, DBuf<uint8_t>& keep);
-void outer_zeta(Ctx& ctx, const u32* d_state8, const Digest* d_cap, size_t ncap, const u32* d_lds, size_t n_ld, E2* d_points);
+void outer_zeta(Ctx& ctx, const u32* d_state8, const Digest* d_cap, size_t ncap, const u32* d_lds, size_t n_ld, E2* d_points,
+                u32* d_state_out = nullptr /* 8 words: the challenger's input buffer behind zeta (where the opened values are absorbed) */);
 // joint proof: d_all = world rows of [circuit totals | claims share] (one all_gather) -> d_tot[0] = claims' sum, d_tot[1 + pos] = circuit totals
 void outer_joint_totals(Ctx& ctx, const E2* d_all, size_t world, size_t na, const std::vector<int>& src_rank, E2* d_tot);
 // writes quotient values in storage order: out[c * nq + t] for c in {0,1}
@@ -466,13 +467,46 @@ struct DeepPoints {
   uint32_t shift[2];    // 0, or: z_q = z' * w^shift for the point z' whose denominators den[q] holds (w = the domain's generator);
                         // the kernel then reads den[q] through open.hip::rev_dec, and K / the coefficients carry the factor w^-shift
 };
+// ---- the opened values' transcript step on the device (open.hip::open_alpha_k; src/prover.rs:540-580 -> p3 TwoAdicFriPcs::open):
+// finish the barycentric sums, absorb every opened value into the transcript (BLAKE3 of state || values), sample the FRI batching
+// challenge alpha and fill what the reduced openings need from it - alpha's powers, every matrix's coefficients, every height's
+// constants K - so that nothing between the barycentric sums and the end of FRI waits for the host. The host replays the step
+// from the raw sums afterwards (it is the authority on the challenge; the values are the kernels' output either way).
+struct OpenEntry {      // one (matrix, point) of the opening, in the transcript's observe order (round -> matrix -> point)
+  uint32_t sum_off;     // the matrix's raw sums start here in the sums array (value of column c, point p at sum_off + c * np + p)
+  uint32_t out_off;     // where this entry's w finished values go in the opened array (= observe order)
+  uint32_t w, np, p;    // columns; points of the matrix; which of them this entry is
+  uint32_t log_h;       // log2 of the trace height (the barycentric domain: the coset of 2^log_h points)
+  uint32_t point_id;    // the point's index in the device point array (zeta, zeta * g ...)
+  uint32_t mat;         // index of the matrix's DeepMat in the blob; ~0 = no reduced opening for it
+  uint32_t exp;         // its coefficient is alpha^exp ...
+  uint32_t slot;        // ... and coeff * sum_c alpha^c y_c is added to K[slot]
+  uint64_t s_pow, dinv; // 7^(2^log_h) and 1 / (2^log_h * s_pow): the finishing factor is (z^(2^log_h) - s_pow) * dinv
+  uint64_t cmul;        // the coefficient's extra factor (1, or g^-1 for a point read through another one's denominators)
+};
+struct OpenAlphaArgs {
+  const OpenEntry* entries;
+  uint32_t n_entries, n_vals, gw, n_slots;
+  const E2* sums;       // raw barycentric sums
+  const E2* points;     // device opening points
+  const uint32_t* state_in;  // 8 words: the challenger's input buffer (the digest its last sample left)
+  E2* opened;           // n_vals finished values in observe order
+  E2* apow;             // gw + 1 powers of alpha
+  struct DeepMat* mats; // the DeepMat blob: coeff / coeff7 are filled here
+  E2* K;                // n_slots constants
+  uint32_t* state_out;  // 8 words: the input buffer after the sample (where FRI's transcript goes on)
+  E2* alpha_out;
+  Digest* cv_scratch;   // one chaining value per 1024 bytes of transcript
+};
+void open_alpha(Ctx& ctx, const OpenAlphaArgs& a);
 // ro[i] = sum over matrices/points of coeff * (red_z - sum_c alpha^c m[i][c]) / (z - x_i)
 // alpha_pows_host (optional): the same powers on the host; short lists then travel inside the kernel's argument block
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* alpha_pows_dev, E2* ro,
                  const E2* alpha_pows_host = nullptr, Digest* fri_leaves = nullptr /* height / 2 leaf digests of FRI's first round */,
                  const DeepMat* mats_dev = nullptr /* the list already in device memory */,
                  size_t row0 = 0, size_t full_height = 0 /* rows [row0, row0 + height) of a domain of full_height rows (0 = height): pts.den
-                                                            are indexed by the FULL domain's row */);
+                                                            are indexed by the FULL domain's row */,
+                 const E2* K_dev = nullptr /* the points' constants K in device memory (open_alpha_k) instead of pts.K */);
 // FRI: leaves of pairs -> digests handled by merkle_build on a 4-column view; fold:
 // row0 / rows_total: `cur`, `roll_in`, `out` are the slice [row0, row0 + rows) of a folded layer of rows_total rows (0 = whole layer)
 void fri_fold(Ctx& ctx, const E2* cur, size_t rows, E2 beta, const E2* roll_in /*nullable*/, E2* out, size_t row0 = 0, size_t rows_total = 0);

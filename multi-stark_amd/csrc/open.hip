@@ -7,6 +7,7 @@
 #include "b3_quad.h"
 #include "challenge_dev.h"
 #include "fri_dev.h"
+#include "outer_dev.h"
 #include "tree_dev.h"
 #include "msamd.h"
 
@@ -264,6 +265,7 @@ struct DeepParams {
   Digest* leaves;  // when set: digest of FRI row i / 2 = (ro[i], ro[i + 1]), the leaf layer of the first commit-phase round
   u32 log_height;  // log2 of the FULL domain the rows belong to (only read for shifted points)
   size_t row0;     // the launch's row i is row row0 + i of that domain: the inverse denominators are indexed by the full domain's row
+  const E2* K_dev; // when set: the points' constants K lie here (filled by open_alpha_k), not in pts.K
 };
 // ro[i] = sum_q den_q[i] * (K_q - sum_m coeff_{m,q} * s_m[i]),  s_m[i] = sum_c alpha^c m[i][c]
 // (= sum over matrices and points of coeff * (red_z - s_m[i]) / (z_q - x_i), regrouped by point so that the
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void deep_reduce_k(DeepParams p) {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     if ((u32)q < p.pts.n) {
-      const E2 K = p.pts.K[q];
+      const E2 K = p.K_dev ? p.K_dev[q] : p.pts.K[q];
       const E2 t0 = e2(gl_sub(K.c0, acc_reduce(T[q][0])), gl_sub(K.c1, acc_reduce(T[q][1])));
       const E2 t1 = e2(gl_sub(K.c0, acc_reduce(T[q][2])), gl_sub(K.c1, acc_reduce(T[q][3])));
       const E2* __restrict__ den = p.pts.den[q];
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void deep_reduce_wide_k(DeepParams p) {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     if ((u32)q < p.pts.n) {
-      const E2 K = p.pts.K[q];
+      const E2 K = p.K_dev ? p.K_dev[q] : p.pts.K[q];
       const E2 t0 = e2(gl_sub(K.c0, tot[q * 4 + 0]), gl_sub(K.c1, tot[q * 4 + 1]));
       const E2 t1 = e2(gl_sub(K.c0, tot[q * 4 + 2]), gl_sub(K.c1, tot[q * 4 + 3]));
       const E2* __restrict__ den = p.pts.den[q];
@@ -1000,6 +1002,145 @@ void bary_sums_batch(Ctx& ctx, const std::vector<BarySpec>& specs, DBuf<E2>& par
 }
 
 // y = sum * (z^h - s^h) / (h s^h), s = GENERATOR (p3 interpolate_coset); sums indexed c * np + p
+// ---- open_alpha_k: see msamd.h (OpenAlphaArgs). One workgroup of 256 threads.
+namespace {
+__device__ __forceinline__ u32 open_msg_word(const OpenAlphaArgs& a, u32 i) {
+  // the transcript piece as 32-bit words: the 8 state words, then the opened values (c0 low, c0 high, c1 low, c1 high)
+  return i < 8 ? a.state_in[i] : reinterpret_cast<const u32*>(a.opened)[i - 8];
+}
+constexpr u32 OPEN_MAX_ENTRIES = 512;
+__device__ __forceinline__ E2 wave_sum_e2(E2 v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const u64 o0 = (u64)__shfl_xor((unsigned long long)v.c0, m, 64), o1 = (u64)__shfl_xor((unsigned long long)v.c1, m, 64);
+    v = e2(gl_add(v.c0, o0), gl_add(v.c1, o1));
+  }
+  return v;
+}
+__global__ __launch_bounds__(256) void open_alpha_k(OpenAlphaArgs a) {
+  __shared__ E2 sh_alpha;
+  __shared__ E2 sh_e[OPEN_MAX_ENTRIES];  // per entry: the finishing factor, later the coefficient, later coeff * column sum
+  const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // (1) finish the barycentric sums: y = sum * (z^(2^log_h) - s_pow) * dinv, into observe order. The factor is one chain of
+  // log_h squarings per entry: a thread per entry computes it, then everybody scales
+  for (u32 e = t; e < a.n_entries; e += 256) {
+    const OpenEntry en = a.entries[e];
+    sh_e[e] = e2_mul_base(e2_sub(e2_exp_pow2(a.points[en.point_id], en.log_h), e2(en.s_pow)), en.dinv);
+  }
+  __syncthreads();
+  for (u32 e = wave; e < a.n_entries; e += 4) {
+    const OpenEntry en = a.entries[e];
+    const E2 scale = sh_e[e];
+    for (u32 c = lane; c < en.w; c += 64) a.opened[en.out_off + c] = e2_mul(a.sums[en.sum_off + c * en.np + en.p], scale);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // (2) BLAKE3 of state || values: a lane per 1024-byte chunk, then the left-full tree over the chaining values
+  const u32 len = 32 + 16 * a.n_vals, nchunks = (len + 1023) / 1024;
+  for (u32 ch = t; ch < nchunks; ch += 256) {
+    const u32 clen = len - 1024 * ch < 1024 ? len - 1024 * ch : 1024;
+    const u32 nblk = (clen + 63) / 64;
+    u32 cv[8];
+    b3_iv(cv);
+    for (u32 b = 0; b < nblk; b++) {
+      u32 m[16];
+      const u32 bl = clen - 64 * b < 64 ? clen - 64 * b : 64;
+#pragma unroll
+      for (u32 k = 0; k < 16; k++) m[k] = 4 * k < bl ? open_msg_word(a, 256 * ch + 16 * b + k) : 0u;
+      const u32 flags = (b == 0 ? (u32)B3_CHUNK_START : 0u) | (b + 1 == nblk ? (u32)B3_CHUNK_END | (nchunks == 1 ? (u32)B3_ROOT : 0u) : 0u);
+      b3_compress(cv, m, ch, bl, flags);
+    }
+    store_digest(a.cv_scratch + ch, cv);
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (u32 n = nchunks; n > 1; n = (n + 1) / 2) {  // pair adjacent values, an odd last one moves up unchanged; in place
+    const u32 nn = (n + 1) / 2;
+    u32 d[8];
+    // node i reads 2 i and 2 i + 1 (>= i) and is written to i: passes of 256 nodes from the left, reads and writes of a pass
+    // separated by a barrier, never overwrite an input a later pass still needs
+    for (u32 base = 0; base < nn; base += 256) {
+      const u32 i = base + t;
+      const bool on = i < nn;
+      if (on) {
+        if (2 * i + 1 < n) {
+          u32 l[8], r[8], m[16];
+          load_digest(a.cv_scratch + 2 * i, l);
+          load_digest(a.cv_scratch + 2 * i + 1, r);
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            m[k] = l[k];
+            m[8 + k] = r[k];
+          }
+          b3_iv(d);
+          b3_compress(d, m, 0, 64, B3_PARENT | (n == 2 ? (u32)B3_ROOT : 0u));
+        } else {
+          load_digest(a.cv_scratch + 2 * i, d);
+        }
+      }
+      __syncthreads();
+      if (on) store_digest(a.cv_scratch + i, d);
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  // (3) alpha <- sample; the input buffer afterwards is the latest digest
+  if (t == 0) {
+    DevChallenger s;
+    u32 dg[8];
+    load_digest(a.cv_scratch, dg);
+    for (int k = 0; k < 8; k++) s.dg[k] = dg[k];
+    s.pos = 32;
+    const E2 alpha = dc_sample_ext(s);
+    for (int k = 0; k < 8; k++) a.state_out[k] = s.dg[k];
+    *a.alpha_out = alpha;
+    sh_alpha = alpha;
+  }
+  __syncthreads();
+  const E2 alpha = sh_alpha;
+  // (4) alpha's powers, and every entry's coefficient alpha^exp * cmul (a thread per power / per entry)
+  for (u32 i = t; i <= a.gw; i += 256) a.apow[i] = e2_pow(alpha, i);
+  for (u32 e = t; e < a.n_entries; e += 256) {
+    const OpenEntry en = a.entries[e];
+    sh_e[e] = e2_mul_base(e2_pow(alpha, en.exp), en.cmul);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // (5) per entry (a wave each, in turn): the column sum sum_c alpha^c y_c; lane 0 leaves the coefficient in the matrix's
+  // descriptor and coeff * sum for the constants
+  for (u32 e = wave; e < a.n_entries; e += 4) {
+    const OpenEntry en = a.entries[e];
+    if (en.mat == ~0u) continue;
+    E2 part = e2(0);
+    for (u32 c = lane; c < en.w; c += 64) part = e2_add(part, e2_mul(a.apow[c], a.opened[en.out_off + c]));
+    part = wave_sum_e2(part);
+    if (lane == 0) {
+      const E2 coeff = sh_e[e];
+      DeepMat& dm = a.mats[en.mat];
+      dm.coeff[en.p] = coeff;
+      dm.coeff7[en.p] = gl_mul(coeff.c1, GL_EXT_W);
+      sh_e[e] = e2_mul(coeff, part);
+    }
+  }
+  __syncthreads();
+  // (6) the constants: K[slot] = sum over the slot's entries (field sums are exact: any order)
+  for (u32 sl = t; sl < a.n_slots; sl += 256) {
+    E2 k = e2(0);
+    for (u32 e = 0; e < a.n_entries; e++)
+      if (a.entries[e].slot == sl && a.entries[e].mat != ~0u) k = e2_add(k, sh_e[e]);
+    a.K[sl] = k;
+  }
+}
+}  // namespace
+
+void open_alpha(Ctx& ctx, const OpenAlphaArgs& a) {
+  if (!a.entries || !a.sums || !a.points || !a.state_in || !a.opened || !a.apow || !a.state_out || !a.alpha_out || !a.cv_scratch)
+    throw std::runtime_error("open_alpha: null argument");
+  if (a.n_entries > OPEN_MAX_ENTRIES) throw std::runtime_error("open_alpha: too many (matrix, point) pairs");
+  hipLaunchKernelGGL(open_alpha_k, dim3(1), dim3(256), 0, ctx.stream, a);
+  HIP_CHECK(hipGetLastError());
+}
+
 void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npoints, E2* out /* p * w + c */) {
   size_t h = size_t(1) << log_h;
   u64 s_pow = gl_exp_pow2(GL_GEN, log_h);
@@ -1011,7 +1152,7 @@ void bary_finish(const E2* sums, size_t w, unsigned log_h, const E2* zs, int npo
 }
 
 void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& pts, size_t height, const E2* apow_dev, E2* ro,
-                 const E2* apow_host, Digest* fri_leaves, const DeepMat* mats_dev, size_t row0, size_t full_height) {
+                 const E2* apow_host, Digest* fri_leaves, const DeepMat* mats_dev, size_t row0, size_t full_height, const E2* K_dev) {
   if (pts.n > 2) throw std::runtime_error("deep_reduce: more than two opening points at one height");
   for (auto& m : mats)
     for (u32 k = 0; k < m.npoints; k++)
@@ -1026,7 +1167,7 @@ void deep_reduce(Ctx& ctx, const std::vector<DeepMat>& mats, const DeepPoints& p
     ctx.h2d(dm.p, mats.data(), mats.size() * sizeof(DeepMat));
     mats_dev = dm.p;
   }
-  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves, 0, row0};
+  DeepParams p{mats_dev, (u32)mats.size(), apow_dev, pts, ro, height, fri_leaves, 0, row0, K_dev};
   if (!full_height) full_height = height;
   if (row0 > full_height || height > full_height - row0 || (row0 & 1)) throw std::runtime_error("deep_reduce: row range outside the domain");
   if (pts.shift[0] || pts.shift[1]) {

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void outer_alpha_k(OuterAlphaArgs a) {
 
 // observe the quotient commitment, zeta <- sample; points[0] = zeta, points[1 + i] = zeta * g(2^lds[i]) (src/prover.rs:538-560)
 __global__ __launch_bounds__(256) void outer_zeta_k(const u32* __restrict__ state_in, const u32* __restrict__ cap, u32 ncap,
-                                                    const u32* __restrict__ lds, u32 n_ld, E2* __restrict__ points) {
+                                                    const u32* __restrict__ lds, u32 n_ld, E2* __restrict__ points,
+                                                    u32* __restrict__ state_out /* nullable: 8 words, the input buffer behind zeta */) {
   __shared__ u32 msg[256];
   __shared__ E2 sh_zeta;
   const u32 t = threadIdx.x;
@@ -127,6 +128,8 @@ __global__ __launch_bounds__(256) void outer_zeta_k(const u32* __restrict__ stat
     const E2 zeta = dc_sample_ext(s);
     points[0] = zeta;
     sh_zeta = zeta;
+    if (state_out)
+      for (int k = 0; k < 8; k++) state_out[k] = s.dg[k];
   }
   __syncthreads();
   for (u32 i = t; i < n_ld; i += 256) points[1 + i] = e2_mul_base(sh_zeta, gl_two_adic_generator(lds[i]));
@@ -208,10 +211,10 @@ void outer_alpha(Ctx& ctx, const u32* d_state12, const Digest* d_cap, size_t nca
   HIP_CHECK(hipGetLastError());
 }
 
-void outer_zeta(Ctx& ctx, const u32* d_state8, const Digest* d_cap, size_t ncap, const u32* d_lds, size_t n_ld, E2* d_points) {
+void outer_zeta(Ctx& ctx, const u32* d_state8, const Digest* d_cap, size_t ncap, const u32* d_lds, size_t n_ld, E2* d_points, u32* d_state_out) {
   if (32 + 32 * ncap > 1024) throw std::runtime_error("outer_zeta: transcript piece does not fit one BLAKE3 chunk");
   hipLaunchKernelGGL(outer_zeta_k, dim3(1), dim3(256), 0, ctx.stream, d_state8, reinterpret_cast<const u32*>(d_cap), (u32)ncap, d_lds, (u32)n_ld,
-                     d_points);
+                     d_points, d_state_out);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -1031,6 +1031,7 @@ bool e2_same(E2 a, E2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
 // moment the host needs the values - returns every value; pcs_open then swaps the placeholders for them.
 struct SymbolicPoints {
   const E2* d_points = nullptr;
+  const u32* d_state = nullptr;  // 8 words: the challenger's input buffer behind the last point's sample (device), or null
   size_t n = 0;
   std::function<void(std::vector<E2>& values)> resolve;
   std::vector<int> next_log;  // per id: point id = point 0 times the generator of the subgroup of order 2^next_log[id] (-1: unrelated)
@@ -1116,9 +1117,16 @@ struct FriHead {
     return b;
   }
 };
+// FRI's transcript starts from a state that lies on the DEVICE (the opened values were absorbed there, open_alpha_k): fri_prove
+// takes it from d_state instead of uploading the host challenger's, and calls after_wait right behind its first wait - the
+// host catches up there (replays what the device did, checks it) before FRI's own steps are replayed.
+struct FriDeviceStart {
+  DBuf<uint32_t> d_state;
+  std::function<void()> after_wait;
+};
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
                size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr,
-               FriHead* head = nullptr, DTree* round0 = nullptr);
+               FriHead* head = nullptr, DTree* round0 = nullptr, FriDeviceStart* dstart = nullptr);
 
 // TwoAdicFriPcs::open + prove_fri; serialises the FriProof straight into `fri_bytes`.
 void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std::vector<OpenedRound>& opened, PW& fri_bytes,
@@ -1264,20 +1272,32 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   }
   std::vector<E2> h_sums(std::max<size_t>(total_vals, 1));
   g_probes.mark("opened values queued");
-  ctx.d2h(h_sums.data(), d_sums.p, total_vals * sizeof(E2));
-  g_probes.mark("sync 4 (opened values)");
-  if (sym) {  // the host learns the points now (and replays the transcript that produced them)
-    std::vector<E2> values(sym->n);
-    sym->resolve(values);
-    auto swap_in = [&](E2& z) {
-      if (is_sym_point(z)) z = values[z.c0];
-    };
-    for (auto& z : upts) swap_in(z);
-    for (auto& r : rounds)
-      for (auto& pts : r.points)
-        for (auto& z : pts) swap_in(z);
-  }
-  {
+  // The opened values' transcript step on the DEVICE (open_alpha_k): with the outer transcript already there (`sym`) and FRI's
+  // rounds device-driven, the finishing factors, the absorption of every opened value, the batching challenge alpha, its powers
+  // and the reduced openings' coefficients and constants are one single-workgroup launch, and the proof's only wait is FRI's:
+  // the raw sums arrive with it, and the host then replays the outer transcript, finishes the sums itself, absorbs the values
+  // and compares its alpha with the device's. OPT-IN (MSAMD_DEV_OPENING=1): measured EQUAL to the host doing the step between
+  // two waits (5.58-5.61 against 5.51-5.57 ms per HBM-resident proof, A / B on one box): the 64 + 13 us the GPU idles at the
+  // opened-values wait are traded for a 25-30 us single-workgroup launch on the critical path and for the host's share of the
+  // step (finishing the sums, absorbing the values: ~30 us) moving behind the proof's last kernel.
+  const size_t fri_stop = (size_t(1) << lb) << prm.log_final_poly_len;
+  size_t n_entry_pairs = 0;
+  for (auto& r : rounds)
+    for (auto& pts : r.points) n_entry_pairs += pts.size();
+  const bool dev_open = sym && sym->d_state && gmax > fri_stop && prm.cap_height == 0 && prm.commit_pow_bits <= 16 && prm.max_log_arity == 1 &&
+                        32 + 16 * total_vals <= (size_t(256) << 10) && gw < (size_t(1) << 20) && n_entry_pairs <= 512 && !getenv("MSAMD_HOST_FRI") && getenv("MSAMD_DEV_OPENING");
+  auto finish_and_observe = [&]() {  // host: the opened values from the raw sums (points known), absorbed in round -> matrix -> point order
+    if (sym) {  // the host learns the points now (and replays the transcript that produced them)
+      std::vector<E2> values(sym->n);
+      sym->resolve(values);
+      auto swap_in = [&](E2& z) {
+        if (is_sym_point(z)) z = values[z.c0];
+      };
+      for (auto& z : upts) swap_in(z);
+      for (auto& r : rounds)
+        for (auto& pts : r.points)
+          for (auto& z : pts) swap_in(z);
+    }
     size_t off = 0;
     for (auto& r : rounds) {
       OpenedRound orr;
@@ -1299,61 +1319,101 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
       }
       opened.push_back(std::move(orr));
     }
-  }
-  tr.mark("bary_eval");
-  g_probes.mark("opened values observed");
-  const E2 alpha = ch.sample_ext();
+  };
+  E2 alpha = e2(0);
   std::vector<E2> apow(gw + 1);
-  apow[0] = e2(1);
-  for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
-  // reduced openings per LDE height; the opening points of one height are numbered locally (at most two)
+  if (dev_open) {
+    ctx.d2h_queue(h_sums.data(), d_sums.p, total_vals * sizeof(E2));
+  } else {
+    ctx.d2h(h_sums.data(), d_sums.p, total_vals * sizeof(E2));
+    g_probes.mark("sync 4 (opened values)");
+    finish_and_observe();
+    tr.mark("bary_eval");
+    g_probes.mark("opened values observed");
+    alpha = ch.sample_ext();
+    apow[0] = e2(1);
+    for (size_t i = 1; i <= gw; i++) apow[i] = e2_mul(apow[i - 1], alpha);
+  }
+  // reduced openings per LDE height; the opening points of one height are numbered locally (at most two). Everything but the
+  // coefficients and the constants K follows from the opening's SHAPE; those two come from alpha and the opened values - on the
+  // host here, or from open_alpha_k, which gets one OpenEntry per (matrix, point) saying where its inputs and outputs lie
   std::vector<size_t> num_reduced(33, 0);
   std::vector<std::vector<DeepMat>> lists(33);
   std::vector<DeepPoints> hpts(33);
   std::vector<std::vector<size_t>> hpt_global(33);
   std::vector<char> present(33, 0);
+  std::vector<OpenEntry> entries;                        // dev_open: observe order
+  std::vector<std::pair<unsigned, size_t>> entry_mat;    // (height, index in lists[height]) of each entry's matrix
   constexpr size_t NEXT_MARK = size_t(1) << 62;
   for (auto& hp : hpts) memset(&hp, 0, sizeof(hp));
-  for (size_t ri = 0; ri < rounds.size(); ri++) {
-    auto& r = rounds[ri];
-    for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
-      const DMat& m = r.data->ldes[mi];
-      unsigned lh = log2_strict(m.h);
-      present[lh] = 1;
-      auto& pts = r.points[mi];
-      if (pts.empty()) continue;
-      DeepMat dm;
-      memset(&dm, 0, sizeof(dm));
-      dm.d = m.d();
-      dm.w = (uint32_t)m.w;
-      dm.npoints = (uint32_t)pts.size();
-      for (size_t pi = 0; pi < pts.size(); pi++) {
-        // a "next" point is named by the first point's arrays plus a mark (all matrices of one height share g, so the pair
-        // (arrays, mark) identifies the point at this height)
-        const bool nx = pi == 1 && is_next[ri][mi];
-        const size_t gk = point_index(pts[nx ? 0 : pi]) | (nx ? NEXT_MARK : size_t(0));
-        size_t local = 0;
-        while (local < hpt_global[lh].size() && hpt_global[lh][local] != gk) local++;
-        if (local == hpt_global[lh].size()) {
-          if (local == 2) throw std::runtime_error("pcs_open: more than two opening points at one LDE height");
-          hpt_global[lh].push_back(gk);
-          hpts[lh].den[local] = dens[gk & ~NEXT_MARK].p;
-          hpts[lh].shift[local] = nx ? (uint32_t(1) << lb) : 0u;  // g = w_H^blowup
-          hpts[lh].K[local] = e2(0);
-          hpts[lh].n = (uint32_t)(local + 1);
+  {
+    size_t sum_off = 0, out_off = 0;
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+      auto& r = rounds[ri];
+      for (size_t mi = 0; mi < r.data->ldes.size(); mi++) {
+        const DMat& m = r.data->ldes[mi];
+        unsigned lh = log2_strict(m.h);
+        present[lh] = 1;
+        auto& pts = r.points[mi];
+        if (pts.empty()) continue;
+        DeepMat dm;
+        memset(&dm, 0, sizeof(dm));
+        dm.d = m.d();
+        dm.w = (uint32_t)m.w;
+        dm.npoints = (uint32_t)pts.size();
+        for (size_t pi = 0; pi < pts.size(); pi++) {
+          // a "next" point is named by the first point's arrays plus a mark (all matrices of one height share g, so the pair
+          // (arrays, mark) identifies the point at this height)
+          const bool nx = pi == 1 && is_next[ri][mi];
+          const size_t gk = point_index(pts[nx ? 0 : pi]) | (nx ? NEXT_MARK : size_t(0));
+          size_t local = 0;
+          while (local < hpt_global[lh].size() && hpt_global[lh][local] != gk) local++;
+          if (local == hpt_global[lh].size()) {
+            if (local == 2) throw std::runtime_error("pcs_open: more than two opening points at one LDE height");
+            hpt_global[lh].push_back(gk);
+            hpts[lh].den[local] = dens[gk & ~NEXT_MARK].p;
+            hpts[lh].shift[local] = nx ? (uint32_t(1) << lb) : 0u;  // g = w_H^blowup
+            hpts[lh].K[local] = e2(0);
+            hpts[lh].n = (uint32_t)(local + 1);
+          }
+          const u64 cmul = nx ? gl_inv(gl_two_adic_generator(lh - lb)) : 1;  // 1 / (z g - x_j) = g^-1 / (z - x_sigma(j))
+          dm.pt[pi] = (uint32_t)local;
+          if (dev_open) {
+            const unsigned log_h = lh - lb;
+            const u64 s_pow = gl_exp_pow2(GL_GEN, log_h);
+            OpenEntry en;
+            memset(&en, 0, sizeof(en));
+            en.sum_off = (uint32_t)sum_off;
+            en.out_off = (uint32_t)out_off;
+            en.w = (uint32_t)m.w;
+            en.np = (uint32_t)pts.size();
+            en.p = (uint32_t)pi;
+            en.log_h = log_h;
+            if (!is_sym_point(pts[pi])) throw std::runtime_error("pcs_open: device opening needs device points");
+            en.point_id = (uint32_t)pts[pi].c0;
+            en.exp = (uint32_t)num_reduced[lh];
+            en.slot = (uint32_t)(2 * lh + local);
+            en.s_pow = s_pow;
+            en.dinv = gl_inv(gl_mul(s_pow, (u64(1) << log_h) % GL_P));
+            en.cmul = cmul;
+            entries.push_back(en);
+            entry_mat.emplace_back(lh, lists[lh].size());
+          } else {
+            E2 coeff = e2_pow(alpha, num_reduced[lh]);
+            E2 rz = e2(0);
+            const std::vector<E2>& ys = opened[ri][mi][pi];
+            for (size_t c = 0; c < m.w; c++) rz = e2_add(rz, e2_mul(apow[c], ys[c]));
+            coeff = e2_mul_base(coeff, cmul);
+            dm.coeff[pi] = coeff;
+            dm.coeff7[pi] = gl_mul(coeff.c1, GL_EXT_W);
+            hpts[lh].K[local] = e2_add(hpts[lh].K[local], e2_mul(coeff, rz));
+          }
+          num_reduced[lh] += m.w;
+          out_off += m.w;
         }
-        E2 coeff = e2_pow(alpha, num_reduced[lh]);
-        E2 rz = e2(0);
-        const std::vector<E2>& ys = opened[ri][mi][pi];
-        for (size_t c = 0; c < m.w; c++) rz = e2_add(rz, e2_mul(apow[c], ys[c]));
-        if (nx) coeff = e2_mul_base(coeff, gl_inv(gl_two_adic_generator(lh - lb)));  // 1 / (z g - x_j) = g^-1 / (z - x_sigma(j))
-        dm.pt[pi] = (uint32_t)local;
-        dm.coeff[pi] = coeff;
-        dm.coeff7[pi] = gl_mul(coeff.c1, GL_EXT_W);
-        hpts[lh].K[local] = e2_add(hpts[lh].K[local], e2_mul(coeff, rz));
-        num_reduced[lh] += m.w;
+        sum_off += pts.size() * m.w;
+        lists[lh].push_back(dm);
       }
-      lists[lh].push_back(dm);
     }
   }
   g_probes.mark("reduced-opening coefficients");
@@ -1362,7 +1422,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   size_t n_mats = 0;
   for (auto& l : lists) n_mats += l.size();
   std::vector<uint8_t> deep_blob((gw + 1) * sizeof(E2) + n_mats * sizeof(DeepMat));
-  memcpy(deep_blob.data(), apow.data(), (gw + 1) * sizeof(E2));
+  if (!dev_open) memcpy(deep_blob.data(), apow.data(), (gw + 1) * sizeof(E2));
   std::vector<size_t> list_off(33, 0);
   {
     size_t off = (gw + 1) * sizeof(E2);
@@ -1376,9 +1436,44 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
   DBuf<uint8_t> d_deep(ctx, deep_blob.size());
   ctx.h2d(d_deep.p, deep_blob.data(), deep_blob.size());
   const E2* d_apow = reinterpret_cast<const E2*>(d_deep.p);
+  DBuf<E2> d_K, d_opened, d_alpha;
+  DBuf<uint32_t> d_fri_state;
+  DBuf<OpenEntry> d_entries;
+  DBuf<Digest> d_cvs;
+  E2 h_alpha_dev = e2(0);
+  if (dev_open) {
+    for (size_t e = 0; e < entries.size(); e++)
+      entries[e].mat = (uint32_t)((list_off[entry_mat[e].first] - (gw + 1) * sizeof(E2)) / sizeof(DeepMat) + entry_mat[e].second);
+    d_entries = DBuf<OpenEntry>(ctx, std::max<size_t>(entries.size(), 1));
+    ctx.h2d(d_entries.p, entries.data(), entries.size() * sizeof(OpenEntry));
+    d_K = DBuf<E2>(ctx, 66);
+    d_opened = DBuf<E2>(ctx, std::max<size_t>(total_vals, 1));
+    d_alpha = DBuf<E2>(ctx, 1);
+    d_fri_state = DBuf<uint32_t>(ctx, 8);
+    d_cvs = DBuf<Digest>(ctx, (32 + 16 * total_vals + 1023) / 1024);
+    OpenAlphaArgs oa;
+    memset(&oa, 0, sizeof(oa));
+    oa.entries = d_entries.p;
+    oa.n_entries = (uint32_t)entries.size();
+    oa.n_vals = (uint32_t)total_vals;
+    oa.gw = (uint32_t)gw;
+    oa.n_slots = 66;
+    oa.sums = d_sums.p;
+    oa.points = sym->d_points;
+    oa.state_in = sym->d_state;
+    oa.opened = d_opened.p;
+    oa.apow = reinterpret_cast<E2*>(d_deep.p);
+    oa.mats = reinterpret_cast<DeepMat*>(d_deep.p + (gw + 1) * sizeof(E2));
+    oa.K = d_K.p;
+    oa.state_out = d_fri_state.p;
+    oa.alpha_out = d_alpha.p;
+    oa.cv_scratch = d_cvs.p;
+    open_alpha(ctx, oa);
+    ctx.d2h_queue(&h_alpha_dev, d_alpha.p, sizeof(E2));
+  }
   std::vector<DBuf<E2>> inputs;  // descending height
   DTree fri_round0;              // the tallest vector is FRI's first committed matrix: its leaf layer is hashed where it is produced
-  if (use_side) ctx.side_fork();  // behind the upload of the alpha powers
+  if (use_side) ctx.side_fork();  // behind the upload of the alpha powers (and the launch that fills them)
   for (int lh = 32; lh >= 0; lh--) {
     if (!present[lh]) continue;
     size_t h = size_t(1) << lh;
@@ -1392,7 +1487,8 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
         merkle_alloc(ctx, fri_round0, h / 2);
         leaves = fri_round0.base();
       }
-      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow, ro.p, apow.data(), leaves, reinterpret_cast<const DeepMat*>(d_deep.p + list_off[lh]));
+      deep_reduce(ctx, lists[lh], hpts[lh], h, d_apow, ro.p, apow.data(), leaves, reinterpret_cast<const DeepMat*>(d_deep.p + list_off[lh]), 0, 0,
+                  dev_open ? d_K.p + 2 * lh : nullptr);
     }
     inputs.push_back(std::move(ro));
   }
@@ -1419,7 +1515,17 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
     shape.widths.push_back(std::move(widths));
     shape.nsib.push_back(t.cap_layer());
   }
-  fri_prove(sys, ch, inputs, log_gmax, segs, out_off, shape, nullptr, fri_bytes, tr, nullptr, &fri_round0);
+  FriDeviceStart dstart;
+  if (dev_open) {
+    dstart.d_state = std::move(d_fri_state);
+    dstart.after_wait = [&]() {  // FRI's wait has delivered the raw sums, the commitments and the device's challenges
+      finish_and_observe();
+      alpha = ch.sample_ext();
+      if (!e2_same(alpha, h_alpha_dev)) throw std::runtime_error("the device transcript's batching challenge differs from the host challenger's");
+      g_probes.mark("opened values observed");
+    };
+  }
+  fri_prove(sys, ch, inputs, log_gmax, segs, out_off, shape, nullptr, fri_bytes, tr, nullptr, &fri_round0, dev_open ? &dstart : nullptr);
 }
 
 // prove_fri (commit phase, final polynomial, query proof of work, query openings) over the reduced openings
@@ -1429,7 +1535,7 @@ void pcs_open(HSystem& sys, std::vector<OpenRound>& rounds, Challenger& ch, std:
 // `remote`, called with the sampled indices and filling the same layout.
 void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsigned log_gmax, const std::vector<GatherSeg>& input_segs,
                size_t input_qbytes, const InputShape& shape, const InputGather* remote, PW& fri_bytes, PhaseTrace& tr, FriHead* head,
-               DTree* round0) {
+               DTree* round0, FriDeviceStart* dstart) {
   Ctx& ctx = *sys.ctx;
   const unsigned head_rounds = head ? head->n_rounds : 0;
   if (head && !remote) throw std::runtime_error("FRI: head rounds need the remote gather");
@@ -1461,8 +1567,9 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   // whole commit phase is submitted without a host synchronisation. The host then replays the transcript from
   // the returned roots / witnesses on its own challenger; the device values are checked, not trusted.
   // (rounds of arity above 2, max_log_arity > 1, are host-driven: no call site of the reference folds wider, src/types.rs:189-190)
-  const bool dev_rounds = folded.n > stop && prm.cap_height == 0 && ch.input.size() == 32 && prm.commit_pow_bits <= 16 &&
+  const bool dev_rounds = folded.n > stop && prm.cap_height == 0 && (dstart || ch.input.size() == 32) && prm.commit_pow_bits <= 16 &&
                           prm.max_log_arity == 1 && !getenv("MSAMD_HOST_FRI");
+  if (dstart && !dev_rounds) throw std::runtime_error("FRI: a transcript that starts on the device needs device-driven rounds");
   // With a one-coefficient final polynomial the query phase's challenger work (observe the final polynomial, grind,
   // sample every index) also runs on the device and the openings are gathered from the device-side indices, so
   // the whole of FRI costs one host synchronisation; the host replay below checks witness and indices.
@@ -1476,7 +1583,9 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   if (dev_rounds) {
     const bool use_tail = !getenv("MSAMD_NO_FRI_TAIL");
     for (size_t l = folded.n; l > stop; l >>= 1) n_total++;
-    if (head && head->on_device) {
+    if (dstart) {
+      d_state = std::move(dstart->d_state);  // the opened values were absorbed on the device: FRI goes on from that state
+    } else if (head && head->on_device) {
       d_state = std::move(head->d_state);  // the head rounds' challenger steps have run on the device: go on from their state
     } else {
       d_state = DBuf<uint32_t>(ctx, 8);
@@ -1690,6 +1799,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     ctx.d2h(fin.data(), fin_src, stop * sizeof(E2));  // the one synchronisation of the FRI phase
     g_probes.mark("sync 5 (FRI)");
     fin_hold.reset();
+    if (dstart && dstart->after_wait) dstart->after_wait();  // the host catches up with what the device did in front of FRI
     for (size_t k = 0; k < hrecs.size(); k++) {  // the rounds that ran on row shards, replayed first: they come first in the transcript
       Digest root;
       memcpy(root.b, hrecs[k].root, 32);
@@ -2061,7 +2171,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     ctx.side_join();
     od.digest = DBuf<Digest>(ctx, 1);
     if (dev_outer) {
-      od.state = DBuf<u32>(ctx, 20);
+      od.state = DBuf<u32>(ctx, 28);  // 12 words behind gamma, 8 behind alpha, 8 behind zeta
       d_bg = DBuf<ChallengeBG>(ctx, 1);
     }
     if (late_chunk0) {
@@ -2280,11 +2390,12 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     ctx.h2d(od.lds.p, od.uniq_ld.data(), n_ld * sizeof(u32));
     od.points = DBuf<E2>(ctx, 1 + n_ld);
     od.h_points.assign(1 + n_ld, e2(0));
-    outer_zeta(ctx, od.state.p + 12, d_cap, ncap, od.lds.p, n_ld, od.points.p);
+    outer_zeta(ctx, od.state.p + 12, d_cap, ncap, od.lds.p, n_ld, od.points.p, od.state.p + 20);
     ctx.d2h_queue(od.h_points.data(), od.points.p, (1 + n_ld) * sizeof(E2));
     pt_zeta = sym_point(0);
     for (size_t pos = 0; pos < NA; pos++) pt_next[pos] = sym_point(id_of[pos]);
     sym.d_points = od.points.p;
+    sym.d_state = od.state.p + 20;
     sym.n = 1 + n_ld;
     sym.next_log.assign(1 + n_ld, -1);
     for (size_t k = 0; k < n_ld; k++) sym.next_log[1 + k] = (int)od.uniq_ld[k];

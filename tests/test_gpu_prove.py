@@ -407,6 +407,39 @@ def test_device_generated_bench_witness(pkg, ctx, oracle, fe, num_adds, a0, b0):
 # every alternative code path selectable by environment variable must give the same proof bytes: host-driven FRI rounds,
 # host-side query step, no single-workgroup FRI tail, host sweep for the lookup values, interpreter kernels instead of
 # the hiprtc-compiled ones (the library reads these variables at call time)
+def test_device_side_opening_step(pkg, ctx, oracle, fe, monkeypatch, capfd):
+    """MSAMD_DEV_OPENING=1: the opened values' transcript step (finishing factors, absorption, the FRI batching challenge, the
+    reduced openings' coefficients and constants) as one launch, FRI continuing from the device state: ONE host wait per proof,
+    the same bytes. Systems: the bench workload (two points per matrix, a short circuit on the side stream), the nine-circuit
+    system, a preprocessed table with lookups and claims, host-resident witnesses."""
+    import numpy as np
+
+    cases = []
+    tr, cl = fe.u32_add_bench_witness(1 << 14)
+    cases.append((fe.u32_add_system_inputs(), fe.bench_params(), tr, cl))
+    tr, cl = fe.multi_u32_add_witness(8, 1 << 11)
+    cases.append((fe.multi_u32_add_system_inputs(8), fe.bench_params(), tr, cl))
+    rng = np.random.default_rng(5)
+    calls = [(int(rng.integers(0, 4)), int(rng.integers(0, 256)), int(rng.integers(0, 256))) for _ in range(3000)]
+    tr, cl = fe.byte_operations_witness(calls)
+    cases.append((fe.byte_operations_inputs(), fe.test_params(), tr, cl))
+    for inputs, params, tr, cl in cases:
+        packed = fe.pack_claims(cl)
+        g = pkg.System.new(ctx, params, inputs)
+        want = oracle.System(g.blob).prove(tr, packed)
+        w, hw = g.witness(tr, packed), g.host_witness(tr, packed)
+        assert g.prove_multiple_claims(w).to_bytes() == want
+        monkeypatch.setenv("MSAMD_DEV_OPENING", "1")
+        n0 = ctx.sync_count()
+        assert g.prove_multiple_claims(w).to_bytes() == want
+        assert ctx.sync_count() - n0 == 1, "the device-side opening step leaves ONE host wait per proof"
+        assert g.prove_multiple_claims(hw).to_bytes() == want and g.prove_multiple_claims(w).to_bytes() == want
+        monkeypatch.delenv("MSAMD_DEV_OPENING")
+        n0 = ctx.sync_count()
+        assert g.prove_multiple_claims(w).to_bytes() == want
+        assert ctx.sync_count() - n0 == 2
+
+
 @pytest.mark.parametrize("var", ["MSAMD_HOST_FRI", "MSAMD_HOST_QUERY", "MSAMD_NO_FRI_TAIL", "MSAMD_HOST_LOOKUP_VALUES", "MSAMD_NO_JIT", "MSAMD_NO_SUBTREE",
                                  "MSAMD_MATERIALISE_LOOKUPS", "MSAMD_NO_FRI_FUSED", "MSAMD_NO_FLAG_SYNC", "MSAMD_NO_SIDE_STREAM", "MSAMD_OLD_TRANSPOSE", "MSAMD_GENERIC_LEAF_HASH", "MSAMD_NO_DEEP_LEAVES",
                                  "MSAMD_HOST_TRANSCRIPT", "MSAMD_NO_NEXT_SHIFT", "MSAMD_OLD_CLAIMS_TREE", "MSAMD_CLAIMS_ACC_MAIN", "MSAMD_NO_BARY_BATCH", "MSAMD_NO_NTT_SMALL",
