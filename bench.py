@@ -91,9 +91,10 @@ class Watchdog:
     the others blocked forever, and a hang must not be recorded as a success. Whatever rank 0 has measured so far is
     printed first, with the error recorded."""
 
-    def __init__(self, rank, what, seconds, partial, ctx=None):
+    def __init__(self, rank, what, seconds, partial, ctx=None, soft=False):
         self.done = threading.Event()
         self.rank, self.what, self.seconds, self.partial, self.ctx = rank, what, seconds, partial, ctx
+        self.soft = soft  # a SECONDARY leg: what was measured before it is complete - print it and end with status 0
         self.leg = "setup"
         threading.Thread(target=self._run, daemon=True).start()
 
@@ -113,13 +114,17 @@ class Watchdog:
         if self.done.wait(self.seconds):
             return
         where = self.where()
-        log("[rank %d] %s did not finish within %.0f s (%s): exiting with status 3" % (self.rank, self.what, self.seconds, where))
+        log("[rank %d] %s did not finish within %.0f s (%s): exiting with status %d" % (self.rank, self.what, self.seconds, where, 0 if self.soft else 3))
         if self.rank == 0:
             line = self.partial()
             if line is not None:
-                line["error"] = "%s timed out after %.0f s (collective hang or a failed rank); rank 0 was in %s" % (self.what, self.seconds, where)
+                why = "%s timed out after %.0f s (collective hang or a failed rank); rank 0 was in %s" % (self.what, self.seconds, where)
+                if self.soft:
+                    line["secondary_leg_error"] = why  # the primary figures above it stand
+                else:
+                    line["error"] = why
                 print(json.dumps(line), flush=True)
-        os._exit(3)
+        os._exit(0 if self.soft else 3)
 
     def finish(self):
         self.done.set()
@@ -744,12 +749,11 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
 
     wd = Watchdog(rank, "the multi-GPU bench", args.primary_timeout, partial, ctx)
     joint_primary = not args.replicas_primary
-    if not args.no_replicas_leg or not joint_primary:
-        wd.leg = "replicas (one independent proof per rank)"
-        done["replicas"] = replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces, claims)
-    if joint_primary or not args.no_joint_leg:
+
+    def run_joint():
         try:
             done["joint"] = joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims, wd)
+            return None
         except PreflightFailed as e:
             # nothing of the joint leg is timed on a prover whose bytes are wrong: report what there is, with the reason
             wd.finish()
@@ -769,6 +773,19 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
             if rank == 0:
                 print(json.dumps(line), flush=True)
             os._exit(4)
+
+    def run_replicas():
+        wd.leg = "replicas (one independent proof per rank)"
+        done["replicas"] = replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces, claims)
+
+    # The PRIMARY leg runs first: a secondary leg that hangs or fails on first contact with several GPUs must not take the
+    # figure the run is for with it.
+    if joint_primary:
+        failed = run_joint()
+        if failed is not None:
+            return failed
+    else:
+        run_replicas()
     wd.finish()
     prim = done["joint"] if joint_primary else done["replicas"]
     info, dominant, dom, rows = prim
@@ -798,6 +815,27 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
     result["roofline"] = roofline_of(dominant, dom, full_size=False)
     if joint_primary:
         result["config"]["preflight"] = info.get("preflight")
+    # ---- the secondary leg, behind a watchdog of its own that prints the primary line (status 0) if the leg cannot finish
+    want_secondary = (joint_primary and not args.no_replicas_leg) or (not joint_primary and not args.no_joint_leg)
+    if want_secondary and not result.get("error"):
+        wd2 = Watchdog(rank, "the secondary leg of the multi-GPU bench", min(args.primary_timeout, 240.0), lambda: result, ctx, soft=True)
+        try:
+            if joint_primary:
+                wd2.leg = "replicas (one independent proof per rank)"
+                done["replicas"] = replicas_leg(args, pkg, fe, ctx, torch, dist, mgpu, rank, local_rank, traces, claims)
+                result["replicas"] = done["replicas"][0]
+            else:
+                wd2.leg = "joint proof (secondary)"
+                done["joint"] = joint_leg(args, pkg, fe, ctx, torch, dist, rank, local_rank, traces, claims, wd2)
+                result["joint_proof"] = done["joint"][0]
+        except BaseException as e:  # noqa: BLE001  (the primary figures stand; the failure is part of the record)
+            log("[rank %d] secondary leg failed: %r" % (rank, e))
+            result["secondary_leg_error"] = "secondary leg failed: %r" % (e,)
+            wd2.finish()
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)  # (no closing barrier: a rank that failed inside a collective would never join it)
+        wd2.finish()
     if not args.no_cpu_baseline and rank == 0:
         # the same CPU leg as at N = 1 (one [ByteTable, U32Add] proof at 2^cpu-log-adds additions on this box's host cores): rows/s of
         # the restatement does not depend on how many adders the system holds. The other ranks wait at the closing barrier.
@@ -805,10 +843,6 @@ def multi_gpu(args, pkg, fe, ctx, torch, dist, rank, local_rank, n_gpus):
         result["cpu_baseline"] = cpu_baseline(fe, one.blob, args.cpu_log_adds)
         result["cpu_baseline"]["sample"] += "; measured on rank 0's host cores while the other ranks idle"
         del one
-    if joint_primary and "replicas" in done:
-        result["replicas"] = done["replicas"][0]
-    if not joint_primary and "joint" in done:
-        result["joint_proof"] = done["joint"][0]
     return result
 
 
@@ -916,18 +950,6 @@ def local_multi_gpu(args):
     def rank_body(rank, group):
         ctx = ctxs[rank] = pkg.Context(devices[rank])
         res = {}
-        # ---- secondary leg first (as under the launcher): one independent [ByteTable, U32Add] proof per rank per step
-        if not args.no_replicas_leg:
-            if rank == 0:
-                wd.leg = "replicas (one independent proof per rank)"
-            one = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
-            (bt, add), cl = fe.u32_add_bench_witness(num_adds, *mgpu_seeds(rank))
-            opacked = fe.pack_claims(cl)
-            ow = one.host_witness([bt, add], opacked)
-            proof, elapsed, _, _, _ = timed(ctx, lambda: one.prove_multiple_claims(ow), rank)
-            res["replicas"] = (elapsed, len(proof.to_bytes()), ow.rows, hashlib.sha256(proof.to_bytes()).hexdigest())
-            del ow, one
-            ctx.trim()
         # ---- the joint proof
         system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(N))
         comm = group.comm(ctx, rank)
@@ -962,6 +984,18 @@ def local_multi_gpu(args):
             del witness
         finally:
             comm.close()
+        # ---- secondary leg, behind the primary one: one independent [ByteTable, U32Add] proof per rank per step
+        if not args.no_replicas_leg and "joint" in res:
+            if rank == 0:
+                wd.leg = "replicas (one independent proof per rank)"
+            one = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+            (bt, add), cl = fe.u32_add_bench_witness(num_adds, *mgpu_seeds(rank))
+            opacked = fe.pack_claims(cl)
+            ow = one.host_witness([bt, add], opacked)
+            proof, elapsed, _, _, _ = timed(ctx, lambda: one.prove_multiple_claims(ow), rank)
+            res["replicas"] = (elapsed, len(proof.to_bytes()), ow.rows, hashlib.sha256(proof.to_bytes()).hexdigest())
+            del ow, one
+            ctx.trim()
         return res
 
     group = sharded.LocalGroup(N)
@@ -985,7 +1019,7 @@ def local_multi_gpu(args):
                  "what": "joint proof of [ByteTable, U32Add x %d] at 2^%d additions per rank == System::prove_multiple_claims of the full system on "
                          "device %d, byte for byte, from host- and device-resident witnesses; same bytes on every rank; verifier accepts" % (N, k, devices[0])}
     replicas = None
-    if not args.no_replicas_leg:
+    if not args.no_replicas_leg and all("replicas" in r for r in results):
         el = max(r["replicas"][0] for r in results)
         replicas = {"what": "one independent [ByteTable, U32Add @ 2^%d] proof per rank per step (thread ranks, host-resident witnesses)" % args.log_adds,
                     "value": results[0]["replicas"][2] * N * args.steps / el, "unit": "rows/s", "ms_per_step": 1e3 * el / args.steps,
