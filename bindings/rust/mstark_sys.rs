@@ -87,6 +87,11 @@ extern "C" {
     pub fn ms_witness_create_host(sys: *mut ms_system, traces: *const *const u64, heights: *const u64, n_claims: usize,
                                   claim_offsets: *const u64, claim_data: *const u64, pinned: *mut i32,
                                   out: *mut *mut ms_witness) -> i32;
+    pub fn ms_claims_slice_range(sys: *mut ms_system, heights: *const u64, n_claims: usize, claim_offsets: *const u64, rank: i32, world: i32,
+                                 first_elem: *mut u64, n_elems: *mut u64) -> i32;
+    pub fn ms_witness_create_host_sliced(sys: *mut ms_system, traces: *const *const u64, heights: *const u64, n_claims: usize,
+                                         claim_offsets: *const u64, data_first: u64, data_count: u64, data_slice: *const u64,
+                                         head: *const u64, n_head: usize, pinned: *mut i32, out: *mut *mut ms_witness) -> i32;
     pub fn ms_witness_prefetch(w: *mut ms_witness, on: i32) -> i32;
     pub fn ms_witness_u32_add_bench(sys: *mut ms_system, num_adds: usize, a0: u32, b0: u32, out: *mut *mut ms_witness) -> i32;
     pub fn ms_witness_destroy(w: *mut ms_witness);

@@ -228,6 +228,19 @@ typedef struct ms_comm {
 #define MS_COMM_SKIP_SELF 1u
 int32_t ms_prove_sharded(ms_system* sys, ms_witness* w, const ms_comm* comm, const int32_t* owners, uint8_t* proof_out, size_t cap,
                          size_t* proof_len, double* stage_ms);
+/* A rank of a joint proof need not hold ALL claims on the host (8.4 M claims on each of eight ranks at BASELINE config 3): it
+ * reads the element range ms_claims_slice_range reports - the claims whose transcript words fall into its range of BLAKE3
+ * chunks, cut from the system's shape, the circuits' heights and the n_claims + 1 element offsets (which every rank keeps
+ * in full: 8 bytes per claim) - plus the first 130 elements, which every rank needs for the transcript's first chunk.
+ * ms_witness_create_host_sliced is ms_witness_create_host with that part of claim_data only: data_slice holds the elements
+ * [data_first, data_first + data_count), head the first min(total, 130). A list of at most 8192 transcript words is absorbed
+ * whole by every rank (the range is then everything). Only ms_prove_sharded accepts such a witness. */
+int32_t ms_claims_slice_range(ms_system* sys, const uint64_t* heights, size_t n_claims, const uint64_t* claim_offsets, int32_t rank,
+                              int32_t world, uint64_t* first_elem, uint64_t* n_elems);
+int32_t ms_witness_create_host_sliced(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, size_t n_claims,
+                                      const uint64_t* claim_offsets, uint64_t data_first, uint64_t data_count,
+                                      const uint64_t* data_slice, const uint64_t* head, size_t n_head, int32_t* pinned,
+                                      ms_witness** out);
 
 /* Where a joint proof is: the library records every call it makes into the transport - the prover's phase, the collective,
  * its size, the rank ("stage-2 commit: all_to_all_cols_start (29360128 bytes, part 3) on rank 5 of 8"). `out` receives the

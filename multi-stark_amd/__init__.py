@@ -43,7 +43,7 @@ def exported_symbols():
     """Every entry point include/mstark.h declares (used by the CPU-side ABI test)."""
     return ["ms_last_error", "ms_device_count", "ms_ctx_create", "ms_ctx_destroy", "ms_ctx_sync", "ms_ctx_sync_count", "ms_ctx_trim", "ms_ctx_set_profile_mask",
             "ms_ctx_kernel_stats", "ms_ctx_kernel_units", "ms_ctx_reset_stats", "ms_ctx_debug_fail_alloc", "ms_kernel_count", "ms_kernel_name", "ms_system_create",
-            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_witness_prefetch",
+            "ms_system_destroy", "ms_system_preprocessed_commit", "ms_system_circuit_info", "ms_witness_create", "ms_witness_create_host", "ms_claims_slice_range", "ms_witness_create_host_sliced", "ms_witness_prefetch",
             "ms_witness_u32_add_bench", "ms_witness_destroy", "ms_prove", "ms_prove_sharded", "ms_ctx_comm_progress", "ms_comm_rccl_unique_id", "ms_comm_rccl_create",
             "ms_comm_rccl_table", "ms_comm_rccl_bytes_moved", "ms_comm_rccl_destroy", "ms_comm_local_group_create", "ms_comm_local_group_abort",
             "ms_comm_local_group_destroy", "ms_comm_local_create", "ms_comm_local_table", "ms_comm_local_bytes_moved", "ms_comm_local_destroy", "ms_verify", "ms_dft_batch", "ms_coset_lde_batch", "ms_quotient_lde", "ms_mmcs_commit",
@@ -515,6 +515,35 @@ class System:
         h = C.c_void_p()
         pinned = C.c_int32(0)
         _check(lib().ms_witness_create_host(self.h, tptr, _p(hs), C.c_size_t(len(offs) - 1), _p(offs), _p(data), C.byref(pinned), C.byref(h)))
+        w = SystemWitness(h, int(hs.sum()), self)
+        w.keep = trs
+        w.pinned = bool(pinned.value)
+        return w
+
+    def claims_slice_range(self, heights, claim_offsets, rank, world):
+        """(first element, count) of the claims' data that rank `rank` of `world` reads in a joint proof (ms_claims_slice_range)"""
+        hs, offs = _u64(heights), _u64(claim_offsets)
+        first, count = C.c_uint64(), C.c_uint64()
+        _check(lib().ms_claims_slice_range(self.h, _p(hs), C.c_size_t(len(offs) - 1), _p(offs), C.c_int32(rank), C.c_int32(world), C.byref(first), C.byref(count)))
+        return int(first.value), int(count.value)
+
+    def host_witness_sliced(self, traces, claim_offsets, data_first, data_slice, head, remote_heights=None):
+        """host_witness for a rank of a joint proof that holds only ITS part of the claims' data (ms_witness_create_host_sliced):
+        all offsets, the elements [data_first, data_first + len(data_slice)) and the first min(total, 130) elements"""
+        remote_heights = remote_heights or {}
+        trs = [_u64(t) if t is not None and len(t) else np.zeros((0, 1), dtype=np.uint64) for t in traces]
+        n = self.n_circuits
+        if len(trs) != n:
+            raise MstarkError("expected one trace per circuit")
+        tptr = (u64p * n)(*[None if i in remote_heights else _p(t) for i, t in enumerate(trs)])
+        hs = _u64([remote_heights.get(i, t.shape[0]) for i, t in enumerate(trs)])
+        offs, sl, hd = _u64(claim_offsets), _u64(data_slice), _u64(head)
+        sl_arg = sl if sl.size else np.zeros(1, dtype=np.uint64)
+        hd_arg = hd if hd.size else np.zeros(1, dtype=np.uint64)
+        h = C.c_void_p()
+        pinned = C.c_int32(0)
+        _check(lib().ms_witness_create_host_sliced(self.h, tptr, _p(hs), C.c_size_t(len(offs) - 1), _p(offs), C.c_uint64(data_first),
+                                                   C.c_uint64(sl.size), _p(sl_arg), _p(hd_arg), C.c_size_t(hd.size), C.byref(pinned), C.byref(h)))
         w = SystemWitness(h, int(hs.sum()), self)
         w.keep = trs
         w.pinned = bool(pinned.value)

@@ -242,6 +242,36 @@ int32_t ms_witness_create_host(ms_system* sys, const uint64_t* const* traces, co
   return MS_OK;
   MS_CATCH
 }
+int32_t ms_claims_slice_range(ms_system* sys, const uint64_t* heights, size_t n_claims, const uint64_t* claim_offsets, int32_t rank,
+                              int32_t world, uint64_t* first_elem, uint64_t* n_elems) {
+  MS_TRY if (!sys || !heights || !claim_offsets || !first_elem || !n_elems) throw std::runtime_error("ms_claims_slice_range: null argument");
+  if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("ms_claims_slice_range: rank out of range");
+  if (claim_offsets[0] != 0) throw std::runtime_error("claim offsets must start at 0");
+  std::vector<size_t> hs(heights, heights + sys->sys->circuits.size());
+  for (size_t h : hs)
+    if (h & (h - 1)) throw std::runtime_error("trace height must be a power of two");
+  size_t first = 0, count = 0;
+  claims_slice_range(*sys->sys, hs.data(), n_claims, claim_offsets, (size_t)rank, (size_t)world, first, count);
+  *first_elem = first;
+  *n_elems = count;
+  return MS_OK;
+  MS_CATCH
+}
+int32_t ms_witness_create_host_sliced(ms_system* sys, const uint64_t* const* traces, const uint64_t* heights, size_t n_claims,
+                                      const uint64_t* claim_offsets, uint64_t data_first, uint64_t data_count,
+                                      const uint64_t* data_slice, const uint64_t* head, size_t n_head, int32_t* pinned,
+                                      ms_witness** out) {
+  *out = nullptr;
+  MS_TRY std::unique_ptr<ms_witness> w(new ms_witness());
+  if (data_count == ~uint64_t(0)) throw std::runtime_error("ms_witness_create_host_sliced: data_count out of range");
+  w->w = witness_create_host(*sys->sys, traces, heights, n_claims, claim_offsets, data_slice, (size_t)data_first, (size_t)data_count, head, n_head);
+  if (pinned) *pinned = w->w->pinned ? 1 : 0;
+  w->owner = sys;
+  sys->refs++;
+  *out = w.release();
+  return MS_OK;
+  MS_CATCH
+}
 int32_t ms_witness_prefetch(ms_witness* w, int32_t on) {
   MS_TRY HWitness& wit = *w->w;
   if (!wit.host_resident) throw std::runtime_error("ms_witness_prefetch: only a host-resident witness is uploaded per proof");

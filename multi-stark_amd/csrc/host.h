@@ -100,6 +100,12 @@ struct HWitness {
   std::vector<DLookups> lookups;
   // claims: host copy (transcript for small inputs) and device copy
   std::vector<u64> claim_offsets, claim_data;
+  // A rank of a joint proof may hold only the part of the claims' data it reads (ms_witness_create_host_sliced): claim_data
+  // then holds elements [claim_elem0, claim_elem0 + claim_data.size()) of claim_elems_total, claim_head the first 130 (chunk 0
+  // of the claims transcript is hashed by every rank); the offsets are always complete.
+  size_t claim_elem0 = 0, claim_elems_total = 0;
+  std::vector<u64> claim_head;
+  bool claims_partial = false;
   DBuf<u64> d_claim_offsets, d_claim_data;
   // host-resident witness (ms_witness_create_host): between proofs nothing of it lives in HBM. prove() uploads the
   // traces and the claims on the context's copy stream and runs from_stage_1 on the device, every time.
@@ -142,8 +148,13 @@ struct HWitness {
   HWitness& operator=(const HWitness&) = delete;
   ~HWitness();
 };
+// data_first / data_count: claim_data holds the elements [data_first, data_first + data_count) only (a joint proof's rank:
+// claims_slice_range) and head the first min(total, 130) elements; data_count = ~0: claim_data is complete
 std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* traces, const u64* heights, size_t n_claims,
-                                              const u64* claim_offsets, const u64* claim_data);
+                                              const u64* claim_offsets, const u64* claim_data, size_t data_first = 0,
+                                              size_t data_count = ~size_t(0), const u64* head = nullptr, size_t n_head = 0);
+void claims_slice_range(const HSystem& sys, const size_t* heights, size_t n_claims, const u64* offsets, size_t rank, size_t world, size_t& first,
+                        size_t& count);
 std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces, const u64* heights, const u64* const* mult,
                                          const u64* const* args, size_t n_claims, const u64* claim_offsets,
                                          const u64* claim_data);

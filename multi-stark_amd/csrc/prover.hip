@@ -449,6 +449,7 @@ std::unique_ptr<HWitness> witness_from_device(HSystem& sys, std::vector<DBuf<u64
   w->claim_data.resize(claim_elems);
   ctx.d2h(w->claim_offsets.data(), d_claim_offsets.p, (n_claims + 1) * 8);
   if (claim_elems) ctx.d2h(w->claim_data.data(), d_claim_data.p, claim_elems * 8);
+  w->claim_elems_total = claim_elems;
   w->d_claim_offsets = std::move(d_claim_offsets);
   w->d_claim_data = std::move(d_claim_data);
   return w;
@@ -518,6 +519,7 @@ std::unique_ptr<HWitness> witness_create(HSystem& sys, const u64* const* traces,
   for (size_t i = 0; i < n_claims; i++)
     if (claim_offsets[i + 1] < claim_offsets[i]) throw std::runtime_error("claim offsets must be non-decreasing");
   w->claim_data.assign(claim_data, claim_data + tot);
+  w->claim_elems_total = tot;
   for (u64 x : w->claim_data)
     if (x >= GL_P) throw std::runtime_error("non-canonical claim value");
   w->d_claim_offsets = DBuf<u64>(ctx, n_claims + 1);
@@ -721,7 +723,8 @@ HWitness::~HWitness() {
 }
 
 std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* traces, const u64* heights, size_t n_claims,
-                                              const u64* claim_offsets, const u64* claim_data) {
+                                              const u64* claim_offsets, const u64* claim_data, size_t data_first, size_t data_count,
+                                              const u64* head, size_t n_head) {
   Ctx& ctx = *sys.ctx;
   HIP_CHECK(hipSetDevice(ctx.device));
   std::unique_ptr<HWitness> w(new HWitness());
@@ -794,12 +797,26 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
     if (claim_offsets[i + 1] < claim_offsets[i]) throw std::runtime_error("claim offsets must be non-decreasing");
   const size_t tot = n_claims ? (size_t)claim_offsets[n_claims] : 0;
   w->claim_offsets.assign(claim_offsets, claim_offsets + n_claims + 1);
-  w->claim_data.assign(claim_data, claim_data + tot);
+  w->claim_elems_total = tot;
+  if (data_count == ~size_t(0)) {
+    w->claim_data.assign(claim_data, claim_data + tot);
+  } else {  // this rank's part of the data only
+    if (data_first > tot || data_count > tot - data_first) throw std::runtime_error("claims slice outside the claims' data");
+    const size_t need_head = std::min<size_t>(tot, 130);
+    if (n_head < need_head || (need_head && !head)) throw std::runtime_error("claims slice: the first 130 elements are needed on every rank");
+    w->claims_partial = true;
+    w->has_remote = true;  // (only ms_prove_sharded accepts such a witness)
+    w->claim_elem0 = data_first;
+    w->claim_data.assign(claim_data, claim_data + data_count);
+    w->claim_head.assign(head, head + need_head);
+    for (u64 x : w->claim_head)
+      if (x >= GL_P) throw std::runtime_error("non-canonical claim value");
+  }
   for (u64 x : w->claim_data)
     if (x >= GL_P) throw std::runtime_error("non-canonical claim value");
   // the uploads read the witness's own copies (the small-claims transcript needs them on the host anyway)
   w->pin(w->claim_offsets.data(), (n_claims + 1) * 8);
-  w->pin(w->claim_data.data(), tot * 8);
+  w->pin(w->claim_data.data(), w->claim_data.size() * 8);
   ctx.sync();
   return w;
 }

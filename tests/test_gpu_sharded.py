@@ -449,6 +449,72 @@ def test_joint_prover_host_synchronisations(pkg, fe):
         assert max(counts) == plain, (world, counts, plain)  # exactly the one-GPU prover's two waits: opened values, FRI
 
 
+@pytest.mark.parametrize("world,log_adds", [(8, 12), (4, 13), (2, 13)])
+def test_claims_sliced_on_the_host(pkg, fe, world, log_adds):
+    """every rank holds only the part of the claims' data it reads (ms_claims_slice_range / ms_witness_create_host_sliced: all
+    offsets, its element range, the first 130 elements): the same bytes as with all claims on every rank; the parts together
+    are little more than one copy of the data; a rank given too small a part fails with a reason"""
+    import importlib
+
+    import numpy as np
+
+    sharded = importlib.import_module("multi_stark_amd.sharded")
+    traces, claims = fe.multi_u32_add_witness(world, 1 << log_adds)
+    offs, data = fe.pack_claims(claims)
+    owners = sharded.u32_add_owners(world)
+    ctx0 = pkg.Context(0)
+    sys0 = pkg.System.new(ctx0, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+    want = sys0.prove_multiple_claims(sys0.witness(traces, (offs, data))).to_bytes()
+    heights = [t.shape[0] for t in traces]
+    held = []
+
+    def body(rank, group):
+        ctx = pkg.Context(0)
+        system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+        first, count = system.claims_slice_range(heights, offs, rank, world)
+        held.append(count)
+        mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+        remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+        w = system.host_witness_sliced(mine, offs, first, data[first:first + count].copy(), data[:130].copy(), remote_heights=remote)
+        comm = group.comm(ctx, rank)
+        try:
+            got = [system.prove_sharded(w, comm, owners).to_bytes() for _ in range(2)]
+            with pytest.raises(pkg.MstarkError):
+                system.prove_multiple_claims(w)  # the one-GPU prover needs every claim
+            return got[0] == want and got[1] == want
+        finally:
+            comm.close()
+
+    group = sharded.LocalGroup(world)
+    try:
+        assert all(group.run(body))
+    finally:
+        group.close()
+    assert sum(held) <= data.size + 16 * world * 8, (held, data.size)  # the parts overlap by a claim or two at the seams
+    # a part that is too small is an error with a reason, on that rank (its peers are released by the transport's abort)
+    def short_body(rank, group):
+        ctx = pkg.Context(0)
+        system = pkg.System.new(ctx, fe.bench_params(), fe.multi_u32_add_system_inputs(world))
+        first, count = system.claims_slice_range(heights, offs, rank, world)
+        if rank == world - 1:
+            count -= 8
+        mine = [t if owners[i] in (-1, rank) else None for i, t in enumerate(traces)]
+        remote = {i: traces[i].shape[0] for i in range(len(traces)) if owners[i] not in (-1, rank)}
+        w = system.host_witness_sliced(mine, offs, first, data[first:first + count].copy(), data[:130].copy(), remote_heights=remote)
+        comm = group.comm(ctx, rank)
+        try:
+            system.prove_sharded(w, comm, owners)
+        finally:
+            comm.close()
+
+    group = sharded.LocalGroup(world)
+    try:
+        with pytest.raises(pkg.MstarkError, match="does not hold the part of the claims"):
+            group.run(short_body)
+    finally:
+        group.close()
+
+
 def test_thread_ranks_failure_does_not_hang(pkg, fe, monkeypatch):
     """a rank that fails in the middle of a joint proof (injected allocation failure) makes every rank return an error -
     nobody waits for it forever - and the same contexts prove again afterwards"""
