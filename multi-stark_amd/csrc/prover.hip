@@ -1850,6 +1850,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     ctx.d2h(fin.data(), folded.p, folded.n * sizeof(E2));
   }
   tr.mark("fri_commit_phase");
+  g_probes.mark("FRI rounds replayed");
   const bool host_trace = getenv("MSAMD_TRACE_HOST") != nullptr;
   const double t_sync = host_trace ? now_ms() : 0;
   // final polynomial: truncate, undo the bit reversal, inverse DFT (tiny: on the host)
@@ -1885,6 +1886,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
       if (indices[i] != dq[1 + i]) throw std::runtime_error("FRI: device query indices diverged from the host transcript");
     }
     tr.mark("final_poly+grind+gather");
+    g_probes.mark("query indices replayed");
   } else {
     query_pow = grind(ctx, ch, (unsigned)prm.query_pow_bits);
     for (auto& ix : indices) ix = ch.sample_bits(log_max_height);
@@ -1967,6 +1969,7 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   w.u64_(final_poly.size());
   for (auto& e : final_poly) w.ext(e);
   w.u64_(query_pow);
+  g_probes.mark("FriProof bytes written");
   if (host_trace) fprintf(stderr, "[msamd] host work after the FRI read-back: %.1f us (transcript replay + FriProof bytes)\n", 1e3 * (now_ms() - t_sync));
 }
 }  // namespace
