@@ -9,6 +9,7 @@ TAG=${1:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 find_csv() { find "$1" -name "*$2" | head -1; }
+echo "== warm the box (a fresh box pages the image in during its first minute: not part of any figure)"; python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config4 --no-in-flight > /dev/null 2>&1
 echo "== bench line"; python3 $REPO/bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench_line.log || exit 1
 echo "== kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config4 --no-in-flight > $OUT/${TAG}_stats_run.json 2> $OUT/stats.log || exit 1
 cp "$(find_csv $OUT/stats kernel_stats.csv)" $OUT/${TAG}_kernel_stats_bench.csv
