@@ -498,7 +498,7 @@ mod tests {
         use p3_symmetric::Permutation;
         use rand::distr::StandardUniform;
         use rand::rngs::SmallRng;
-        use rand::{Rng, SeedableRng};
+        use rand::{RngExt, SeedableRng}; // rand 0.10 (Cargo.toml:36): the sampling methods live on RngExt, as in src/prover.rs:968
 
         let mut rng = SmallRng::seed_from_u64(42);
         let perm = Poseidon2BabyBear::<16>::new_from_rng_128(&mut rng);
