@@ -290,6 +290,7 @@ Ctx::~Ctx() {
     if (e) (void)hipEventDestroy(e);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (claims_stream) (void)hipStreamDestroy(claims_stream);
+  for (auto e : group_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(stream);
 }
 
@@ -602,6 +603,15 @@ const uint8_t* Ctx::d2h_queue_staged(const void* src, size_t n) {
 void Ctx::d2h(void* dst, const void* src, size_t n) {
   d2h_queue(dst, src, n);
   sync_and_deliver();
+}
+
+hipEvent_t Ctx::group_event(size_t i) {
+  while (group_events.size() <= i) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    group_events.push_back(e);
+  }
+  return group_events[i];
 }
 
 hipEvent_t Ctx::prof_begin(int id) {

@@ -96,6 +96,9 @@ struct HWitness {
   HSystem* sys = nullptr;
   std::vector<size_t> heights;
   std::vector<DBuf<u64>> traces;  // row-major on device, as uploaded (empty for circuits another rank computes)
+  // host-resident, narrow upload by row groups (prover.hip HostUpload): the trace already transposed into bit-reversed column-major
+  // storage with the first pass of the inverse transform done, group by group as the rows arrived (empty otherwise)
+  std::vector<DBuf<u64>> early_evals;
   bool has_remote = false;        // some active circuit has no trace here: only prove_sharded accepts the witness
   std::vector<DLookups> lookups;
   // claims: host copy (transcript for small inputs) and device copy
@@ -124,13 +127,14 @@ struct HWitness {
   // runs when prefetching is on (ms_witness_prefetch): the following proof then finds its inputs already in HBM.
   struct Staged {
     bool valid = false, has_host_lookups = false;
-    std::vector<DBuf<u64>> traces, mult, args;
+    std::vector<DBuf<u64>> traces, mult, args, evals;
     std::vector<DBuf<uint8_t>> narrow;  // the narrowed rows as they arrived (kept until the upload has completed)
     DBuf<u64> claim_offsets, claim_data;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // traces, host lookup values, claims
     void clear() {
       valid = false;
       traces.clear();
+      evals.clear();
       narrow.clear();
       mult.clear();
       args.clear();

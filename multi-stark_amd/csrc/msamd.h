@@ -64,6 +64,8 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // bulk uploads of a host-resident witness, running beside the kernels of `stream`
   hipStream_t claims_stream = nullptr;  // the claims of a host-resident witness: DMA copies beside the trace's pulling kernels
+  std::vector<hipEvent_t> group_events;  // one per row group of a narrow upload in flight, created on demand (group_event)
+  hipEvent_t group_event(size_t i);
   // Side stream for the short circuits of a system (prover.hip): between side_fork() and side_join() the launches queued
   // inside a SideScope go to `side_stream` (the scope swaps `stream`) and run beside the long kernels of the main stream
   // instead of in front of them. Blocks allocated inside a scope come from a pool of their own (`pool_free_side`), and a
@@ -243,7 +245,11 @@ struct NttSrc {
   const u64* scale = nullptr;    // per destination column group: scale + (c % src_div) * 2^logn
 };
 void ntt_dif(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, const NttSrc* from = nullptr, u64 out_mul = 1);
-void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64 out_mul = 1);
+void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64 out_mul = 1, bool first_pass_done = false);
+// the first (4096-row tile) pass of ntt_dit on one of eight row groups; ntt_dit(.., first_pass_done = true) finishes (ntt.hip)
+void ntt_dit_first_pass_part(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, unsigned part_rev);
+void transpose_in_rows_part(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, unsigned part);
+void pull_widen_runs(const uint8_t* host_packed, unsigned bytes, size_t count, u64* out, size_t run_words, size_t run_stride, hipStream_t stream);
 // row-major host layout (h x w) on device -> column-major, optionally with rows bit-reversed
 void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, bool bitrev_rows);
 void transpose_out(Ctx& ctx, const u64* colmajor, u64* rowmajor, size_t h, size_t w, bool bitrev_rows);
@@ -254,7 +260,7 @@ void pull_widen_words(const uint8_t* host_packed, unsigned bytes, size_t count, 
 // coefficients (unscaled inverse DFT output, natural order, column-major n x w) -> bit-reversed coset LDE (Bn x w)
 void lde_from_coeffs(Ctx& ctx, const u64* coef, u64* lde, unsigned logn, unsigned log_blowup, size_t w);
 // evaluations in bit-reversed row order (column-major n x w, destroyed) -> bit-reversed coset LDE (Bn x w)
-void coset_lde(Ctx& ctx, u64* evals_bitrev, u64* lde, unsigned logn, unsigned log_blowup, size_t w);
+void coset_lde(Ctx& ctx, u64* evals_bitrev, u64* lde, unsigned logn, unsigned log_blowup, size_t w, bool first_pass_done = false);
 // src/prover.rs:631-717 fused: quotient values in storage (bit-reversed) order, nq x D column-major (destroyed)
 // -> committed quotient LDE (B n x qD)
 void quotient_lde(Ctx& ctx, u64* qvals_bitrev, u64* lde, unsigned logn, unsigned logq, unsigned log_blowup, size_t D);

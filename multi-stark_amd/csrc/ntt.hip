@@ -288,12 +288,13 @@ constexpr int NTT8S_LDS = 2048 + 128 + 8;
 
 // 12-bit contiguous pass over one 4096-element tile (bits 11..0 of the position inside the tile).
 template <bool DIT, bool INV>
+// (tile_mul, tile_add: workgroup x takes tile x * tile_mul + tile_add - 1, 0 for every tile; ntt_dit_first_pass_part below)
 __global__ __launch_bounds__(256) void ntt12_k(const u64* __restrict__ src, u64* __restrict__ dst, unsigned logn,
                                                const u64* __restrict__ twc, const u64* __restrict__ twc3, unsigned src_div,
-                                               const u64* __restrict__ scale, u64 out_mul) {
+                                               const u64* __restrict__ scale, u64 out_mul, u32 tile_mul, u32 tile_add) {
   __shared__ u64 sm[NTT12_LDS];
   const size_t n = size_t(1) << logn;
-  const size_t col = blockIdx.y, off = size_t(blockIdx.x) << 12;
+  const size_t col = blockIdx.y, off = (size_t(blockIdx.x) * tile_mul + tile_add) << 12;
   const u64* s = src + (col / src_div) * n + off;
   const u64* sc = scale ? scale + (col % src_div) * n + off : nullptr;
   u64* d = dst + col * n + off;
@@ -663,16 +664,19 @@ void launch_strided(Ctx& ctx, const u64* src, u64* dst, unsigned k, unsigned log
 
 template <int DIT>
 void launch_contig(Ctx& ctx, const u64* src, u64* dst, unsigned K, unsigned logn, size_t ncols, bool inverse,
-                   unsigned src_div, const u64* scale, u64 out_mul) {
-  dim3 grid((unsigned)(size_t(1) << (logn - K)), (unsigned)ncols);
+                   unsigned src_div, const u64* scale, u64 out_mul, u32 tile_mul = 1, u32 tile_add = 0) {
+  if (tile_mul != 1 && K != 12) throw std::runtime_error("ntt: a tile subset needs the 12-bit pass");
+  dim3 grid((unsigned)((size_t(1) << (logn - K)) / tile_mul), (unsigned)ncols);
   if (K == 12) {
     const int id = DIT ? K_NTT12_DIT : K_NTT12_DIF;
     hipEvent_t ev12 = ctx.prof_begin(id);
     if (inverse)
-      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, MSAMD_R16TW ? ctx.twfi : ctx.twc3i, src_div, scale, out_mul);
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), true>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twci, MSAMD_R16TW ? ctx.twfi : ctx.twc3i, src_div, scale, out_mul,
+                         tile_mul, tile_add);
     else
-      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, src_div, scale, out_mul);
-    ctx.prof_end(id, ev12, 16.0 * double(ncols) * double(size_t(1) << logn));
+      hipLaunchKernelGGL((ntt12_k<(DIT != 0), false>), grid, dim3(256), 0, ctx.stream, src, dst, logn, ctx.twc, MSAMD_R16TW ? ctx.twf : ctx.twc3, src_div, scale, out_mul,
+                         tile_mul, tile_add);
+    ctx.prof_end(id, ev12, 16.0 * double(ncols) * double(size_t(1) << logn) / tile_mul);
     return;
   }
   unsigned threads = K >= 9 ? 256 : 64;
@@ -728,10 +732,13 @@ __global__ void transpose_in_k(const u64* __restrict__ in, u64* __restrict__ out
 // are consecutive storage rows (128-byte runs per column). Columns go through LDS 16 at a time.
 // (blockIdx.y: a short, wide matrix - 512 rows x 2625 columns in the reference's BLAKE3 system - gives only h / 256 row blocks, so
 // the columns are dealt out over a second grid dimension, cols_per_block at a time, instead of one block walking all of them)
+// (sel_bits, sel_shift, sel_val: with sel_bits > 0 the grid covers only the blocks whose `mid` holds sel_val in the sel_bits bits
+// from sel_shift up - transpose_in_rows_part)
 __global__ __launch_bounds__(256) void transpose_in_br_k(const u64* __restrict__ in, u64* __restrict__ out, size_t h, size_t w,
-                                                         unsigned logh, u32 cols_per_block) {
+                                                         unsigned logh, u32 cols_per_block, u32 sel_bits, u32 sel_shift, u32 sel_val) {
   __shared__ u64 tile[256][17];
-  const u32 mid = blockIdx.x;
+  const u32 mid = sel_bits ? ((blockIdx.x >> sel_shift) << (sel_shift + sel_bits)) | (sel_val << sel_shift) | (blockIdx.x & ((1u << sel_shift) - 1u))
+                           : blockIdx.x;
   const size_t rmid = size_t(bitrev32(mid, logh - 8)) << 4;
   const u32 t = threadIdx.x;
   const u32 lo = t & 15, hi = t >> 4;
@@ -809,11 +816,22 @@ void ntt_dif(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, con
   launch_contig<0>(ctx, src, data, p.K, logn, ncols, inverse, src_div, scale, out_mul);
 }
 
-void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64 out_mul) {
+// The first pass of ntt_dit (4096-row tiles of the bit-reversed storage) on the tiles t with t mod 8 == part_rev only - the
+// natural rows whose residue modulo 2^(logn - 12) has part = rev3(part_rev) in its top three bits, i.e. one "row group" of a
+// host-resident trace that arrives in eight groups (prover.hip, HostUpload). ntt_dit(..., first_pass_done = true) does the rest.
+void ntt_dit_first_pass_part(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, unsigned part_rev) {
+  check_dims(logn, ncols);
+  if (logn < 15 || part_rev >= 8) throw std::runtime_error("ntt: a first pass by row groups needs 2^15 rows");
+  if (ncols == 0) return;
+  launch_contig<1>(ctx, data, data, 12, logn, ncols, inverse, 1, nullptr, 1, 8, part_rev);
+}
+
+void ntt_dit(Ctx& ctx, u64* data, unsigned logn, size_t ncols, bool inverse, u64 out_mul, bool first_pass_done) {
   check_dims(logn, ncols);
   if (ncols == 0) return;
   Plan p = make_plan(logn);
-  launch_contig<1>(ctx, data, data, p.K, logn, ncols, inverse, 1, nullptr, p.bits.empty() ? out_mul : 1);
+  if (first_pass_done && p.bits.empty()) throw std::runtime_error("ntt: no pass behind the first one");
+  if (!first_pass_done) launch_contig<1>(ctx, data, data, p.K, logn, ncols, inverse, 1, nullptr, p.bits.empty() ? out_mul : 1);
   unsigned logB = p.K;
   for (size_t i = p.bits.size(); i-- > 0;) {
     logB += p.bits[i];
@@ -842,8 +860,8 @@ void lde_from_coeffs(Ctx& ctx, const u64* coef, u64* lde, unsigned logn, unsigne
   ntt_dif(ctx, lde, logn, w << log_blowup, false, &from, 1);
 }
 
-void coset_lde(Ctx& ctx, u64* evals_bitrev, u64* lde, unsigned logn, unsigned log_blowup, size_t w) {
-  ntt_dit(ctx, evals_bitrev, logn, w, true, 1);  // unscaled inverse DFT: n * coefficients, natural order
+void coset_lde(Ctx& ctx, u64* evals_bitrev, u64* lde, unsigned logn, unsigned log_blowup, size_t w, bool first_pass_done) {
+  ntt_dit(ctx, evals_bitrev, logn, w, true, 1, first_pass_done);  // unscaled inverse DFT: n * coefficients, natural order
   lde_from_coeffs(ctx, evals_bitrev, lde, logn, log_blowup, w);
 }
 
@@ -888,13 +906,31 @@ void transpose_in(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t
     const size_t tiles_per_block = (col_tiles + by - 1) / by;
     by = (col_tiles + tiles_per_block - 1) / tiles_per_block;
     hipLaunchKernelGGL(transpose_in_br_k, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
-                       (u32)(tiles_per_block * 16));
+                       (u32)(tiles_per_block * 16), 0u, 0u, 0u);
   }
   else
     hipLaunchKernelGGL(transpose_in_k, dim3((unsigned)((h + 63) / 64)), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
                        bitrev_rows ? 1 : 0);
   HIP_CHECK(hipGetLastError());
   ctx.prof_end(K_TRANSPOSE, ev, 16.0 * double(h) * double(w));
+}
+
+// transpose_in(.., bitrev_rows = true) for ONE of eight row groups: the natural rows r whose residue modulo 2^T, T = log2 h - 12,
+// has `part` in its top three bits (runs of 2^(T-3) consecutive rows every 2^T). Those are the blocks of transpose_in_br_k
+// whose `mid` has rev3(part) in bits 8..10, and they fill the 4096-row storage tiles t with t mod 8 == rev3(part). h >= 2^19.
+void transpose_in_rows_part(Ctx& ctx, const u64* rowmajor, u64* colmajor, size_t h, size_t w, unsigned part) {
+  const unsigned logh = log2_strict(h);
+  if ((size_t(1) << logh) != h || logh < 19 || part >= 8) throw std::runtime_error("transpose: row groups need a power of two of at least 2^19 rows");
+  if (w == 0) return;
+  hipEvent_t ev = ctx.prof_begin(K_TRANSPOSE);
+  const size_t bx = h >> 11, col_tiles = (w + 15) / 16;  // an eighth of the h / 256 blocks
+  size_t by = bx < 1024 ? std::min(col_tiles, (1024 + bx - 1) / bx) : 1;
+  const size_t tiles_per_block = (col_tiles + by - 1) / by;
+  by = (col_tiles + tiles_per_block - 1) / tiles_per_block;
+  hipLaunchKernelGGL(transpose_in_br_k, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, ctx.stream, rowmajor, colmajor, h, w, logh,
+                     (u32)(tiles_per_block * 16), 3u, 8u, bitrev32(part, 3));
+  HIP_CHECK(hipGetLastError());
+  ctx.prof_end(K_TRANSPOSE, ev, 2.0 * double(h) * double(w));
 }
 
 namespace {
@@ -929,15 +965,17 @@ __global__ __launch_bounds__(256) void widen_k(const T* __restrict__ in, size_t 
 // The same, reading PINNED HOST memory itself (zero-copy over PCIe): one launch per chunk instead of a DMA copy into a staging
 // buffer plus a widening launch behind it. 16-byte loads, a fixed grid that keeps about a megabyte of requests in flight;
 // tools/micro/pull_rate.hip: eight 1.8 MB chunks in 327 us against 465 us for copy + widen (one 14.7 MB chunk: 282 against 321).
-template <class T>
-__global__ __launch_bounds__(256) void pull_widen_k(const T* __restrict__ host, size_t count, u64* __restrict__ out) {
+// (RUNS: the source is a sequence of runs of run_words words - a multiple of 16 - and run m goes to out + m * run_stride)
+template <class T, bool RUNS>
+__global__ __launch_bounds__(256) void pull_widen_k(const T* __restrict__ host, size_t count, u64* __restrict__ out, u32 run_words, u32 run_stride) {
   constexpr size_t PER = 16 / sizeof(T);
   const size_t stride = size_t(gridDim.x) * blockDim.x * PER;
   const size_t whole = count / PER * PER;
   for (size_t i = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) * PER; i < whole; i += stride) {
     const uint4 v = *reinterpret_cast<const uint4*>(host + i);
     const u32 w[4] = {v.x, v.y, v.z, v.w};
-    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + i);
+    const size_t dst = RUNS ? size_t((u32)i / run_words) * run_stride + (u32)i % run_words : i;
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(out + dst);
     if (sizeof(T) == 1) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -952,24 +990,36 @@ __global__ __launch_bounds__(256) void pull_widen_k(const T* __restrict__ host, 
       o[1] = make_ulonglong2(w[2], w[3]);
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+  if (!RUNS && blockIdx.x == 0 && threadIdx.x == 0)  // (runs are whole multiples of 16 words: no tail)
     for (size_t k = whole; k < count; k++) out[k] = host[k];
+}
+template <bool RUNS>
+void pull_widen_launch(const uint8_t* host_packed, unsigned bytes, size_t count, u64* out, u32 run_words, u32 run_stride, hipStream_t stream) {
+  if (reinterpret_cast<uintptr_t>(host_packed) & 15) throw std::runtime_error("pull_widen_words: source must be 16-byte aligned");
+  const dim3 grid((unsigned)std::min<size_t>(256, (count * bytes / 16 + 255) / 256 + 1)), block(256);
+  if (bytes == 1)
+    hipLaunchKernelGGL((pull_widen_k<uint8_t, RUNS>), grid, block, 0, stream, host_packed, count, out, run_words, run_stride);
+  else if (bytes == 2)
+    hipLaunchKernelGGL((pull_widen_k<uint16_t, RUNS>), grid, block, 0, stream, reinterpret_cast<const uint16_t*>(host_packed), count, out, run_words, run_stride);
+  else if (bytes == 4)
+    hipLaunchKernelGGL((pull_widen_k<uint32_t, RUNS>), grid, block, 0, stream, reinterpret_cast<const uint32_t*>(host_packed), count, out, run_words, run_stride);
+  else
+    throw std::runtime_error("pull_widen_words: unsupported width");
+  HIP_CHECK(hipGetLastError());
 }
 }  // namespace
 // `host_packed`: pinned host memory (hipHostMalloc), 16-byte aligned
 void pull_widen_words(const uint8_t* host_packed, unsigned bytes, size_t count, u64* out, hipStream_t stream) {
   if (!count) return;
-  if (reinterpret_cast<uintptr_t>(host_packed) & 15) throw std::runtime_error("pull_widen_words: source must be 16-byte aligned");
-  const dim3 grid((unsigned)std::min<size_t>(256, (count * bytes / 16 + 255) / 256 + 1)), block(256);
-  if (bytes == 1)
-    hipLaunchKernelGGL(pull_widen_k<uint8_t>, grid, block, 0, stream, host_packed, count, out);
-  else if (bytes == 2)
-    hipLaunchKernelGGL(pull_widen_k<uint16_t>, grid, block, 0, stream, reinterpret_cast<const uint16_t*>(host_packed), count, out);
-  else if (bytes == 4)
-    hipLaunchKernelGGL(pull_widen_k<uint32_t>, grid, block, 0, stream, reinterpret_cast<const uint32_t*>(host_packed), count, out);
-  else
-    throw std::runtime_error("pull_widen_words: unsupported width");
-  HIP_CHECK(hipGetLastError());
+  pull_widen_launch<false>(host_packed, bytes, count, out, 0, 0, stream);
+}
+// the same for a source made of runs of `run_words` words (a multiple of 16; count a multiple of it and below 2^32): run m is
+// written to out + m * run_stride
+void pull_widen_runs(const uint8_t* host_packed, unsigned bytes, size_t count, u64* out, size_t run_words, size_t run_stride, hipStream_t stream) {
+  if (!count) return;
+  if (run_words == 0 || run_words % 16 || count % run_words || count >> 32 || run_stride >> 32 || run_stride % 2)
+    throw std::runtime_error("pull_widen_runs: runs must be multiples of 16 words, the chunk below 2^32 words");
+  pull_widen_launch<true>(host_packed, bytes, count, out, (u32)run_words, (u32)run_stride, stream);
 }
 void widen_words(const uint8_t* packed, unsigned bytes, size_t count, u64* out, hipStream_t stream) {
   if (!count) return;

@@ -187,15 +187,17 @@ void commit_matrices(Ctx& ctx, std::vector<DMat>&& ldes, unsigned cap_height, Pc
 }
 
 // host row-major evaluations -> device bit-reversed coset LDE
-static DMat lde_of_host_matrix(Ctx& ctx, const u64* rowmajor_dev, size_t h, size_t w, unsigned lb) {
+// (`early`: the matrix already transposed and through the first pass of the inverse transform - HostUpload's row groups; taken over)
+static DMat lde_of_host_matrix(Ctx& ctx, const u64* rowmajor_dev, size_t h, size_t w, unsigned lb, DBuf<u64>* early = nullptr) {
   unsigned logn = log2_strict(h);
-  DBuf<u64> ev(ctx, h * w);
-  transpose_in(ctx, rowmajor_dev, ev.p, h, w, true);
+  const bool first_pass_done = early && early->p;
+  DBuf<u64> ev = first_pass_done ? std::move(*early) : DBuf<u64>(ctx, h * w);
+  if (!first_pass_done) transpose_in(ctx, rowmajor_dev, ev.p, h, w, true);
   DMat lde;
   lde.h = h << lb;
   lde.w = w;
   lde.buf = DBuf<u64>(ctx, lde.h * w);
-  coset_lde(ctx, ev.p, lde.d(), logn, lb, w);
+  coset_lde(ctx, ev.p, lde.d(), logn, lb, w, first_pass_done);
   return lde;
 }
 
@@ -594,13 +596,23 @@ class PackPool {
   static constexpr size_t MAX_CHUNKS = 64;
   size_t n_chunks = 0;
   // starts narrowing in[0 .. cnt) into out; chunk k covers elements [chunk_begin(k), chunk_begin(k + 1))
-  void start(const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks) {
+  // (run_words != 0, "row groups": `in` is a sequence of blocks of run_stride words and chunk k is made of the k-th run of
+  // run_words words of every block, packed back to back: out[chunk_begin(k) + m * run_words + i] = in[m * run_stride + k * run_words + i].
+  // run_stride = chunks * run_words, cnt a multiple of run_stride.)
+  void start(const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks, size_t run_words = 0) {
     job_mu_.lock();  // one job at a time (contexts on other threads wait here); released by finish()
     std::unique_lock<std::mutex> lk(mu_);
     in_ = in, out_ = out, pb_ = pb, cnt_ = cnt;
     n_chunks = std::max<size_t>(1, std::min(chunks, MAX_CHUNKS));
-    per_chunk_ = ((cnt + n_chunks - 1) / n_chunks + 63) & ~size_t(63);
-    n_chunks = (cnt + per_chunk_ - 1) / per_chunk_;
+    run_words_ = run_words;
+    if (run_words) {
+      per_chunk_ = cnt / n_chunks;
+      run_stride_ = n_chunks * run_words;
+      runs_per_chunk_ = cnt / run_stride_;
+    } else {
+      per_chunk_ = ((cnt + n_chunks - 1) / n_chunks + 63) & ~size_t(63);
+      n_chunks = (cnt + per_chunk_ - 1) / per_chunk_;
+    }
     next_.store(0);
     acc_.store(0);
     nsub_ = 2 * threads_.size();  // pieces per chunk
@@ -627,7 +639,9 @@ class PackPool {
   }
   struct Job {  // start ... finish, also when an error unwinds the caller
     PackPool& p;
-    Job(PackPool& pool, const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks) : p(pool) { p.start(in, out, pb, cnt, chunks); }
+    Job(PackPool& pool, const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks, size_t run_words = 0) : p(pool) {
+      p.start(in, out, pb, cnt, chunks, run_words);
+    }
     ~Job() { p.finish(); }
   };
 
@@ -647,6 +661,16 @@ class PackPool {
     const size_t it = next_.fetch_add(1);
     if (it >= n_chunks * nsub_) return false;
     const size_t k = it / nsub_, sub = it % nsub_;
+    if (run_words_) {
+      const size_t per = (runs_per_chunk_ + nsub_ - 1) / nsub_;
+      const size_t m0 = std::min(runs_per_chunk_, sub * per), m1 = std::min(runs_per_chunk_, m0 + per);
+      u64 acc = 0;
+      for (size_t m = m0; m < m1; m++)
+        acc |= narrow_range(in_ + m * run_stride_ + k * run_words_, out_ + (k * per_chunk_ + m * run_words_) * pb_, pb_, run_words_);
+      if (m1 > m0) acc_.fetch_or(acc);
+      left_[k].fetch_sub(1, std::memory_order_release);
+      return true;
+    }
     const size_t b = chunk_begin(k), e = chunk_begin(k + 1);
     const size_t piece = (((e - b) + nsub_ - 1) / nsub_ + 7) & ~size_t(7);
     const size_t lo = std::min(e, b + sub * piece), hi = std::min(e, lo + piece);
@@ -679,6 +703,7 @@ class PackPool {
   uint8_t* out_ = nullptr;
   unsigned pb_ = 1;
   size_t cnt_ = 0, per_chunk_ = 0, nsub_ = 1;
+  size_t run_words_ = 0, run_stride_ = 0, runs_per_chunk_ = 0;
   std::atomic<size_t> next_{0};
   std::atomic<u64> acc_{0};
   std::atomic<int> left_[MAX_CHUNKS];
@@ -831,6 +856,17 @@ struct HostUpload {
   Ctx& ctx;
   bool on = false;
   bool skip_claims = false;  // the multi-rank prover uploads per-rank slices of the claims itself
+  // Row groups (plain prover only, opt-in: MSAMD_ROW_GROUPS=1). A transform needs every row of a column, so with chunks of
+  // consecutive rows nothing of stage 1 can start before the last chunk has landed. The first pass of the inverse transform,
+  // though, works on 4096-row tiles of the bit-reversed storage, and tile t holds the natural rows r with r mod 2^T = rev_T(t),
+  // T = log2 h - 12: a chunk made of the rows whose residue has k in its top three bits - runs of 2^(T-3) consecutive rows
+  // every 2^T - completes the tiles t = 8 i + rev3(k). So chunk k is narrowed, pulled (scattered back to its rows: stage 2 reads
+  // the row-major trace), transposed and taken through that first pass while the host narrows chunk k + 1, and stage 1 starts
+  // at the second pass: 0.12 ms of kernels leave the critical path. Measured (2^20 x 14, 32-row runs of 3.5 KB every 28 KB):
+  // the HOST side loses more than that - sixteen threads narrow the trace in 0.39 ms from consecutive rows and in 0.52-0.59 ms
+  // from such runs (tools/micro/pack_runs.cpp; 0.43 ms only at 512-row runs, which would need a first pass of 8 levels), the
+  // last chunk is queued at 0.94-1.00 ms instead of 0.41-0.48, and the step is 0.05-0.2 ms SLOWER. Hence off by default.
+  bool row_groups = false;
   HostUpload(HWitness& wit, Ctx& c) : w(wit), ctx(c) {}
   // does stage 2 of this circuit run from the uploaded trace (stage2_terms_trace_jit)?
   bool fused(size_t ci) const {
@@ -844,6 +880,7 @@ struct HostUpload {
       if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     st.clear();
     st.traces.resize(C);
+    st.evals.resize(C);
     st.mult.resize(C);
     st.args.resize(C);
     // buffers first: pool blocks handed out here may still be in use by kernels queued earlier on ctx.stream
@@ -886,7 +923,34 @@ struct HostUpload {
         static const bool pull = !getenv("MSAMD_NO_PULL");  // MSAMD_NO_PULL=1: DMA copy into a staging buffer + widening launch
         static const bool two_streams = getenv("MSAMD_PULL_TWO_STREAMS") != nullptr;  // (measured: no difference, 6.03-6.16 ms either way)
         if (!pull) narrow[ci] = DBuf<uint8_t>(ctx, cnt * pb);
-        {
+        const bool want_groups = getenv("MSAMD_ROW_GROUPS") != nullptr;  // (read per proof: tests flip it)
+        const unsigned logh = log2_strict(h);
+        const bool groups = row_groups && pull && !two_streams && want_groups && (size_t(1) << logh) == h && logh >= 19 && cnt < (size_t(1) << 35) &&
+                            ctx.stream == ctx.main_stream;
+        if (groups) {
+          const size_t T = logh - 12, run_rows = size_t(1) << (T - 3), run_words = run_rows * c.main_width, run_stride = run_words * 8;
+          st.evals[ci] = DBuf<u64>(ctx, cnt);
+          PackPool::Job job(*pool, w.h_traces[ci], w.h_packed[ci], pb, cnt, 8, run_words);
+          sent = true;
+          auto first_pass = [&](unsigned k) {  // group k has landed: transposed and through the first pass on the main stream
+            HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.group_event(k), 0));
+            transpose_in_rows_part(ctx, st.traces[ci].p, st.evals[ci].p, h, c.main_width, k);
+            ntt_dit_first_pass_part(ctx, st.evals[ci].p, logh, c.main_width, true, bitrev32(k, 3));
+          };
+          for (unsigned k = 0; k < 8; k++) {
+            if (!pool->wait_chunk(k)) {  // a value outgrew the width found at creation: the plain path below
+              sent = false;
+              break;
+            }
+            if (k == 0) g_probes.mark("narrow upload: first chunk ready");
+            pull_widen_runs(w.h_packed[ci] + pool->chunk_begin(k) * pb, pb, cnt / 8, st.traces[ci].p + k * run_words, run_words, run_stride, ctx.copy_stream);
+            HIP_CHECK(hipEventRecord(ctx.group_event(k), ctx.copy_stream));
+            if (k) first_pass(k - 1);  // (behind the pull: the link must not wait for this thread's launches)
+          }
+          if (sent) first_pass(7);
+          g_probes.mark("narrow upload: last chunk queued");
+          if (!sent) st.evals[ci].reset();  // (what the launches above wrote is abandoned; the block is reused behind them)
+        } else {
           static const size_t n_chunks = getenv("MSAMD_PACK_CHUNKS") ? (size_t)atoi(getenv("MSAMD_PACK_CHUNKS")) : 8;
           PackPool::Job job(*pool, w.h_traces[ci], w.h_packed[ci], pb, cnt, n_chunks);
           sent = true;
@@ -958,8 +1022,10 @@ struct HostUpload {
       issue(w.stage[w.cur]);
     HWitness::Staged& st = w.stage[w.cur];
     // the proof reads through the witness's usual members
+    w.early_evals.resize(st.traces.size());
     for (size_t ci = 0; ci < st.traces.size(); ci++) {
       w.traces[ci] = std::move(st.traces[ci]);
+      w.early_evals[ci] = std::move(st.evals[ci]);
       w.lookups[ci].mult = std::move(st.mult[ci]);
       w.lookups[ci].args = std::move(st.args[ci]);
     }
@@ -990,6 +1056,7 @@ struct HostUpload {
     (void)hipStreamSynchronize(ctx.claims_stream);
     w.stage[w.cur].narrow.clear();
     for (auto& t : w.traces) t.reset();
+    for (auto& t : w.early_evals) t.reset();
     for (auto& lk : w.lookups) {
       lk.mult.reset();
       lk.args.reset();
@@ -2035,6 +2102,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
 
   RoctxRange whole("stark/prove");
   HostUpload up(wit, ctx);  // host-resident witness: uploads start now and run beside the transcript set-up
+  up.row_groups = true;
   up.start();
   g_probes.mark("uploads issued");
   Challenger ch(sys.seed);
@@ -2157,7 +2225,8 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     for (size_t pos : order) {
       const size_t ci = aidx[pos];
       SideScope sc(ctx, on_side[pos]);
-      ldes[pos] = lde_of_host_matrix(ctx, wit.traces[ci].p, wit.heights[ci], sys.circuits[ci].main_width, lb);
+      ldes[pos] = lde_of_host_matrix(ctx, wit.traces[ci].p, wit.heights[ci], sys.circuits[ci].main_width, lb,
+                                     !on_side[pos] && ci < wit.early_evals.size() ? &wit.early_evals[ci] : nullptr);
     }
     ctx.side_join();
     if (early_claims) {
@@ -2235,13 +2304,22 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
   // stay in device memory (d_tot[0] = claims, d_tot[1 + pos] = circuit) and come back with that commitment.
   DBuf<E2> d_tot(ctx, NA + 1);
   std::vector<E2> h_tot(NA + 1);
-  if (n_claims > 256 || dev_outer) {
-    // nothing reads the claims' sum before the accumulators are formed behind the stage-2 commitment: with a side stream it
-    // runs there, beside the long circuits' stage-2 terms (the streams join in front of that commitment)
-    const bool beside = ctx.side_enabled && !getenv("MSAMD_CLAIMS_ACC_MAIN");
-    if (beside && !ctx.side_forked) ctx.side_fork();
-    SideScope sc(ctx, beside);
+  // nothing reads the claims' sum before the accumulators are formed behind the stage-2 commitment: with a side stream it
+  // runs there, beside the long circuits' stage-2 kernels (the streams join in front of that commitment) and BEHIND the short
+  // circuits' stage 2, which the side stream also carries: the sum is a quarter of a millisecond of few, long-running waves
+  // (one per SIMD); in front of the short circuits it held their launches back until the long circuit's stage-2 trace was
+  // being written, and beside the long circuit's terms it cost that kernel 20 us (226 -> 206). MSAMD_CLAIMS_ACC_FIRST=1: the
+  // earlier order
+  const bool claims_on_device = n_claims > 256 || dev_outer;
+  const bool claims_beside = claims_on_device && ctx.side_enabled && !getenv("MSAMD_CLAIMS_ACC_MAIN");
+  const bool claims_last = claims_beside && !getenv("MSAMD_CLAIMS_ACC_FIRST");
+  auto claims_sum_launch = [&]() {
+    if (claims_beside && !ctx.side_forked) ctx.side_fork();
+    SideScope sc(ctx, claims_beside);
     claims_accumulator_dyn(ctx, wit.d_claim_data.p, wit.d_claim_offsets.p, n_claims, d_bg.p, d_tot.p);
+  };
+  if (claims_on_device) {
+    if (!claims_last) claims_sum_launch();
   } else {
     E2 acc0 = e2(0);
     for (size_t i = 0; i < n_claims; i++) {
@@ -2266,6 +2344,7 @@ std::vector<uint8_t> prove(HSystem& sys, HWitness& wit, StageMs* times) {
     s2_evals[pos] = DBuf<u64>(ctx, n * c.stage2_width);
     stage2_circuit_dyn(ctx, sys, wit, ci, d_bg.p, s2_evals[pos].p, d_tot.p + 1 + pos);
   }
+  if (claims_last) claims_sum_launch();
   lap(1);
   t0 = now_ms();
   phase.next("stark/stage2_commit");

@@ -243,6 +243,50 @@ def test_host_resident_witness_narrow_upload(pkg, ctx, oracle, fe, case, monkeyp
         assert g.prove_multiple_claims(hw).to_bytes() == want
 
 
+# Row groups (MSAMD_ROW_GROUPS=1; measured slower on the pool's hosts, hence opt-in): from 2^19 rows on the narrow upload of the plain
+# prover is cut into eight groups of rows that each complete whole tiles of the inverse transform's first pass
+# (HostUpload::row_groups), and that pass runs group by group as the rows arrive. Odd width, 16- and 32-row runs, every width
+# class; a value that outgrows its class in the FIRST group and one in the SIXTH (five groups already transposed and
+# transformed: abandoned) must give the plain path's proof
+@pytest.mark.parametrize("log_h,case", [(19, "bytes"), (19, "u16"), (20, "u32")])
+def test_host_resident_witness_row_groups(pkg, ctx, oracle, fe, log_h, case, monkeypatch):
+    monkeypatch.setenv("MSAMD_ROW_GROUPS", "1")
+    top = {"bytes": 1 << 8, "u16": 1 << 16, "u32": 1 << 32}[case]
+    h = 1 << log_h
+    t = fe.pythagorean_trace(h).copy()
+    # (k a, k b, k c) stays a triple: a row-dependent factor makes the rows differ (a row landing in another row's place must show)
+    kmax = (top - 1) // int(t.max())
+    k = (np.arange(h, dtype=np.uint64) * np.uint64(2654435761) >> np.uint64(7)) % np.uint64(kmax) + np.uint64(1)
+    t = t * k[:, None]
+    t[1] = fe.pythagorean_trace(4)[1] * np.uint64(kmax)   # the class's largest value is present
+    assert top // 2 <= int(t.max()) < top or case == "bytes"
+    traces = [np.ascontiguousarray(t, dtype=np.uint64)]
+    g = pkg.System.new(ctx, fe.test_params(), fe.pythagorean_inputs())
+    packed = fe.pack_claims([])
+    osys = oracle.System(g.blob)
+    want = osys.prove(traces, packed)
+    hw = g.host_witness(traces, packed)
+    for _ in range(2):
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+    # the path under test is the one that ran: eight transposes and eight first passes for the one matrix
+    ctx.set_profile(["transpose", "ntt12_dit"])
+    ctx.reset_stats()
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    st = ctx.kernel_stats()
+    ctx.set_profile([])
+    assert st["transpose"]["launches"] == 8 and st["ntt12_dit"]["launches"] >= 8, st
+    assert g.prove_multiple_claims(g.witness(traces, packed)).to_bytes() == want
+    kept = hw.keep[0]
+    run = 1 << (log_h - 12 - 3)
+    for row in (5, 5 * run + 3, h - 1):   # groups 0, 5 and 7
+        old = kept[row].copy()
+        kept[row] = old * np.uint64(1 << 20)   # still a triple, outside every width class's range or at least this one's
+        assert int(kept[row].max()) >= top
+        assert g.prove_multiple_claims(hw).to_bytes() == osys.prove([kept.copy()], packed), row
+        kept[row] = old
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+
+
 # ms_witness_prefetch: each proof of a host-resident witness also uploads the inputs of the next one; same bytes, also
 # across switching it on and off, interleaved with other witnesses, and after an injected mid-proof failure
 def test_host_witness_prefetch(pkg, ctx, oracle, fe):
