@@ -21,6 +21,8 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct msbb_system { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_witness { _p: [u8; 0] }
 #[repr(C)] pub struct msbb_mmcs { _p: [u8; 0] }
+#[repr(C)] pub struct msbb_challenger { _p: [u8; 0] }
+#[repr(C)] pub struct msbb_trace { _p: [u8; 0] }
 
 pub const MS_OK: i32 = 0;
 pub const MS_ERR: i32 = -1;
@@ -181,4 +183,26 @@ extern "C" {
     pub fn msbb_mmcs_open(m: *mut msbb_mmcs, index: usize, vals_out: *mut u32, proof_out: *mut u32, n_siblings: *mut usize) -> i32;
     pub fn msbb_mmcs_destroy(m: *mut msbb_mmcs);
     pub fn msbb_field_op(ctx: *mut ms_ctx, op: i32, a: *const u32, b: *const u32, n: usize, out: *mut u32) -> i32;
+    // Level 2 of the BabyBear configuration (include/mstark_bb.h)
+    pub fn msbb_challenger_create(sys: *mut msbb_system, out: *mut *mut msbb_challenger) -> i32;
+    pub fn msbb_challenger_destroy(ch: *mut msbb_challenger);
+    pub fn msbb_challenger_observe(ch: *mut msbb_challenger, elems: *const u32, n: usize) -> i32;
+    pub fn msbb_challenger_observe_digests(ch: *mut msbb_challenger, digests: *const u32, n: usize) -> i32;
+    pub fn msbb_challenger_sample_ext(ch: *mut msbb_challenger, out4: *mut u32) -> i32;
+    pub fn msbb_challenger_sample_bits(ch: *mut msbb_challenger, bits: u32, out: *mut u64) -> i32;
+    pub fn msbb_challenger_observe_claims(ch: *mut msbb_challenger, w: *mut msbb_witness) -> i32;
+    pub fn msbb_trace_destroy(t: *mut msbb_trace);
+    pub fn msbb_trace_info(t: *const msbb_trace, out3: *mut u64) -> i32;
+    pub fn msbb_system_preprocessed_mmcs(sys: *mut msbb_system, out: *mut *mut msbb_mmcs) -> i32;
+    pub fn msbb_witness_commit_stage1(w: *mut msbb_witness, cap_out: *mut u32, out: *mut *mut msbb_mmcs) -> i32;
+    pub fn msbb_witness_claims_accumulator(w: *mut msbb_witness, beta: *const u32, gamma: *const u32, acc_out: *mut u32) -> i32;
+    pub fn msbb_stage2_build(w: *mut msbb_witness, beta: *const u32, gamma: *const u32, acc_in: *const u32, accs_out: *mut u32,
+                             traces_out: *mut *mut msbb_trace) -> i32;
+    pub fn msbb_pcs_commit_traces(sys: *mut msbb_system, n: usize, evals: *const *mut msbb_trace, cap_out: *mut u32, out: *mut *mut msbb_mmcs) -> i32;
+    pub fn msbb_quotient(sys: *mut msbb_system, circuit: usize, log_n: u32, s1: *mut msbb_mmcs, s1_idx: usize, s2: *mut msbb_mmcs, s2_idx: usize,
+                         publics16: *const u32, alpha: *const u32, q_lde_out: *mut *mut msbb_trace) -> i32;
+    pub fn msbb_pcs_commit_ldes(sys: *mut msbb_system, n: usize, ldes: *const *mut msbb_trace, cap_out: *mut u32, out: *mut *mut msbb_mmcs) -> i32;
+    pub fn msbb_pcs_open(sys: *mut msbb_system, n_rounds: usize, rounds: *const *mut msbb_mmcs, n_points: *const u64, points: *const u32,
+                         ch: *mut msbb_challenger, opened_out: *mut u32, opened_cap_words: usize, fri_out: *mut u8, fri_cap: usize,
+                         fri_len: *mut usize) -> i32;
 }

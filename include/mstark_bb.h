@@ -79,6 +79,52 @@ void msbb_mmcs_destroy(msbb_mmcs* m);
 /* op 0 add, 1 sub, 2 mul, 3 inverse(a), 4 ext4 mul (quads), 5 ext4 inverse (quads) */
 int32_t msbb_field_op(ms_ctx* ctx, int32_t op, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out);
 
+/* ---- Level 2: the prover's steps on DEVICE HANDLES for this configuration, the counterpart of include/mstark.h's Level 2 - a
+ * host that keeps the reference's own prover loop (src/prover.rs:290-603) calls the device once per step, and only
+ * commitments, accumulators and challenges cross the boundary. Field elements are canonical u32, extension elements four
+ * of them, digests eight (as everywhere in this header; the proof bytes hold Montgomery words, src/prover.rs:241-248).
+ * tests/test_gpu_bb_level2.py drives the loop from Python and obtains the bytes msbb_prove writes.
+ *   msbb_challenger_create          config.initialise_challenger()                       baby_bear_config.rs:96-100
+ *   msbb_challenger_observe / _observe_digests / _sample_ext / _sample_bits              DuplexChallenger, baby_bear_config.rs:37
+ *   msbb_challenger_observe_claims  the claims absorbed by the transcript                src/prover.rs:369-373
+ *   msbb_witness_commit_stage1      pcs.commit(stage-1 traces)                           src/prover.rs:338-350
+ *   msbb_witness_claims_accumulator the initial accumulator                              src/prover.rs:382-387
+ *   msbb_stage2_build               LookupValues::stage_2_traces -> evaluation handles   src/prover.rs:400, src/lookup.rs:472-555
+ *   msbb_pcs_commit_traces          pcs.commit(stage-2 traces) on those handles          src/prover.rs:414-419
+ *   msbb_quotient                   quotient_values + slices + LDE -> LDE handle         src/prover.rs:459-468,483,511-517
+ *   msbb_pcs_commit_ldes            pcs.commit_ldes                                      src/prover.rs:526
+ *   msbb_system_preprocessed_mmcs   the ProverKey's preprocessed prover data (a view)    src/system.rs:190-195
+ *   msbb_pcs_open                   pcs.open: opened values + the FriProof bytes         src/prover.rs:580
+ * Matrices of a commitment are indexed by ACTIVE position. A handle consumed by a commit call keeps existing but is empty.
+ * The commitment parameters (log_blowup, cap_height) and the FRI parameters are the system's. Host-resident witnesses are
+ * not accepted. msbb_pcs_open: n_points has one entry per matrix (rounds flattened, at most two points per matrix), points
+ * four words per point; opened values come back in round -> matrix -> point -> column order, four words each;
+ * MS_ERR_BUFFER with *fri_len = the needed size when a capacity is too small (the challenger has then been advanced). */
+typedef struct msbb_challenger msbb_challenger;
+typedef struct msbb_trace msbb_trace;
+int32_t msbb_challenger_create(msbb_system* sys, msbb_challenger** out);
+void msbb_challenger_destroy(msbb_challenger* ch);
+int32_t msbb_challenger_observe(msbb_challenger* ch, const uint32_t* elems, size_t n);
+int32_t msbb_challenger_observe_digests(msbb_challenger* ch, const uint32_t* digests, size_t n);
+int32_t msbb_challenger_sample_ext(msbb_challenger* ch, uint32_t out4[4]);
+int32_t msbb_challenger_sample_bits(msbb_challenger* ch, uint32_t bits, uint64_t* out);
+int32_t msbb_challenger_observe_claims(msbb_challenger* ch, msbb_witness* w);
+void msbb_trace_destroy(msbb_trace* t);
+int32_t msbb_trace_info(const msbb_trace* t, uint64_t out3[3]); /* height, width, kind (0 evaluations, 1 LDE) */
+int32_t msbb_system_preprocessed_mmcs(msbb_system* sys, msbb_mmcs** out); /* *out = NULL when the system has no preprocessed trace */
+int32_t msbb_witness_commit_stage1(msbb_witness* w, uint32_t* cap_out, msbb_mmcs** out);
+int32_t msbb_witness_claims_accumulator(msbb_witness* w, const uint32_t beta[4], const uint32_t gamma[4], uint32_t acc_out[4]);
+/* accs_out: 4 words per active circuit (the accumulator after each circuit); traces_out: one handle per active circuit */
+int32_t msbb_stage2_build(msbb_witness* w, const uint32_t beta[4], const uint32_t gamma[4], const uint32_t acc_in[4], uint32_t* accs_out,
+                          msbb_trace** traces_out);
+int32_t msbb_pcs_commit_traces(msbb_system* sys, size_t n, msbb_trace* const* evals, uint32_t* cap_out, msbb_mmcs** out);
+/* publics16 = [beta, gamma, acc_in, acc_out] (src/lookup.rs:78-84) */
+int32_t msbb_quotient(msbb_system* sys, size_t circuit, uint32_t log_n, msbb_mmcs* s1, size_t s1_idx, msbb_mmcs* s2, size_t s2_idx,
+                      const uint32_t publics16[16], const uint32_t alpha[4], msbb_trace** q_lde_out);
+int32_t msbb_pcs_commit_ldes(msbb_system* sys, size_t n, msbb_trace* const* ldes, uint32_t* cap_out, msbb_mmcs** out);
+int32_t msbb_pcs_open(msbb_system* sys, size_t n_rounds, msbb_mmcs* const* rounds, const uint64_t* n_points, const uint32_t* points,
+                      msbb_challenger* ch, uint32_t* opened_out, size_t opened_cap_words, uint8_t* fri_out, size_t fri_cap, size_t* fri_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,11 @@ def exported_symbols():
     """Every entry point include/mstark_bb.h declares (used by the CPU-side ABI test)."""
     return ["msbb_system_create", "msbb_system_destroy", "msbb_system_preprocessed_commit", "msbb_system_circuit_info",
             "msbb_witness_create", "msbb_witness_create_host", "msbb_witness_destroy", "msbb_prove", "msbb_verify", "msbb_set_poseidon2", "msbb_poseidon2_permute",
-            "msbb_dft_batch", "msbb_coset_lde_batch", "msbb_mmcs_commit", "msbb_mmcs_open", "msbb_mmcs_destroy", "msbb_field_op"]
+            "msbb_dft_batch", "msbb_coset_lde_batch", "msbb_mmcs_commit", "msbb_mmcs_open", "msbb_mmcs_destroy", "msbb_field_op",
+            "msbb_challenger_create", "msbb_challenger_destroy", "msbb_challenger_observe", "msbb_challenger_observe_digests",
+            "msbb_challenger_sample_ext", "msbb_challenger_sample_bits", "msbb_challenger_observe_claims", "msbb_trace_destroy", "msbb_trace_info",
+            "msbb_system_preprocessed_mmcs", "msbb_witness_commit_stage1", "msbb_witness_claims_accumulator", "msbb_stage2_build",
+            "msbb_pcs_commit_traces", "msbb_quotient", "msbb_pcs_commit_ldes", "msbb_pcs_open"]
 
 
 import sys
@@ -158,6 +162,166 @@ class System:
             _check(rc)
             keys = ["stage1_commit", "lookup_construction", "stage2_commit", "quotient", "fri_open", "total"]
             return Proof(out[: n.value].tobytes(), dict(zip(keys, times.tolist())) if want_times else None)
+
+
+# ---- Level 2: the prover's steps on device handles (include/mstark_bb.h; tests/test_gpu_bb_level2.py drives the reference's loop)
+def _e4(x):
+    a = _u32(x).reshape(-1)
+    assert a.size == 4
+    return a
+
+
+class Challenger:
+    """config.initialise_challenger() of the system's configuration (msbb_challenger_*): values in and out are canonical"""
+
+    def __init__(self, system):
+        self.system = system
+        self.h = C.c_void_p()
+        _check(_lib().msbb_challenger_create(system.h, C.byref(self.h)))
+
+    def observe(self, elems):
+        a = _u32(np.array([int(x) % P for x in elems], dtype=np.uint64))   # (Val::from_usize for the integers of the shape)
+        _check(_lib().msbb_challenger_observe(self.h, _p32(a), C.c_size_t(a.size)))
+
+    def observe_digests(self, words):
+        a = _u32(words).reshape(-1)
+        assert a.size % 8 == 0
+        _check(_lib().msbb_challenger_observe_digests(self.h, _p32(a), C.c_size_t(a.size // 8)))
+
+    def observe_claims(self, witness):
+        _check(_lib().msbb_challenger_observe_claims(self.h, witness.h))
+
+    def sample_ext(self):
+        o = np.zeros(4, dtype=np.uint32)
+        _check(_lib().msbb_challenger_sample_ext(self.h, _p32(o)))
+        return tuple(int(x) for x in o)
+
+    def sample_bits(self, bits):
+        o = C.c_uint64()
+        _check(_lib().msbb_challenger_sample_bits(self.h, C.c_uint32(bits), C.byref(o)))
+        return o.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib().msbb_challenger_destroy(self.h)
+            self.h = None
+
+
+class Trace:
+    """a matrix that stays in HBM between two steps (msbb_trace)"""
+
+    def __init__(self, h):
+        self.h = h
+
+    def info(self):
+        o = np.zeros(3, dtype=np.uint64)
+        _check(_lib().msbb_trace_info(self.h, o.ctypes.data_as(u64p)))
+        return tuple(int(x) for x in o)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib().msbb_trace_destroy(self.h)
+            self.h = None
+
+
+class Committed:
+    """prover data of one commitment (msbb_mmcs) with its cap"""
+
+    def __init__(self, h, cap, shapes=None):
+        self.h, self.cap, self.shapes = h, cap, shapes
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib().msbb_mmcs_destroy(self.h)
+            self.h = None
+
+
+def _cap_buf(cap_height):
+    return np.zeros(8 << cap_height, dtype=np.uint32)
+
+
+def _trim_cap(cap, cap_height, max_height):
+    return cap[: 8 * min(1 << cap_height, max_height)].copy()
+
+
+def commit_stage1(witness, params, lde_heights):
+    cap = _cap_buf(params.cap_height)
+    h = C.c_void_p()
+    _check(_lib().msbb_witness_commit_stage1(witness.h, _p32(cap), C.byref(h)))
+    return Committed(h, _trim_cap(cap, params.cap_height, max(lde_heights)))
+
+
+def claims_accumulator(witness, beta, gamma):
+    o = np.zeros(4, dtype=np.uint32)
+    _check(_lib().msbb_witness_claims_accumulator(witness.h, _p32(_e4(beta)), _p32(_e4(gamma)), _p32(o)))
+    return tuple(int(x) for x in o)
+
+
+def stage2_build(witness, n_active, beta, gamma, acc_in):
+    accs = np.zeros(4 * n_active, dtype=np.uint32)
+    hs = (C.c_void_p * n_active)()
+    _check(_lib().msbb_stage2_build(witness.h, _p32(_e4(beta)), _p32(_e4(gamma)), _p32(_e4(acc_in)), _p32(accs), hs))
+    return [tuple(int(x) for x in accs[4 * i: 4 * i + 4]) for i in range(n_active)], [Trace(C.c_void_p(h)) for h in hs]
+
+
+def _commit(fn, system, params, traces, lde_heights):
+    n = len(traces)
+    hs = (C.c_void_p * n)(*[t.h for t in traces])
+    cap = _cap_buf(params.cap_height)
+    h = C.c_void_p()
+    _check(fn(system.h, C.c_size_t(n), hs, _p32(cap), C.byref(h)))
+    return Committed(h, _trim_cap(cap, params.cap_height, max(lde_heights)))
+
+
+def pcs_commit_traces(system, params, traces):
+    heights = [t.info()[0] << params.log_blowup for t in traces]
+    return _commit(_lib().msbb_pcs_commit_traces, system, params, traces, heights)
+
+
+def pcs_commit_ldes(system, params, ldes):
+    heights = [t.info()[0] for t in ldes]
+    return _commit(_lib().msbb_pcs_commit_ldes, system, params, ldes, heights)
+
+
+def quotient(system, circuit, log_n, s1, s1_idx, s2, s2_idx, publics16, alpha):
+    pub = _u32(publics16).reshape(-1)
+    assert pub.size == 16
+    h = C.c_void_p()
+    _check(_lib().msbb_quotient(system.h, C.c_size_t(circuit), C.c_uint32(log_n), s1.h, C.c_size_t(s1_idx), s2.h, C.c_size_t(s2_idx), _p32(pub),
+                                _p32(_e4(alpha)), C.byref(h)))
+    return Trace(h)
+
+
+def preprocessed_mmcs(system):
+    h = C.c_void_p()
+    _check(_lib().msbb_system_preprocessed_mmcs(system.h, C.byref(h)))
+    return Committed(h, system.preprocessed_commit()) if h.value else None
+
+
+def pcs_open(system, rounds, challenger):
+    """rounds: [(Committed, [widths], [[point, ...] per matrix])]; returns (opened canonical words, FriProof bytes)"""
+    hs = (C.c_void_p * len(rounds))(*[r[0].h for r in rounds])
+    npts, pts, words = [], [], 0
+    for _, widths, points in rounds:
+        assert len(widths) == len(points)
+        for w, ps in zip(widths, points):
+            npts.append(len(ps))
+            for p_ in ps:
+                pts.extend(int(x) for x in p_)
+            words += 4 * w * len(ps)
+    npts = np.ascontiguousarray(npts, dtype=np.uint64)
+    pts = _u32(pts if pts else [0])
+    opened = np.zeros(max(words, 1), dtype=np.uint32)
+    cap = 1 << 20
+    while True:
+        fri = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t()
+        rc = _lib().msbb_pcs_open(system.h, C.c_size_t(len(rounds)), hs, npts.ctypes.data_as(u64p), _p32(pts), challenger.h, _p32(opened),
+                                  C.c_size_t(opened.size), fri.ctypes.data_as(u8p), C.c_size_t(cap), C.byref(n))
+        if rc == -3 and n.value > cap:
+            raise _pkg().MstarkError("msbb_pcs_open: FriProof larger than the buffer (%d bytes); the challenger has been advanced" % n.value)
+        _check(rc)
+        return opened[:words].copy(), fri[: n.value].tobytes()
 
 
 # ---- PCS-level entry points

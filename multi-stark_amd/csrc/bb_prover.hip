@@ -489,6 +489,20 @@ struct FriOut {
   std::vector<uint8_t> query_bytes;  // the serialised Vec<QueryProof> body (without its length)
 };
 
+// the opening_proof field of Proof::to_bytes (FriProof: commit-phase caps, their proof-of-work witnesses, the query proofs, the
+// final polynomial, the query proof-of-work witness)
+void write_fri(W& w, const FriOut& fri, const Params& prm) {
+  w.u64_(fri.commits.size());
+  for (auto& c : fri.commits) w.cap(c);
+  w.u64_(fri.pow_witnesses.size());
+  for (u32 x : fri.pow_witnesses) w.fe(bb_to_monty(x));
+  w.u64_(prm.num_queries);
+  w.b.insert(w.b.end(), fri.query_bytes.begin(), fri.query_bytes.end());
+  w.u64_(fri.final_poly.size());
+  for (auto& e : fri.final_poly) w.ext(e);
+  w.fe(bb_to_monty(fri.query_pow_witness));
+}
+
 // challenger.grind(bits): from 8 bits on the search runs on the device (one permutation per candidate); the host
 // challenger then replays the winning witness and checks it
 u32 grind(BSystem& sys, Challenger& ch, unsigned bits) {
@@ -1011,15 +1025,7 @@ std::vector<uint8_t> prove(BSystem& sys, BWitness& wit, double* stage_ms) {
   for (auto& e : accumulators) w.ext(e);
   w.u64_(log_degrees.size());
   for (auto d : log_degrees) w.u8((uint8_t)d);
-  w.u64_(fri.commits.size());
-  for (auto& c : fri.commits) w.cap(c);
-  w.u64_(fri.pow_witnesses.size());
-  for (u32 x : fri.pow_witnesses) w.fe(bb_to_monty(x));
-  w.u64_(prm.num_queries);
-  w.b.insert(w.b.end(), fri.query_bytes.begin(), fri.query_bytes.end());
-  w.u64_(fri.final_poly.size());
-  for (auto& e : fri.final_poly) w.ext(e);
-  w.fe(bb_to_monty(fri.query_pow_witness));
+  write_fri(w, fri, prm);
   write_round(w, opened[2]);
   w.u8(sys.has_pre ? 1 : 0);
   if (sys.has_pre) write_round(w, opened[3]);
@@ -1682,6 +1688,20 @@ struct msbb_mmcs {
   ms_ctx* owner = nullptr;
   Ctx* ctx = nullptr;
   BPcsData data;
+  // Level 2: a view of prover data owned by a system (its preprocessed commitment), which the handle keeps alive
+  const BPcsData* view = nullptr;
+  msbb_system* sys_ref = nullptr;
+  const BPcsData& d() const { return view ? *view : data; }
+};
+// Level 2: a matrix that stays in HBM between two steps (stage-2 evaluations, a quotient LDE)
+struct msbb_trace {
+  ms_ctx* owner = nullptr;
+  BMat m;
+  int kind = 0;  // 0 evaluations over the trace domain (natural order), 1 committed-domain LDE (bit-reversed storage)
+};
+struct msbb_challenger {
+  msbb_system* owner = nullptr;
+  std::unique_ptr<Challenger> ch;
 };
 // a process-wide permutation for the PCS-level entry points (msbb_set_poseidon2)
 struct PermHolder {
@@ -1903,12 +1923,12 @@ int32_t msbb_mmcs_open(msbb_mmcs* m, size_t index, uint32_t* vals_out, uint32_t*
   BB_TRY
   Ctx& c = *m->ctx;
   HIP_CHECK(hipSetDevice(c.device));
-  const BTree& t = m->data.tree;
+  const BTree& t = m->d().tree;
   unsigned log_max = log2_strict(t.sizes[0]);
   if (index >= t.sizes[0]) throw std::runtime_error("index out of range");
   std::vector<GatherSeg> segs;
   u32 pos = 0;
-  for (auto& mat : m->data.ldes) {
+  for (auto& mat : m->d().ldes) {
     size_t row = index >> (log_max - log2_strict(mat.h));
     segs.push_back(GatherSeg{mat.buf.p + row, pos, (u32)mat.w, (u32)mat.ld});
     pos += (u32)mat.w;
@@ -1930,9 +1950,294 @@ int32_t msbb_mmcs_open(msbb_mmcs* m, size_t index, uint32_t* vals_out, uint32_t*
 void msbb_mmcs_destroy(msbb_mmcs* m) {
   if (!m) return;
   ms_ctx* c = m->owner;
+  msbb_system* s = m->sys_ref;
   m->data = BPcsData();
   delete m;
+  if (s) system_unref(s);
   msamd::ctx_release(c);
+}
+}  // extern "C"
+// ---- Level 2 (include/mstark_bb.h): the steps of prove() above, one call each, on device handles
+static E4 e4_in(const uint32_t w[4]) {
+  E4 e;
+  for (int k = 0; k < 4; k++) {
+    if (w[k] >= BB_P) throw std::runtime_error("non-canonical extension-field coordinate");
+    e.c[k] = bb_to_monty(w[k]);
+  }
+  return e;
+}
+static void e4_out(E4 e, uint32_t w[4]) {
+  for (int k = 0; k < 4; k++) w[k] = bb_from_monty(e.c[k]);
+}
+static void cap_out_words(const std::vector<Digest8>& cap, uint32_t* out) {
+  for (size_t i = 0; i < cap.size(); i++)
+    for (int k = 0; k < 8; k++) out[8 * i + k] = bb_from_monty(cap[i].w[k]);
+}
+static msbb_mmcs* new_mmcs(msbb_system* sys) {
+  msbb_mmcs* h = new msbb_mmcs();
+  h->ctx = sys->sys->ctx;
+  h->owner = sys->owner;
+  msamd::ctx_retain(sys->owner);
+  return h;
+}
+static msbb_trace* new_trace(msbb_system* sys, BMat&& m, int kind) {
+  msbb_trace* t = new msbb_trace();
+  t->m = std::move(m);
+  t->kind = kind;
+  t->owner = sys->owner;
+  msamd::ctx_retain(sys->owner);
+  return t;
+}
+static std::vector<size_t> active_circuits(const BWitness& w) {
+  std::vector<size_t> a;
+  for (size_t i = 0; i < w.heights.size(); i++)
+    if (w.heights[i]) a.push_back(i);
+  return a;
+}
+static void need_device_witness(const msbb_witness* w) {
+  if (!w) throw std::runtime_error("null argument");
+  if (w->w->host_resident) throw std::runtime_error("the step-wise entry points need a device-resident witness (msbb_witness_create)");
+}
+typedef std::unique_ptr<msbb_mmcs, void (*)(msbb_mmcs*)> MmcsPtr;
+extern "C" {
+
+int32_t msbb_challenger_create(msbb_system* sys, msbb_challenger** out) {
+  BB_TRY
+  if (!sys || !out) throw std::runtime_error("null argument");
+  std::unique_ptr<msbb_challenger> h(new msbb_challenger());
+  h->ch.reset(new Challenger(&sys->sys->perm));
+  for (u32 v : sys->sys->seed) h->ch->observe(v);  // config.initialise_challenger(), baby_bear_config.rs:96-100
+  h->owner = sys;
+  sys->refs++;
+  *out = h.release();
+  return MS_OK;
+  BB_CATCH
+}
+void msbb_challenger_destroy(msbb_challenger* ch) {
+  if (!ch) return;
+  msbb_system* s = ch->owner;
+  delete ch;
+  system_unref(s);
+}
+int32_t msbb_challenger_observe(msbb_challenger* ch, const uint32_t* elems, size_t n) {
+  BB_TRY
+  if (!ch || (n && !elems)) throw std::runtime_error("null argument");
+  for (size_t i = 0; i < n; i++)
+    if (elems[i] >= BB_P) throw std::runtime_error("non-canonical value");
+  for (size_t i = 0; i < n; i++) ch->ch->observe(bb_to_monty(elems[i]));
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_challenger_observe_digests(msbb_challenger* ch, const uint32_t* digests, size_t n) {
+  return msbb_challenger_observe(ch, digests, 8 * n);
+}
+int32_t msbb_challenger_sample_ext(msbb_challenger* ch, uint32_t out4[4]) {
+  BB_TRY
+  if (!ch || !out4) throw std::runtime_error("null argument");
+  e4_out(ch->ch->sample_e4(), out4);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_challenger_sample_bits(msbb_challenger* ch, uint32_t bits, uint64_t* out) {
+  BB_TRY
+  if (!ch || !out || bits > 30) throw std::runtime_error("bad argument");
+  *out = ch->ch->sample_bits(bits);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_challenger_observe_claims(msbb_challenger* ch, msbb_witness* w) {
+  BB_TRY
+  if (!ch || !w) throw std::runtime_error("null argument");
+  Challenger& c = *ch->ch;
+  c.observe_usize(w->w->claims.size());  // src/prover.rs:369-373
+  for (auto& cl : w->w->claims) {
+    c.observe_usize(cl.size());
+    for (u32 x : cl) c.observe(bb_to_monty(x));
+  }
+  return MS_OK;
+  BB_CATCH
+}
+void msbb_trace_destroy(msbb_trace* t) {
+  if (!t) return;
+  ms_ctx* c = t->owner;
+  t->m = BMat();
+  delete t;
+  msamd::ctx_release(c);
+}
+int32_t msbb_trace_info(const msbb_trace* t, uint64_t out3[3]) {
+  if (!t || !out3) return MS_ERR;
+  out3[0] = t->m.h, out3[1] = t->m.w, out3[2] = (uint64_t)t->kind;
+  return MS_OK;
+}
+int32_t msbb_system_preprocessed_mmcs(msbb_system* sys, msbb_mmcs** out) {
+  BB_TRY
+  if (!sys || !out) throw std::runtime_error("null argument");
+  *out = nullptr;
+  if (!sys->sys->has_pre) return MS_OK;
+  msbb_mmcs* h = new_mmcs(sys);
+  h->view = &sys->sys->pre_data;
+  h->sys_ref = sys;
+  sys->refs++;
+  *out = h;
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_witness_commit_stage1(msbb_witness* w, uint32_t* cap_out, msbb_mmcs** out) {
+  BB_TRY
+  need_device_witness(w);
+  if (!cap_out || !out) throw std::runtime_error("null argument");
+  BSystem& sys = *w->w->sys;
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  std::vector<BMat> ldes;
+  for (size_t ci : active_circuits(*w->w)) {
+    ldes.emplace_back();
+    bb_coset_lde(ctx, w->w->traces[ci], (unsigned)sys.params.log_blowup, ldes.back());
+  }
+  if (ldes.empty()) throw std::runtime_error("cannot prove with every circuit deactivated");
+  MmcsPtr h(new_mmcs(w->owner), msbb_mmcs_destroy);
+  bb_commit(ctx, sys.d_perm.p, std::move(ldes), (unsigned)sys.params.cap_height, h->data);
+  cap_out_words(tree_cap(ctx, h->data.tree), cap_out);
+  *out = h.release();
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_witness_claims_accumulator(msbb_witness* w, const uint32_t beta[4], const uint32_t gamma[4], uint32_t acc_out[4]) {
+  BB_TRY
+  need_device_witness(w);
+  BSystem& sys = *w->w->sys;
+  HIP_CHECK(hipSetDevice(sys.ctx->device));
+  e4_out(bb_claims_accumulator(*sys.ctx, w->w->d_claim_data.p, w->w->d_claim_offs.p, w->w->claims.size(), e4_in(beta), e4_in(gamma)), acc_out);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_stage2_build(msbb_witness* w, const uint32_t beta[4], const uint32_t gamma[4], const uint32_t acc_in[4], uint32_t* accs_out,
+                          msbb_trace** traces_out) {
+  BB_TRY
+  need_device_witness(w);
+  if (!accs_out || !traces_out) throw std::runtime_error("null argument");
+  BSystem& sys = *w->w->sys;
+  Ctx& ctx = *sys.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  const E4 b = e4_in(beta), g = e4_in(gamma);
+  E4 running = e4_in(acc_in);
+  std::vector<std::unique_ptr<msbb_trace, void (*)(msbb_trace*)>> made;
+  size_t pos = 0;
+  for (size_t ci : active_circuits(*w->w)) {
+    const BCircuit& c = sys.circuits[ci];
+    BMat t;
+    E4 total;
+    bb_stage2(ctx, c.prog, c.lookup_prefix_len, c.lk, w->w->traces[ci], c.pre_width ? &c.pre : nullptr, b, g, t, &total);
+    running = e4_add(running, total);  // src/lookup.rs:544-550
+    e4_out(running, accs_out + 4 * pos);
+    made.emplace_back(new_trace(w->owner, std::move(t), 0), msbb_trace_destroy);
+    pos++;
+  }
+  for (size_t i = 0; i < made.size(); i++) traces_out[i] = made[i].release();
+  return MS_OK;
+  BB_CATCH
+}
+static int32_t commit_handles(msbb_system* sys, size_t n, msbb_trace* const* ts, int kind, uint32_t* cap_out, msbb_mmcs** out) {
+  BB_TRY
+  if (!sys || !n || !ts || !cap_out || !out) throw std::runtime_error("null argument");
+  BSystem& s = *sys->sys;
+  Ctx& ctx = *s.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  for (size_t i = 0; i < n; i++) {
+    if (!ts[i] || ts[i]->kind != kind || !ts[i]->m.h) throw std::runtime_error(kind ? "expected an LDE handle" : "expected an evaluation handle (already consumed?)");
+    if (ts[i]->owner != sys->owner) throw std::runtime_error("handle belongs to another context");
+  }
+  std::vector<BMat> ldes;
+  for (size_t i = 0; i < n; i++) {
+    if (kind) {
+      ldes.push_back(std::move(ts[i]->m));
+    } else {
+      ldes.emplace_back();
+      bb_coset_lde(ctx, ts[i]->m, (unsigned)s.params.log_blowup, ldes.back());
+    }
+    ts[i]->m = BMat();  // consumed
+  }
+  MmcsPtr h(new_mmcs(sys), msbb_mmcs_destroy);
+  bb_commit(ctx, s.d_perm.p, std::move(ldes), (unsigned)s.params.cap_height, h->data);
+  cap_out_words(tree_cap(ctx, h->data.tree), cap_out);
+  *out = h.release();
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_pcs_commit_traces(msbb_system* sys, size_t n, msbb_trace* const* evals, uint32_t* cap_out, msbb_mmcs** out) {
+  return commit_handles(sys, n, evals, 0, cap_out, out);
+}
+int32_t msbb_pcs_commit_ldes(msbb_system* sys, size_t n, msbb_trace* const* ldes, uint32_t* cap_out, msbb_mmcs** out) {
+  return commit_handles(sys, n, ldes, 1, cap_out, out);
+}
+int32_t msbb_quotient(msbb_system* sys, size_t circuit, uint32_t log_n, msbb_mmcs* s1, size_t s1_idx, msbb_mmcs* s2, size_t s2_idx,
+                      const uint32_t publics16[16], const uint32_t alpha[4], msbb_trace** q_lde_out) {
+  BB_TRY
+  if (!sys || !s1 || !s2 || !publics16 || !alpha || !q_lde_out) throw std::runtime_error("null argument");
+  BSystem& s = *sys->sys;
+  Ctx& ctx = *s.ctx;
+  HIP_CHECK(hipSetDevice(ctx.device));
+  if (circuit >= s.circuits.size()) throw std::runtime_error("circuit index out of range");
+  if (s1_idx >= s1->d().ldes.size() || s2_idx >= s2->d().ldes.size()) throw std::runtime_error("matrix index out of range");
+  const BCircuit& c = s.circuits[circuit];
+  const unsigned lb = (unsigned)s.params.log_blowup, log_q = log2_strict(c.quotient_degree());
+  const BMat &m1 = s1->d().ldes[s1_idx], &m2 = s2->d().ldes[s2_idx];
+  if (m1.h != (size_t(1) << (log_n + lb)) || m2.h != m1.h || m1.w != c.main_width || m2.w != c.stage2_width)
+    throw std::runtime_error("the committed matrices do not have this circuit's shape");
+  BQuotientIn in;
+  in.prog = &c.prog, in.lk = &c.lk, in.d_zeros = c.d_zeros.p, in.n_zeros = c.zeros.size(), in.constraint_count = c.constraint_count;
+  in.jit = &c.quotient_jit;
+  in.pre = s.has_pre && s.pre_indices[circuit] >= 0 ? &s.pre_data.ldes[s.pre_indices[circuit]] : nullptr;
+  in.s1 = &m1, in.s2 = &m2;
+  in.log_n = log_n, in.log_q = log_q, in.log_blowup = lb;
+  for (int k = 0; k < 4; k++) in.publics[k] = e4_in(publics16 + 4 * k);  // beta, gamma, acc_in, acc_out (src/lookup.rs:78-84)
+  in.alpha = e4_in(alpha);
+  BMat q_evals, q_lde;
+  bb_quotient(ctx, in, q_evals);
+  bb_quotient_lde(ctx, q_evals, log_n, log_q, lb, q_lde);
+  *q_lde_out = new_trace(sys, std::move(q_lde), 1);
+  return MS_OK;
+  BB_CATCH
+}
+int32_t msbb_pcs_open(msbb_system* sys, size_t n_rounds, msbb_mmcs* const* rounds, const uint64_t* n_points, const uint32_t* points,
+                      msbb_challenger* ch, uint32_t* opened_out, size_t opened_cap_words, uint8_t* fri_out, size_t fri_cap, size_t* fri_len) {
+  BB_TRY
+  if (!sys || !n_rounds || !rounds || !n_points || !ch || !fri_len) throw std::runtime_error("null argument");
+  if (ch->owner != sys) throw std::runtime_error("challenger belongs to another system");
+  BSystem& s = *sys->sys;
+  HIP_CHECK(hipSetDevice(s.ctx->device));
+  std::vector<OpenRound> rs(n_rounds);
+  size_t mi = 0, pi = 0, need_words = 0;
+  for (size_t r = 0; r < n_rounds; r++) {
+    if (!rounds[r] || rounds[r]->owner != sys->owner) throw std::runtime_error("round handle missing or of another context");
+    rs[r].data = &rounds[r]->d();
+    for (auto& m : rs[r].data->ldes) {
+      const size_t np = (size_t)n_points[mi++];
+      if (np > 2) throw std::runtime_error("at most two opening points per matrix");
+      std::vector<E4> pts;
+      for (size_t k = 0; k < np; k++) pts.push_back(e4_in(points + 4 * (pi++)));
+      need_words += np * m.w * 4;
+      rs[r].points.push_back(std::move(pts));
+    }
+  }
+  std::vector<OpenedRound> opened;
+  FriOut fri;
+  pcs_open(s, rs, *ch->ch, opened, fri);
+  W w;
+  write_fri(w, fri, s.params);
+  *fri_len = w.b.size();
+  if (need_words > opened_cap_words || w.b.size() > fri_cap || !opened_out || !fri_out) return MS_ERR_BUFFER;
+  uint32_t* o = opened_out;
+  for (auto& r : opened)
+    for (auto& m : r)
+      for (auto& pt : m)
+        for (auto& e : pt) {
+          e4_out(e, o);
+          o += 4;
+        }
+  memcpy(fri_out, w.b.data(), w.b.size());
+  return MS_OK;
+  BB_CATCH
 }
 int32_t msbb_field_op(ms_ctx* ctx, int32_t op, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
   BB_TRY
