@@ -84,7 +84,7 @@ int32_t msbb_field_op(ms_ctx* ctx, int32_t op, const uint32_t* a, const uint32_t
  * commitments, accumulators and challenges cross the boundary. Field elements are canonical u32, extension elements four
  * of them, digests eight (as everywhere in this header; the proof bytes hold Montgomery words, src/prover.rs:241-248).
  * tests/test_gpu_bb_level2.py drives the loop from Python and obtains the bytes msbb_prove writes.
- *   msbb_challenger_create          config.initialise_challenger()                       baby_bear_config.rs:96-100
+ *   msbb_challenger_create          config.initialise_challenger()                       baby_bear_config.rs:108-114
  *   msbb_challenger_observe / _observe_digests / _sample_ext / _sample_bits              DuplexChallenger, baby_bear_config.rs:37
  *   msbb_challenger_observe_claims  the claims absorbed by the transcript                src/prover.rs:369-373
  *   msbb_witness_commit_stage1      pcs.commit(stage-1 traces)                           src/prover.rs:338-350

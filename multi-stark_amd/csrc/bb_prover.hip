@@ -2006,7 +2006,7 @@ int32_t msbb_challenger_create(msbb_system* sys, msbb_challenger** out) {
   if (!sys || !out) throw std::runtime_error("null argument");
   std::unique_ptr<msbb_challenger> h(new msbb_challenger());
   h->ch.reset(new Challenger(&sys->sys->perm));
-  for (u32 v : sys->sys->seed) h->ch->observe(v);  // config.initialise_challenger(), baby_bear_config.rs:96-100
+  for (u32 v : sys->sys->seed) h->ch->observe(v);  // config.initialise_challenger(), baby_bear_config.rs:108-114
   h->owner = sys;
   sys->refs++;
   *out = h.release();
