@@ -36,5 +36,8 @@ echo "== micro benchmarks (the source of the integer issue peak and of the field
 for m in b3_rate gl_sgpr gl_rate acc_rate pull_rate; do
   if [ -x $REPO/tools/micro/$m ]; then timeout -k 10 120 $REPO/tools/micro/$m > $OUT/${TAG}_micro_$m.txt 2>&1 || echo "micro $m failed" >> $OUT/${TAG}_micro_$m.txt; fi
 done
+echo "== host narrowing: consecutive rows against runs of rows (the row-group experiment of DESIGN section 0)"
+g++ -O2 -std=c++17 -pthread $REPO/tools/micro/pack_runs.cpp $REPO/multi-stark_amd/csrc/pack_host.cpp -o /tmp/pack_runs 2> $OUT/pack_runs_build.log &&
+  { echo "# tools/micro/pack_runs.cpp on this box's host: 16 threads, then 32"; timeout -k 10 120 /tmp/pack_runs 16; echo; timeout -k 10 120 /tmp/pack_runs 32; } > $OUT/${TAG}_micro_pack_runs.txt 2>&1
 rm -rf $OUT/stats $OUT/sq $OUT/clk $OUT/fetch $OUT/write $OUT/tl $OUT/bb $OUT/tlh
 ls -la $OUT
