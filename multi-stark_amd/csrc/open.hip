@@ -680,11 +680,14 @@ __global__ __launch_bounds__(256) void grind_cap_k(GrindCapParams p, const u32* 
 
 // ---------------------------------------------------------------------------------------------------------
 // FRI tail: every remaining commit-phase round in one single-workgroup launch (vectors of <= 2048 elements).
+// (the tail starts at 2048 values at most: the inputs that can still roll in have 2^1 .. 2^10 values - ten distinct heights;
+// round 4's fuzzing found the limit of eight that stood here with a twelve-circuit system)
+constexpr size_t FRI_TAIL_MAX_ROLLS = 12;
 struct FriTailParams {
   const E2* cur0;
   u32 len0, n_rounds, pow_bits, n_roll;
   u32* state;    // device: challenger input buffer (one 32-byte digest) as little-endian words; updated
-  FriTailRoll roll[8];
+  FriTailRoll roll[FRI_TAIL_MAX_ROLLS];
   Digest* tree_out;   // round r: rows_r + rows_r/2 + ... + 1 digests, rounds back to back
   E2* layers_out;     // input vectors of rounds 1.. (round 0's input is cur0), back to back
   E2* final_out;
@@ -1314,7 +1317,7 @@ std::vector<Digest> cap_and_grind(Ctx& ctx, const DTree& t, const std::vector<ui
 void fri_tail(Ctx& ctx, const E2* cur0, uint32_t len0, uint32_t n_rounds, unsigned pow_bits, uint32_t* state_dev,
               const std::vector<FriTailRoll>& rolls, Digest* tree_out, E2* layers_out, FriTailRound* rounds_dev, E2* final_dev) {
   if (len0 > 2048 || len0 < 2 || (len0 & (len0 - 1))) throw std::runtime_error("fri_tail: bad length");
-  if (rolls.size() > 8) throw std::runtime_error("fri_tail: too many roll-in inputs");
+  if (rolls.size() > FRI_TAIL_MAX_ROLLS) throw std::runtime_error("fri_tail: too many roll-in inputs");
   FriTailParams p;
   memset(&p, 0, sizeof(p));
   p.cur0 = cur0;

@@ -31,6 +31,19 @@ def test_simple_proof(pkg, ctx, oracle, fe, rows):
     _prove_both(pkg, ctx, oracle, fe, fe.pythagorean_inputs(), fe.test_params(), [fe.pythagorean_trace(rows)], [])
 
 
+# Many circuits of many heights: every distinct height is one FRI input, and those of at most 1024 values roll in inside the
+# single-workgroup tail (open.hip fri_tail_k). Its table of roll-in inputs held eight until round 4's fuzzing (FUZZ_MANY, twelve
+# circuits) met a system with more: heights 2^0 .. 2^11 at blow-up 2 are ten inputs below the tail's 2048 values, nine at blow-up 4
+@pytest.mark.parametrize("log_blowup,final", [(1, 0), (2, 0)])
+def test_many_heights_roll_into_the_fri_tail(pkg, ctx, oracle, fe, log_blowup, final):
+    heights = [1 << k for k in range(12)]
+    inputs = fe.pythagorean_inputs() * len(heights)
+    traces = [fe.pythagorean_trace(h) for h in heights]
+    params = fe.Params(log_blowup=log_blowup, cap_height=0, log_final_poly_len=final, num_queries=12, commit_proof_of_work_bits=2,
+                       query_proof_of_work_bits=3)
+    _prove_both(pkg, ctx, oracle, fe, inputs, params, traces, [])
+
+
 def test_simple_proof_rejects_tampering(pkg, ctx, oracle, fe):
     g, o, packed, proof = _prove_both(pkg, ctx, oracle, fe, fe.pythagorean_inputs(), fe.test_params(), [fe.pythagorean_trace(8)], [])
     for pos in (len(proof) // 3, len(proof) - 40, 80):
