@@ -682,6 +682,7 @@ def test_thread_ranks_random_systems(pkg, fe, world, seed, monkeypatch):
     n_cases = int(os.environ.get("MSAMD_SHARDED_FUZZ_CASES", "30"))
     group = sharded.LocalGroup(world)
     try:
+        seed += 1000 * int(os.environ.get("MSAMD_SHARDED_FUZZ_SEED", "0"))  # (other systems for an ad-hoc soak)
         res = group.run(lambda rank, g: _thread_random_rank(pkg, fe, fz, np, rank, g, seed, n_cases))
     finally:
         group.close()
@@ -871,6 +872,7 @@ def test_general_ownership_random_systems(pkg, fe, world, seed, monkeypatch):
     n_cases = int(os.environ.get("MSAMD_SHARDED_FUZZ_CASES", "30"))
     group = sharded.LocalGroup(world)
     try:
+        seed += 1000 * int(os.environ.get("MSAMD_SHARDED_FUZZ_SEED", "0"))
         res = group.run(lambda rank, g: _general_random_rank(pkg, fe, fz, np, rank, g, seed, n_cases))
     finally:
         group.close()
