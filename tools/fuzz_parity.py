@@ -7,6 +7,8 @@ usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips 
        FUZZ_BIG=1 ... wider and taller systems;  FUZZ_CLAIMS=1 ... more than 8192 claim words (device-side outer transcript)
        FUZZ_MANY=1 ... systems of 4 .. 40 circuits
        FUZZ_ARITY=1 ... FriParameters::max_log_arity drawn from 1..6 (FRI rounds of arity up to 64)
+       FUZZ_PARAMS=1 ... wider protocol parameters (caps up to 2^6 digests, final polynomials up to 2^5 coefficients, up to 120
+                         queries, up to 12 + 12 proof-of-work bits) and every third case also from a host-resident witness
        FUZZ_FIELD=babybear python3 tools/fuzz_parity.py ...   the same systems over the reference's second configuration
        (BabyBear / Poseidon2, include/mstark_bb.h) against oracle/libms_oracle_bb.so
 The oracle is used only as the checker."""
@@ -95,6 +97,11 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
     params = fe.Params(log_blowup=lb, cap_height=int(rng.integers(0, 3)), log_final_poly_len=int(rng.choice([0, 0, 0, 1, 2])), max_log_arity=mla,
                        num_queries=int(rng.integers(1, 24)), commit_proof_of_work_bits=int(rng.integers(0, 7)),
                        query_proof_of_work_bits=int(rng.integers(0, 7)))
+    if os.environ.get("FUZZ_PARAMS"):  # (drawn from the case number: the rest of the case is the system the plain run draws)
+        pr = np.random.default_rng(3000 + int(case))
+        params = fe.Params(log_blowup=lb, cap_height=int(pr.integers(0, 7)), log_final_poly_len=int(pr.integers(0, 6)), max_log_arity=mla,
+                           num_queries=int(pr.choice([1, 7, 33, 64, 100, 120])), commit_proof_of_work_bits=int(pr.integers(0, 13)),
+                           query_proof_of_work_bits=int(pr.integers(0, 13)))
     circuits, traces = [], []
     # FUZZ_MANY=1: systems of 4 .. 40 circuits (many trace heights, many FRI inputs, long matrix lists) instead of 1 .. 3
     n_circuits = int(np.random.default_rng(2000 + int(case)).integers(4, 41)) if os.environ.get("FUZZ_MANY") else int(rng.integers(1, 4))
@@ -143,6 +150,8 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
         raise AssertionError("case %d: the oracle refused (%s) but the library produced a proof" % (case, oe))
     got = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
     assert got == want, "case %d: proof bytes differ (len %d vs %d)" % (case, len(got), len(want))
+    if os.environ.get("FUZZ_PARAMS") and case % 3 == 0:
+        assert g.prove_multiple_claims(g.host_witness(traces, packed)).to_bytes() == want, "case %d: host-resident witness: proof differs" % case
     b = o.verify(packed, got)
     a = g.verify(packed, got)  # the product verifier of the configuration (ms_verify / msbb_verify)
     assert (a == 0) == (b == 0), "case %d: verifier verdicts differ: library %d, oracle %d" % (case, a, b)
