@@ -7,6 +7,8 @@ usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips 
        FUZZ_BIG=1 ... wider and taller systems;  FUZZ_CLAIMS=1 ... more than 8192 claim words (device-side outer transcript)
        FUZZ_MANY=1 ... systems of 4 .. 40 circuits
        FUZZ_ARITY=1 ... FriParameters::max_log_arity drawn from 1..6 (FRI rounds of arity up to 64)
+       FUZZ_LEVEL2=1 ... every proved case also through the Level-2 entry points (the prover loop of tests/test_gpu_level2.py /
+                         test_gpu_bb_level2.py, one device call per step): same bytes
        FUZZ_PARAMS=1 ... wider protocol parameters (caps up to 2^6 digests, final polynomials up to 2^5 coefficients, up to 120
                          queries, up to 12 + 12 proof-of-work bits) and every third case also from a host-resident witness
        FUZZ_FIELD=babybear python3 tools/fuzz_parity.py ...   the same systems over the reference's second configuration
@@ -150,6 +152,18 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
         raise AssertionError("case %d: the oracle refused (%s) but the library produced a proof" % (case, oe))
     got = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
     assert got == want, "case %d: proof bytes differ (len %d vs %d)" % (case, len(got), len(want))
+    if os.environ.get("FUZZ_LEVEL2"):
+        sys.path.insert(0, os.path.join(ROOT, "tests")) if os.path.join(ROOT, "tests") not in sys.path else None
+        if BABYBEAR:
+            import test_gpu_bb_level2 as l2
+
+            g.n_circuits = len(compiled)
+            step_bytes = l2.level2_prove(g, params, traces, packed)[0]
+        else:
+            import test_gpu_level2 as l2
+
+            step_bytes = l2.level2_prove(pkg, ctx, g, params, traces, packed)[0]
+        assert step_bytes == want, "case %d: the Level-2 loop's proof differs" % case
     if os.environ.get("FUZZ_PARAMS") and case % 3 == 0:
         assert g.prove_multiple_claims(g.host_witness(traces, packed)).to_bytes() == want, "case %d: host-resident witness: proof differs" % case
     b = o.verify(packed, got)
