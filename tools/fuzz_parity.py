@@ -162,6 +162,7 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
         else:
             import test_gpu_level2 as l2
 
+            g.params = params  # (System.new sets it; this system came from its blob)
             step_bytes = l2.level2_prove(pkg, ctx, g, params, traces, packed)[0]
         assert step_bytes == want, "case %d: the Level-2 loop's proof differs" % case
     if os.environ.get("FUZZ_PARAMS") and case % 3 == 0:
