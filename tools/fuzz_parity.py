@@ -191,8 +191,13 @@ def main():
     rng = np.random.default_rng(seed)
     t0 = time.time()
     tally = {}
+    only = {int(x) for x in os.environ["FUZZ_ONLY"].split(",")} if os.environ.get("FUZZ_ONLY") else None  # (replay of chosen cases)
     for case in range(n):
         sub = np.random.default_rng(rng.integers(0, 1 << 62))
+        if only is not None and case not in only:
+            continue
+        if only is not None:
+            print("[fuzz] case %d" % case, flush=True)
         with (fe.field(fe.BABYBEAR) if BABYBEAR else contextlib.nullcontext()):
             r = one_case(pkg, fe, oracle, ctx, sub, case)
         tally[r] = tally.get(r, 0) + 1
