@@ -124,11 +124,16 @@ struct BWitness {
   // host-resident form (msbb_witness_create_host): nothing lives in HBM between proofs; every prove() uploads the caller's
   // (page-locked) trace buffers and the claims, and gives the device copies back when it is done
   bool host_resident = false;
+  bool pinned = true;  // every trace buffer could be page-locked (otherwise the uploads go through the context's bounce buffer)
   std::vector<const u32*> h_traces;
   std::vector<void*> registered;
   std::vector<u32> h_claims_monty;
   std::vector<u64> h_claim_offs;
   ~BWitness() {
+    if (!registered.empty() && sys && sys->ctx) {  // nothing may still be reading the caller's ranges when they lose their page lock
+      (void)hipSetDevice(sys->ctx->device);
+      (void)hipStreamSynchronize(sys->ctx->main_stream);
+    }
     for (void* p : registered) (void)hipHostUnregister(p);
     if (!registered.empty()) (void)hipGetLastError();
   }
@@ -407,6 +412,7 @@ std::unique_ptr<BWitness> witness_create_host(BSystem& sys, const u32* const* tr
     w->h_claim_offs.push_back(claim_offsets[i + 1] - claim_offsets[0]);
   }
   if (pinned) *pinned = all_pinned;
+  w->pinned = all_pinned;
   return w;
 }
 
@@ -418,7 +424,12 @@ struct BHostUpload {
   BHostUpload(BWitness& wit, Ctx& c) : w(wit), ctx(c) {
     if (!w.host_resident) return;
     for (size_t ci = 0; ci < w.h_traces.size(); ci++)
-      if (w.h_traces[ci]) bb_upload_rows_async(ctx, w.h_traces[ci], w.heights[ci], w.sys->circuits[ci].main_width, w.traces[ci]);
+      if (w.h_traces[ci]) {
+        if (w.pinned)
+          bb_upload_rows_async(ctx, w.h_traces[ci], w.heights[ci], w.sys->circuits[ci].main_width, w.traces[ci]);
+        else
+          bb_upload_rows(ctx, w.h_traces[ci], w.heights[ci], w.sys->circuits[ci].main_width, w.traces[ci]);  // (Ctx::bounce_h2d)
+      }
     const size_t n_claims = w.claims.size();
     if (n_claims) {
       w.d_claim_offs = DBuf<u64>(ctx, n_claims + 1);

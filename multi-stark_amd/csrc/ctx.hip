@@ -168,6 +168,10 @@ Ctx::Ctx(int dev) : device(dev) {
     (void)hipGetLastError();
     pinned = nullptr;  // transfers fall back to pageable staging by the runtime
   }
+  if (hipHostMalloc((void**)&bounce, BOUNCE_BYTES, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    bounce = nullptr;  // (synchronous hipMemcpy instead)
+  }
   if (pinned) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, pinned, 0) == hipSuccess && dp) {
@@ -282,6 +286,7 @@ Ctx::~Ctx() {
   if (side_stream) (void)hipStreamDestroy(side_stream);
   for (auto& kv : lde_scales) (void)hipFree(kv.second);
   if (pinned) (void)hipHostFree(pinned);
+  if (bounce) (void)hipHostFree(bounce);
   if (tw0) (void)hipFree(tw0);
   if (twc) (void)hipFree(twc);
   if (twf) (void)hipFree(twf);
@@ -509,6 +514,34 @@ void Ctx::sync_and_deliver() {
   if (side_depth > 0) side_fork();  // synchronised from inside a SideScope: what the scope queues next is joined again
 }
 
+void Ctx::bounce_h2d(void* dst, const void* src, size_t n, hipStream_t on) {
+  hipStream_t s = on ? on : stream;
+  if (!bounce) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+    return;
+  }
+  for (size_t off = 0; off < n; off += BOUNCE_BYTES) {
+    const size_t m = std::min(BOUNCE_BYTES, n - off);
+    memcpy(bounce, (const uint8_t*)src + off, m);
+    HIP_CHECK(hipMemcpyAsync((uint8_t*)dst + off, bounce, m, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // (the buffer is reused by the next chunk; set-up paths only)
+  }
+}
+void Ctx::bounce_d2h(void* dst, const void* src, size_t n) {
+  if (!bounce) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    return;
+  }
+  for (size_t off = 0; off < n; off += BOUNCE_BYTES) {
+    const size_t m = std::min(BOUNCE_BYTES, n - off);
+    HIP_CHECK(hipMemcpyAsync(bounce, (const uint8_t*)src + off, m, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    memcpy((uint8_t*)dst + off, bounce, m);
+  }
+}
+
 void Ctx::h2d(void* dst, const void* src, size_t n) {
   if (n == 0) return;
   if (pinned && n <= (size_t(1) << 20)) {
@@ -519,7 +552,7 @@ void Ctx::h2d(void* dst, const void* src, size_t n) {
     up_used += need;
     return;
   }
-  HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
+  bounce_h2d(dst, src, n);  // (complete on return)
 }
 
 // A read-back that is issued at once (long segments, pageable destinations) is a copy on the CURRENT stream: queued on the main
@@ -541,8 +574,7 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   size_t need = (n + 63) & ~size_t(63);
   if (!pinned || need > pinned_half) {
     join_side_for_copy();
-    HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));  // pageable: staged by the runtime
-    down_direct = true;  // the next synchronisation has to be a real stream synchronisation
+    bounce_d2h(dst, src, n);  // (delivered at once)
     return;
   }
   if (down_used + need > pinned_half) {
@@ -553,8 +585,7 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
     for (auto& d : down_pending) view_pending = view_pending || d.dst == nullptr;
     if (view_pending) {
       join_side_for_copy();
-      HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, stream));
-      down_direct = true;
+      bounce_d2h(dst, src, n);  // (delivered at once)
       return;
     }
     sync_and_deliver();

@@ -107,6 +107,15 @@ struct Ctx {
   // Pageable buffers would make hipMemcpyAsync stage and block on the host for every call.
   uint8_t* pinned = nullptr;
   size_t pinned_half = 0, up_used = 0, down_used = 0;
+  // Transfers that do not fit the staging halves (a whole witness at creation, a matrix read back by a PCS-level call) go through
+  // this page-locked bounce buffer chunk by chunk, each chunk waited for: the caller's pageable memory is never handed to an
+  // asynchronous copy (the runtime would page-lock it on the fly and let go of that lock at a time of its own choosing - next
+  // to hipHostRegister / hipHostUnregister of recycled heap addresses that ended in a GPU memory access fault on a host
+  // address in round 4's fuzzing)
+  uint8_t* bounce = nullptr;
+  static constexpr size_t BOUNCE_BYTES = size_t(4) << 20;
+  void bounce_h2d(void* dst, const void* src, size_t n, hipStream_t on = nullptr);  // on: another stream than `stream`
+  void bounce_d2h(void* dst, const void* src, size_t n);
   struct PendingD2H {
     void* dst;
     const void* src;

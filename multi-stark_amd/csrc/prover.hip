@@ -734,6 +734,9 @@ HWitness::~HWitness() {
     (void)hipSetDevice(sys->ctx->device);
     (void)hipStreamSynchronize(sys->ctx->copy_stream);  // a prefetch may still be writing into the staged buffers
     (void)hipStreamSynchronize(sys->ctx->claims_stream);
+    // (and nothing of an abandoned or delayed proof may still be queued anywhere when the caller's ranges lose their page lock)
+    if (sys->ctx->side_stream) (void)hipStreamSynchronize(sys->ctx->side_stream);
+    (void)hipStreamSynchronize(sys->ctx->main_stream);
   }
   for (auto& st : stage)
     for (auto& e : st.ev)
@@ -897,12 +900,20 @@ struct HostUpload {
     // their own, as DMA copies beside the chunks' pulling kernels - measured WORSE (6.9 against 6.4 ms per step): the link is the
     // narrow upload's bottleneck, and what the claims take of it early delays the trace, which is on the critical path.
     const size_t n_claims = w.claim_offsets.size() - 1, tot = w.claim_data.size();
+    // Uploads read the caller's page-locked ranges (HWitness::pin). Where a range could not be locked, the words go through the
+    // context's bounce buffer instead of an asynchronous copy from pageable memory (Ctx::bounce_h2d has the reason)
+    auto from_caller = [&](void* dst, const void* src, size_t bytes, hipStream_t s) {
+      if (w.pinned)
+        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+      else
+        ctx.bounce_h2d(dst, src, bytes, s);
+    };
     static const bool claims_own_stream = getenv("MSAMD_CLAIMS_OWN_STREAM") != nullptr;
     auto upload_claims = [&](hipStream_t s) {
       st.claim_offsets = DBuf<u64>(ctx, n_claims + 1);
       st.claim_data = DBuf<u64>(ctx, std::max<size_t>(tot, 1));
-      HIP_CHECK(hipMemcpyAsync(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, hipMemcpyHostToDevice, s));
-      if (tot) HIP_CHECK(hipMemcpyAsync(st.claim_data.p, w.claim_data.data(), tot * 8, hipMemcpyHostToDevice, s));
+      from_caller(st.claim_offsets.p, w.claim_offsets.data(), (n_claims + 1) * 8, s);
+      if (tot) from_caller(st.claim_data.p, w.claim_data.data(), tot * 8, s);
       HIP_CHECK(hipEventRecord(st.ev[2], s));
     };
     if (!skip_claims && claims_own_stream) {
@@ -974,7 +985,7 @@ struct HostUpload {
           g_probes.mark("narrow upload: last chunk queued");
         }
       }
-      if (!sent) HIP_CHECK(hipMemcpyAsync(st.traces[ci].p, w.h_traces[ci], cnt * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+      if (!sent) from_caller(st.traces[ci].p, w.h_traces[ci], cnt * 8, ctx.copy_stream);
     }
     if (used_second) {  // the chunks pulled on the second stream are part of "the traces have arrived"
       HIP_CHECK(hipEventRecord(ctx.copy_ev[2], ctx.claims_stream));
@@ -992,9 +1003,8 @@ struct HostUpload {
       st.args[ci] = DBuf<u64>(ctx, std::max<size_t>(h * c.args_width, 1));
       if (!w.h_mult[ci].empty()) {
         st.has_host_lookups = true;
-        HIP_CHECK(hipMemcpyAsync(st.mult[ci].p, w.h_mult[ci].data(), w.h_mult[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
-        if (!w.h_args[ci].empty())
-          HIP_CHECK(hipMemcpyAsync(st.args[ci].p, w.h_args[ci].data(), w.h_args[ci].size() * 8, hipMemcpyHostToDevice, ctx.copy_stream));
+        from_caller(st.mult[ci].p, w.h_mult[ci].data(), w.h_mult[ci].size() * 8, ctx.copy_stream);
+        if (!w.h_args[ci].empty()) from_caller(st.args[ci].p, w.h_args[ci].data(), w.h_args[ci].size() * 8, ctx.copy_stream);
       }
     }
     if (!skip_claims && !claims_own_stream) upload_claims(ctx.copy_stream);

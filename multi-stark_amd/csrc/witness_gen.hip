@@ -103,7 +103,7 @@ std::unique_ptr<HWitness> witness_u32_add_bench(HSystem& sys, size_t num_adds, u
       jump->m[j][c] = r;
     }
   DBuf<XsJump> d_jump(ctx, 1);
-  HIP_CHECK(hipMemcpyAsync(d_jump.p, jump.get(), sizeof(XsJump), hipMemcpyHostToDevice, ctx.stream));
+  ctx.h2d(d_jump.p, jump.get(), sizeof(XsJump));
   std::vector<DBuf<u64>> traces(2);
   traces[0] = DBuf<u64>(ctx, 256);
   traces[1] = DBuf<u64>(ctx, height * 14);
