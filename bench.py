@@ -41,7 +41,7 @@ from __graft_entry__ import load_package, load_oracle  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ALG_BYTES_PER_ROW = 5512
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 WORKLOAD = ("U32-add + byte-table lookup (benches/multi_stark.rs), 2^%d additions per %s, bench_config(): log_blowup 2, "
             "100 queries, 10+10 PoW bits, GoldilocksBlake3Config; %s, proof bytes returned to host")
 HOST_RESIDENT = ("witness (traces + claims, 64-bit words) in pinned host memory at step start: upload, from_stage_1 on the device "
@@ -130,8 +130,15 @@ class Watchdog:
         self.done.set()
 
 
-def profile_first_step(ctx, step, rank):
-    """one untimed step with HIP events around every kernel class: picks the dominant class"""
+# Classes of the Goldilocks path that gather SEVERAL kernels (compress_layer: compress3_k, three sub-tree kernels and the fused FRI
+# rounds; stage2: terms, scans, write; other): their totals are logged, but the roofline line is about the dominant KERNEL, and a
+# class of four kernels that edges past the largest single one by a few per cent from run to run (0.95 against 0.92 ms per proof)
+# is not that. The BabyBear leg keeps every class (its compress_layer is one permutation kernel in two launch shapes).
+MULTI_KERNEL_CLASSES = ("compress_layer", "stage2", "other")
+
+
+def profile_first_step(ctx, step, rank, single_kernel_only=True):
+    """one untimed step with HIP events around every kernel class: picks the dominant kernel (class of one kernel)"""
     names = ctx.kernel_names()
     ctx.set_profile(names)
     ctx.reset_stats()
@@ -139,7 +146,8 @@ def profile_first_step(ctx, step, rank):
     table = ctx.kernel_stats()
     ctx.set_profile([])
     ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
-    dominant = ranked[0][0] if ranked and ranked[0][1]["ms"] > 0 else "ntt12_dif"  # the class that really took the most time
+    eligible = [kv for kv in ranked if not (single_kernel_only and kv[0] in MULTI_KERNEL_CLASSES)]
+    dominant = eligible[0][0] if eligible and eligible[0][1]["ms"] > 0 else "ntt12_dif"  # the kernel that really took the most time
     if rank == 0:
         log("per-kernel-class device time of one proof (HIP events, profiled warmup step):")
         for n, s in ranked:
@@ -148,7 +156,7 @@ def profile_first_step(ctx, step, rank):
     return proof, dominant
 
 
-VALU_FILES = ("r03_valu.json", "r02_valu.json")
+VALU_FILES = ("r04_valu.json", "r03_valu.json", "r02_valu.json")
 VALU_PEAK_TOPS = 39.4  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one integer VALU instruction per lane and clock
 
 
@@ -191,10 +199,10 @@ def roofline_of(dominant, dom, full_size=True):
                         valu_file, "" if full_size else "scaled by algorithmic bytes to this run's launch size "),
             "lane_ops_per_launch": ops, "achieved_Tops": tops, "peak_Tops": VALU_PEAK_TOPS, "frac": tops / VALU_PEAK_TOPS,
         }
-        clock_file = os.path.join(ROOT, "profiles", "r03_clock_valu.txt")
-        if os.path.exists(clock_file):
+        clock_name = next((n for n in ("r04_clock_valu.txt", "r03_clock_valu.txt") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        if clock_name:
             line["valu"]["peak_note"] = ("peak_Tops is at the nominal 2.4 GHz; under these kernels the card holds 2.2-2.3 GHz, and the committed pass "
-                                         "profiles/r03_clock_valu.txt (GRBM_GUI_ACTIVE / 8 / duration, SQ_INSTS_VALU of the same dispatches) gives each "
+                                         "profiles/" + clock_name + " (GRBM_GUI_ACTIVE / 8 / duration, SQ_INSTS_VALU of the same dispatches) gives each "
                                          "class's issue rate against the peak at the clock it ran at")
     return line
 
@@ -436,7 +444,7 @@ def babybear(args, pkg, fe, ctx, torch):
     def step():
         return system.prove_multiple_claims(witness)
 
-    proof, dominant = profile_first_step(ctx, step, 0)
+    proof, dominant = profile_first_step(ctx, step, 0, single_kernel_only=False)
     for _ in range(max(args.warmup, 1) - 1):
         proof = step()
     # ---- timed region: exactly K steps, NO HIP events (this configuration's dominant class is ~150 short launches per proof:
