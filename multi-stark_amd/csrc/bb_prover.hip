@@ -134,8 +134,7 @@ struct BWitness {
       (void)hipSetDevice(sys->ctx->device);
       (void)hipStreamSynchronize(sys->ctx->main_stream);
     }
-    for (void* p : registered) (void)hipHostUnregister(p);
-    if (!registered.empty()) (void)hipGetLastError();
+    for (void* p : registered) msamd::host_range_unpin(p);
   }
 };
 
@@ -393,13 +392,11 @@ std::unique_ptr<BWitness> witness_create_host(BSystem& sys, const u32* const* tr
     for (size_t i = 0; i < h * c.main_width; i++)
       if (traces[ci][i] >= BB_P) throw std::runtime_error("non-canonical trace value");
     w->h_traces[ci] = traces[ci];
-    hipError_t e = hipHostRegister(const_cast<u32*>(traces[ci]), h * c.main_width * 4, hipHostRegisterDefault);
-    if (e == hipSuccess) {
+    const int r = msamd::host_range_pin(traces[ci], h * c.main_width * 4);  // (counted per range: msamd.h)
+    if (r == 1)
       w->registered.push_back(const_cast<u32*>(traces[ci]));
-    } else {
-      (void)hipGetLastError();
-      if (e != hipErrorHostMemoryAlreadyRegistered) all_pinned = false;
-    }
+    else if (r == 0)
+      all_pinned = false;
   }
   w->h_claim_offs.assign(1, 0);
   for (size_t i = 0; i < n_claims; i++) {

@@ -5,6 +5,7 @@
 #include <unistd.h>
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <set>
 
@@ -92,6 +93,42 @@ void install_abort_trace() {
   (void)once;
 }
 }  // namespace
+
+namespace {
+std::mutex g_pin_mu;  // one register / unregister at a time process-wide (thread ranks hand in buffers that share pages)
+struct PinnedRange {
+  size_t bytes;
+  int refs;
+};
+std::map<const void*, PinnedRange> g_pinned_ranges;
+}  // namespace
+int host_range_pin(const void* p, size_t bytes) {
+  if (!p || !bytes) return 1;
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pinned_ranges.find(p);
+  if (it != g_pinned_ranges.end() && it->second.bytes >= bytes) {
+    it->second.refs++;
+    return 1;
+  }
+  if (it != g_pinned_ranges.end()) return 0;  // the same start, now longer: the tail is not locked, and the earlier owners' lock stays as it is
+  const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault);
+  if (e == hipSuccess) {
+    g_pinned_ranges[p] = PinnedRange{bytes, 1};
+    return 1;
+  }
+  (void)hipGetLastError();
+  return e == hipErrorHostMemoryAlreadyRegistered ? 2 : 0;
+}
+void host_range_unpin(const void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pinned_ranges.find(p);
+  if (it == g_pinned_ranges.end()) return;
+  if (--it->second.refs > 0) return;
+  g_pinned_ranges.erase(it);
+  (void)hipHostUnregister(const_cast<void*>(p));
+  (void)hipGetLastError();  // (a range the caller has already freed: nothing to report)
+}
 
 void abandon_pending() {
   Ctx* c = tl_pending_ctx;

@@ -205,6 +205,13 @@ struct SideScope {
 };
 
 // drop read-backs queued by the calling thread whose destinations an error has unwound (called by the C-ABI catch blocks)
+// Page-locking of caller memory for host-resident witnesses (both configurations), counted per range process-wide: two witnesses
+// made from the same buffers share one lock, and the range keeps it until the LAST of them is gone - the second
+// hipHostRegister of a range only reports "already registered", and a plain unregister by the first owner used to leave the
+// second one's uploads reading memory the GPU could no longer see. Returns 1 = locked (by this call or an earlier one of the
+// library), 2 = the application had registered the range itself (left alone), 0 = could not be locked.
+int host_range_pin(const void* p, size_t bytes);
+void host_range_unpin(const void* p);  // for a range host_range_pin returned 1 for
 void abandon_pending();
 
 // RAII device buffer from the pool

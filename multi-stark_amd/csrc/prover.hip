@@ -714,19 +714,14 @@ class PackPool {
 // The reference's prove() is handed a witness that lives in host memory (benches/multi_stark.rs:292-296,
 // src/prover.rs:290-295). Nothing is uploaded here: the caller's buffers are page-locked so that the per-proof uploads
 // run at the link rate, the values are validated, and prove() moves them to HBM on the copy stream every time.
-// page-locking and unlocking of caller memory, one call at a time process-wide: contexts driven from several threads (thread
-// ranks, comm_local.hip) may hand in buffers that share pages
-static std::mutex g_pin_mu;
+// page-locking of caller memory: counted per range process-wide (msamd.h host_range_pin)
 void HWitness::pin(const void* p, size_t bytes) {
   if (!p || !bytes) return;
-  std::lock_guard<std::mutex> lk(g_pin_mu);
-  hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault);
-  if (e == hipSuccess) {
+  const int r = host_range_pin(p, bytes);
+  if (r == 1)
     registered.push_back(const_cast<void*>(p));
-  } else {
-    (void)hipGetLastError();
-    if (e != hipErrorHostMemoryAlreadyRegistered) pinned = false;  // uploads of this range are staged by the runtime
-  }
+  else if (r == 0)
+    pinned = false;  // uploads of this witness go through the context's bounce buffer
 }
 HWitness::~HWitness() {
   if (!host_resident) return;
@@ -741,10 +736,7 @@ HWitness::~HWitness() {
   for (auto& st : stage)
     for (auto& e : st.ev)
       if (e) (void)hipEventDestroy(e);
-  {
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    for (void* p : registered) (void)hipHostUnregister(p);
-  }
+  for (void* p : registered) host_range_unpin(p);
   for (uint8_t* p : h_packed)
     if (p) (void)hipHostFree(p);
   (void)hipGetLastError();  // (a range the caller has already freed or re-registered: nothing to report, nothing to leave behind)

@@ -300,6 +300,49 @@ def test_host_resident_witness_row_groups(pkg, ctx, oracle, fe, log_h, case, mon
         assert g.prove_multiple_claims(hw).to_bytes() == want
 
 
+# Two host-resident witnesses made from the SAME buffers share one page lock, counted per range: when the first one goes, the
+# second must still upload from locked memory (a second hipHostRegister of a range only reports "already registered"; before
+# round 4's count the first witness's unregister left the second one's asynchronous copies reading memory the GPU could no longer
+# see - the kind of access that ended a fuzzing run with a GPU memory fault). Both configurations.
+def test_two_host_witnesses_share_their_buffers(pkg, ctx, oracle, fe):
+    import gc
+
+    traces, claims = fe.u32_add_bench_witness(1 << 12)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    want = oracle.System(g.blob).prove(traces, packed)
+    first = g.host_witness(traces, packed)
+    second = g.host_witness(traces, packed)
+    assert all(a is b for a, b in zip(first.keep, second.keep))   # (the same arrays, not copies)
+    assert g.prove_multiple_claims(first).to_bytes() == want
+    del first
+    gc.collect()
+    for _ in range(3):
+        assert g.prove_multiple_claims(second).to_bytes() == want
+    third = g.host_witness(traces, packed)   # and a new owner while the second still holds the lock
+    del second
+    gc.collect()
+    assert g.prove_multiple_claims(third).to_bytes() == want
+    bb = pkg.babybear
+    import oracle_bb as ob
+
+    K = fe.poseidon2_constants()
+    with fe.field(fe.BABYBEAR):
+        bs = bb.System.new(ctx, fe.test_params(), fe.mul_air_inputs(), K)
+        tr = [fe.mul_air_trace(1 << 10)]
+        none = fe.pack_claims([])
+    ob.set_poseidon2(K)
+    bwant = ob.System(bs.blob).prove(tr, none)
+    tr32 = [np.ascontiguousarray(tr[0], dtype=np.uint32)]   # (the witness keeps an array of this type as it is: both share it)
+    b1 = bs.host_witness(tr32, none)
+    b2 = bs.host_witness(tr32, none)
+    assert b1.keep[0] is tr32[0] and b2.keep[0] is tr32[0]
+    assert bs.prove_multiple_claims(b1).to_bytes() == bwant
+    del b1
+    gc.collect()
+    assert bs.prove_multiple_claims(b2).to_bytes() == bwant and bs.prove_multiple_claims(b2).to_bytes() == bwant
+
+
 # ms_witness_prefetch: each proof of a host-resident witness also uploads the inputs of the next one; same bytes, also
 # across switching it on and off, interleaved with other witnesses, and after an injected mid-proof failure
 def test_host_witness_prefetch(pkg, ctx, oracle, fe):
