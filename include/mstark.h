@@ -109,7 +109,11 @@ int32_t ms_witness_create(ms_system* sys, const uint64_t* const* traces, const u
 /* A SystemWitness that STAYS in host memory, which is what the reference's prove() is handed (src/prover.rs:290-295;
  * criterion builds it in the setup closure, benches/multi_stark.rs:292-296). Nothing is uploaded here: the values are
  * validated and the caller's trace buffers are page-locked (hipHostRegister; *pinned = 1 when every range could be, else
- * uploads are staged by the runtime). The trace buffers must stay valid and unchanged until ms_witness_destroy. Every
+ * the uploads of this witness go through a page-locked bounce buffer of the context - no asynchronous copy ever reads
+ * pageable caller memory). The locks are counted per range process-wide: several witnesses may be made from the same
+ * buffers, the range stays locked until the last of them is destroyed; a range the application has registered itself is
+ * left alone. The trace buffers must stay valid and unchanged until ms_witness_destroy, which waits for the context's
+ * streams before it gives the locks up. Every
  * ms_prove on such a witness moves traces and claims to HBM on a copy stream (claims travel while stage 1 is computed),
  * runs SystemWitness::from_stage_1 (src/system.rs:244-328) on the device and frees the device copies again, so its
  * wall time is the reference's timed region: witness in host memory at the start, proof bytes in host memory at the end.
