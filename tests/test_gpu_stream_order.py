@@ -152,3 +152,21 @@ def test_babybear_two_witnesses(pkg, ctx, fe, monkeypatch, which):
     want = [o.prove([t], none) for t in trs]
     wits = [g.witness([t], none) for t in trs] + [g.host_witness([t], none) for t in trs]
     _alternate(g, wits, want)
+
+
+# Random systems under each delay, device- and host-resident witnesses alternating over numpy buffers whose addresses recur
+# (tools/fuzz_parity.py FUZZ_BIG FUZZ_PARAMS, a process of its own per delay): the run that ended with a GPU memory access fault
+# on a host address in round 4 (asynchronous copies from pageable caller memory beside hipHostRegister / hipHostUnregister of the
+# same ranges) - the first thirty cases of that seed take a few seconds per delay
+@pytest.mark.parametrize("which", DELAYS[1:])
+def test_random_systems_with_alternating_witnesses_under_delays(which):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_BIG="1", FUZZ_PARAMS="1", MSAMD_NO_JIT="1")
+    env[which] = "300"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "30", "5020"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert r.stdout.strip().splitlines()[-1].startswith("OK: 30 random systems"), r.stdout[-500:]
