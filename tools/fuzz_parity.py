@@ -9,6 +9,8 @@ usage: python3 tools/fuzz_parity.py [N_CASES] [SEED]      (MSAMD_NO_JIT=1 skips 
        FUZZ_ARITY=1 ... FriParameters::max_log_arity drawn from 1..6 (FRI rounds of arity up to 64)
        FUZZ_LEVEL2=1 ... every proved case also through the Level-2 entry points (the prover loop of tests/test_gpu_level2.py /
                          test_gpu_bb_level2.py, one device call per step): same bytes
+       FUZZ_FAULTS=1 ... every proved case also with a device allocation failing at three random points of the proof
+                         (ms_ctx_debug_fail_alloc): an error with the injected reason or the same bytes, then the same bytes again
        FUZZ_PARAMS=1 ... wider protocol parameters (caps up to 2^6 digests, final polynomials up to 2^5 coefficients, up to 120
                          queries, up to 12 + 12 proof-of-work bits) and every third case also from a host-resident witness
        FUZZ_FIELD=babybear python3 tools/fuzz_parity.py ...   the same systems over the reference's second configuration
@@ -165,6 +167,20 @@ def one_case(pkg, fe, oracle, ctx, rng, case):
             g.params = params  # (System.new sets it; this system came from its blob)
             step_bytes = l2.level2_prove(pkg, ctx, g, params, traces, packed)[0]
         assert step_bytes == want, "case %d: the Level-2 loop's proof differs" % case
+    if os.environ.get("FUZZ_FAULTS"):
+        fr = np.random.default_rng(4000 + int(case))
+        make = (lambda: g.host_witness(traces, packed)) if case % 2 else (lambda: g.witness(traces, packed))
+        w_f = make()
+        for nth in sorted(int(x) for x in fr.integers(1, 160, 3)):
+            ctx.debug_fail_alloc(nth)
+            try:
+                again = g.prove_multiple_claims(w_f).to_bytes()
+                assert again == want, "case %d: proof differs with an unreached injected failure (%d)" % (case, nth)
+            except pkg.MstarkError as e:
+                assert "injected" in str(e), "case %d: %s" % (case, e)
+            finally:
+                ctx.debug_fail_alloc(0)
+            assert g.prove_multiple_claims(w_f).to_bytes() == want, "case %d: proof differs after an injected failure (%d)" % (case, nth)
     if os.environ.get("FUZZ_PARAMS") and case % 3 == 0:
         assert g.prove_multiple_claims(g.host_witness(traces, packed)).to_bytes() == want, "case %d: host-resident witness: proof differs" % case
     b = o.verify(packed, got)
