@@ -600,8 +600,9 @@ void fri_round_fused(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriTa
                      const FriChallenge& fc);
 // fold with beta read from rec (device); next_leaves != nullptr also writes the next layer's leaf digests
 // row0 / rows_total: `cur`, `roll_in`, `out` are the slice [row0, row0 + rows) of a folded layer of rows_total rows (0 = whole layer)
+// squarings: the fold uses beta^(2^squarings) - step j of a round of arity 2^a, which is a binary folds with beta, beta^2, beta^4 ..
 void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in /*nullable*/, E2* out,
-                  Digest* next_leaves /*nullable*/, size_t row0 = 0, size_t rows_total = 0);
+                  Digest* next_leaves /*nullable*/, size_t row0 = 0, size_t rows_total = 0, unsigned squarings = 0);
 // A FRI round whose tree is spread over ranks (prover_sharded.inc): `layer` holds the `len` sub-tree roots (2 <= len <= 1024, a
 // power of two) with room for len - 1 more digests behind them; ONE launch hashes the levels above them into that room and runs
 // the round's challenger step (observe the root, grind, sample beta: challenge_dev.h), as the last workgroup of subtree_k does

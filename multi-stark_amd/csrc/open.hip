@@ -567,12 +567,13 @@ template <bool LEAF>
 __global__ __launch_bounds__(256) void fri_fold_dev_k(const E2* __restrict__ cur, size_t rows, unsigned log_rows,
                                                       const FriTailRound* __restrict__ rec, const E2* __restrict__ roll,
                                                       const u64* __restrict__ t0i, const u64* __restrict__ t1i, E2* __restrict__ out,
-                                                      Digest* __restrict__ leaves, size_t row0) {
+                                                      Digest* __restrict__ leaves, size_t row0, u32 squarings) {
   // (row0: cur / roll / out are the slice [row0, row0 + rows) of a layer of 2^log_rows rows - a rank's row range of a joint proof)
   const size_t j = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (2 * j >= rows) return;
   const u64 half = 0x7FFFFFFF80000001ULL;  // 1/2 mod p
-  const E2 beta = rec->beta;
+  E2 beta = rec->beta;
+  for (u32 q = 0; q < squarings; q++) beta = e2_sqr(beta);  // (a later step of a wide round)
   const E2 hb = e2_mul_base(beta, half);
   const E2 rf = e2_sqr(beta);
   E2 o[2];
@@ -1220,7 +1221,7 @@ void fri_tree_build(Ctx& ctx, DTree& t, const E2* cur, size_t rows, const FriCha
 }
 
 void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec, const E2* roll_in, E2* out, Digest* next_leaves, size_t row0,
-                  size_t rows_total) {
+                  size_t rows_total, unsigned squarings) {
   unsigned lr = log2_strict(rows_total ? rows_total : rows);
   if (row0 + rows > (size_t(1) << lr)) throw std::runtime_error("fri_fold_dev: row range outside the layer");
   if (lr + 1 > TW_LOG) throw std::runtime_error("FRI layer above 2^28 is not supported");
@@ -1229,10 +1230,10 @@ void fri_fold_dev(Ctx& ctx, const E2* cur, size_t rows, const FriTailRound* rec,
   hipEvent_t ev = ctx.prof_begin(K_FRI_FOLD);
   if (next_leaves)
     hipLaunchKernelGGL(fri_fold_dev_k<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, rec, roll_in,
-                       ctx.tw0i, ctx.tw1i, out, next_leaves, row0);
+                       ctx.tw0i, ctx.tw1i, out, next_leaves, row0, (u32)squarings);
   else
     hipLaunchKernelGGL(fri_fold_dev_k<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx.stream, cur, rows, lr, rec,
-                       roll_in, ctx.tw0i, ctx.tw1i, out, next_leaves, row0);
+                       roll_in, ctx.tw0i, ctx.tw1i, out, next_leaves, row0, (u32)squarings);
   ctx.prof_end(K_FRI_FOLD, ev, (next_leaves ? 64.0 : 48.0) * rows);
   HIP_CHECK(hipGetLastError());
 }

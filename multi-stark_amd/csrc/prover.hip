@@ -1652,9 +1652,22 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   // (true right after the alpha sample) every round's challenger step runs on the device (challenge_dev.h), so the
   // whole commit phase is submitted without a host synchronisation. The host then replays the transcript from
   // the returned roots / witnesses on its own challenger; the device values are checked, not trusted.
-  // (rounds of arity above 2, max_log_arity > 1, are host-driven: no call site of the reference folds wider, src/types.rs:189-190)
+  // Rounds of arity above 2 (max_log_arity > 1; no call site of the reference folds wider, src/types.rs:189-190) take the same
+  // device transcript since the end of round 4, one round at a time: wide leaves + tree + challenger step in the launches of
+  // fri_tree_build, then the round's binary folds with beta, beta^2, beta^4 .. read from the round's record; no fused rounds,
+  // no single-workgroup tail (MSAMD_HOST_WIDE_FRI=1: host-driven, one synchronisation per round, as before).
+  const bool wide = prm.max_log_arity > 1;
   const bool dev_rounds = folded.n > stop && prm.cap_height == 0 && (dstart || ch.input.size() == 32) && prm.commit_pow_bits <= 16 &&
-                          prm.max_log_arity == 1 && !getenv("MSAMD_HOST_FRI");
+                          (!wide || (!head && !getenv("MSAMD_HOST_WIDE_FRI"))) && !getenv("MSAMD_HOST_FRI");
+  const unsigned log_final_height = lb + (unsigned)prm.log_final_poly_len;
+  // p3-fri compute_log_arity_for_round: as far as max_log_arity allows without stepping over the next input or the final height
+  auto round_arity = [&](size_t n, size_t ni) {
+    const unsigned lh = log2_strict(n);
+    unsigned la = std::min<unsigned>((unsigned)prm.max_log_arity, lh - log_final_height);
+    if (ni < inputs.size()) la = std::min(la, lh - log2_strict(inputs[ni].n));
+    if (la < 1) throw std::runtime_error("FRI: two inputs of one height");
+    return la;
+  };
   if (dstart && !dev_rounds) throw std::runtime_error("FRI: a transcript that starts on the device needs device-driven rounds");
   // With a one-coefficient final polynomial the query phase's challenger work (observe the final polynomial, grind,
   // sample every index) also runs on the device and the openings are gathered from the device-side indices, so
@@ -1668,7 +1681,16 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
   const E2* fin_src = nullptr;
   if (dev_rounds) {
     const bool use_tail = !getenv("MSAMD_NO_FRI_TAIL");
-    for (size_t l = folded.n; l > stop; l >>= 1) n_total++;
+    if (wide) {
+      size_t ni = next_in;
+      for (size_t l = folded.n; l > stop;) {
+        l >>= round_arity(l, ni);
+        if (ni < inputs.size() && inputs[ni].n == l) ni++;
+        n_total++;
+      }
+    } else {
+      for (size_t l = folded.n; l > stop; l >>= 1) n_total++;
+    }
     if (dstart) {
       d_state = std::move(dstart->d_state);  // the opened values were absorbed on the device: FRI goes on from that state
     } else if (head && head->on_device) {
@@ -1689,6 +1711,31 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
       leaves_done = true;
     }
     while (folded.n > stop) {
+      if (wide) {
+        const unsigned la = round_arity(folded.n, next_in);
+        const size_t rows = folded.n >> la;
+        trees.emplace_back();
+        trees.back().cap_height = 0;
+        FriChallenge fc{d_state.p, d_recs.p + r, (uint32_t)prm.commit_pow_bits};
+        fri_tree_build(ctx, trees.back(), folded.p, rows, &fc, la);
+        const E2* roll = nullptr;
+        if (next_in < inputs.size() && inputs[next_in].n == rows) roll = inputs[next_in++].p;
+        const E2* src = folded.p;
+        DBuf<E2> step;
+        for (unsigned j = 0; j < la; j++) {
+          const size_t out_rows = folded.n >> (j + 1);
+          DBuf<E2> nxt(ctx, out_rows);
+          fri_fold_dev(ctx, src, out_rows, d_recs.p + r, j + 1 == la ? roll : nullptr, nxt.p, nullptr, 0, 0, j);
+          step = std::move(nxt);  // (the previous intermediate vector is released behind the launch that read it: stream-ordered pool)
+          src = step.p;
+        }
+        layers.push_back(folded.p);
+        arities.push_back(la);
+        layer_bufs.push_back(std::move(folded));
+        folded = std::move(step);
+        r++;
+        continue;
+      }
       if (use_tail && folded.n <= 2048) {
         const uint32_t len0 = (uint32_t)folded.n;
         const uint32_t n_rounds = (uint32_t)(n_total - r);
@@ -1775,13 +1822,8 @@ void fri_prove(HSystem& sys, Challenger& ch, std::vector<DBuf<E2>>& inputs, unsi
     }
     folded = DBuf<E2>();
   }
-  const unsigned log_final_height = lb + (unsigned)prm.log_final_poly_len;
-  while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, max_log_arity > 1, or MSAMD_HOST_FRI)
-    // p3-fri compute_log_arity_for_round: as far as max_log_arity allows without stepping over the next input or the final height
-    const unsigned lh = log2_strict(folded.n);
-    unsigned la = std::min<unsigned>((unsigned)prm.max_log_arity, lh - log_final_height);
-    if (next_in < inputs.size()) la = std::min(la, lh - log2_strict(inputs[next_in].n));
-    if (la < 1) throw std::runtime_error("FRI: two inputs of one height");
+  while (folded.n > stop) {  // host-driven rounds (cap_height > 0, wide grinding, MSAMD_HOST_FRI / MSAMD_HOST_WIDE_FRI, a wide joint proof)
+    const unsigned la = round_arity(folded.n, next_in);
     size_t rows = folded.n >> la;
     const bool prehashed = la == 1 && round0 && round0->digests.p && trees.empty() && layers.empty() && round0->layer_len[0] == rows;
     if (prehashed)

@@ -86,3 +86,22 @@ def test_random_systems_with_wide_folds(pkg, ctx, oracle, fe, monkeypatch):
         r = fuzz_parity.one_case(pkg, fe, oracle, ctx, np.random.default_rng(rng.integers(0, 1 << 62)), case)
         tally[r] = tally.get(r, 0) + 1
     assert tally.get("proved", 0) + tally.get("verified", 0) >= 40, tally
+
+
+def test_wide_rounds_do_not_wait_for_the_host(pkg, ctx, oracle, fe, monkeypatch):
+    """rounds of arity above 2 take the device transcript (round 4): a proof at the bench parameters with max_log_arity = 3 waits
+    for the host as often as a binary one (twice); host-driven (MSAMD_HOST_WIDE_FRI=1) it waits once more per round. Same bytes."""
+    params = fe.Params(2, 0, 0, 3, 100, 10, 10)
+    traces, claims = fe.u32_add_bench_witness(1 << 12)
+    g, o, packed, proof = _prove_both(pkg, ctx, oracle, fe, fe.u32_add_system_inputs(), params, traces, claims)
+    w = g.witness(traces, packed)
+
+    def waits():
+        n0 = ctx.sync_count()
+        assert g.prove_multiple_claims(w).to_bytes() == proof
+        return ctx.sync_count() - n0
+
+    on_device = waits()
+    monkeypatch.setenv("MSAMD_HOST_WIDE_FRI", "1")
+    host_driven = waits()
+    assert on_device == 2 and host_driven >= on_device + 4, (on_device, host_driven)
