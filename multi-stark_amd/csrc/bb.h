@@ -120,7 +120,7 @@ struct FriBeta {
   E4 beta, half_beta, beta2;
 };
 void bb_fri_challenge(Ctx& ctx, DevChallenger* d_ch, const Digest8* d_cap, size_t n_cap, const Poseidon2* d_perm, FriBeta* d_out);
-void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows_out, const FriBeta* d_beta, const E4* roll_in, E4* out);
+void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows_out, const FriBeta* d_beta, const E4* roll_in, E4* out, unsigned squarings = 0);
 // gather scattered words into one buffer: out[dst + k] = src[k * stride], k < n
 struct GatherSeg {
   const u32* src;

@@ -1110,18 +1110,26 @@ __global__ __launch_bounds__(64) void fri_challenge_k(DevChallenger* ch, const D
 void bb_fri_challenge(Ctx& ctx, DevChallenger* d_ch, const Digest8* d_cap, size_t n_cap, const Poseidon2* d_perm, FriBeta* d_out) {
   fri_challenge_k<<<1, 64, 0, ctx.stream>>>(d_ch, d_cap, (u32)n_cap, d_perm, bb_inv(bb_to_monty(2)), d_out);
 }
+// (squarings: the fold uses beta^(2^squarings) - a later step of a round of arity above 2)
 __global__ void fri_fold_dev_k(const E4* __restrict__ cur, size_t rows, unsigned log_rows, const FriBeta* __restrict__ fb, u32 half, u32 g_inv,
-                               const E4* __restrict__ roll, E4* __restrict__ out) {
+                               const E4* __restrict__ roll, E4* __restrict__ out, u32 squarings) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
+  E4 half_beta = fb->half_beta, beta2 = fb->beta2;
+  if (squarings) {
+    E4 bt = fb->beta;
+    for (u32 q = 0; q < squarings; q++) bt = e4_square(bt);
+    half_beta = e4_mul_base(bt, half);
+    beta2 = e4_square(bt);
+  }
   u32 gp = bb_pow(g_inv, bitrev_dev(i, log_rows));
-  E4 pw = e4_mul_base(fb->half_beta, gp);
+  E4 pw = e4_mul_base(half_beta, gp);
   E4 lo = cur[2 * i], hi = cur[2 * i + 1];
   E4 a = pw, b = e4_neg(pw);
   a.c[0] = bb_add(a.c[0], half);
   b.c[0] = bb_add(b.c[0], half);
   E4 r = e4_add(e4_mul(a, lo), e4_mul(b, hi));
-  if (roll) r = e4_add(r, e4_mul(fb->beta2, roll[i]));
+  if (roll) r = e4_add(r, e4_mul(beta2, roll[i]));
   out[i] = r;
 }
 // ---- every level above a layer of `len` digests in ONE launch, the BabyBear / Poseidon2 counterpart of hash.hip::subtree_k:
@@ -1300,10 +1308,10 @@ void bb_fri_round_fused(Ctx& ctx, const Poseidon2* d_perm, const E4* cur, size_t
   subtree_k<true, true><<<(unsigned)(leaves / a.sub), 1024, 0, ctx.stream>>>(a, d_perm);
 }
 
-void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows, const FriBeta* d_beta, const E4* roll_in, E4* out) {
+void bb_fri_fold_dev(Ctx& ctx, const E4* cur, size_t rows, const FriBeta* d_beta, const E4* roll_in, E4* out, unsigned squarings) {
   unsigned lr = log2_host(rows);
   fri_fold_dev_k<<<blocks_for(rows, 256), 256, 0, ctx.stream>>>(cur, rows, lr, d_beta, bb_inv(bb_to_monty(2)), bb_inv(bb_two_adic_generator(lr + 1)), roll_in,
-                                                                out);
+                                                                out, (u32)squarings);
 }
 
 __global__ void gather_k(const GatherSeg* __restrict__ segs, size_t nsegs, u32* __restrict__ out) {

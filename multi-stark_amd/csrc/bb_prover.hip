@@ -663,12 +663,31 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
   // its read-backs, is what spaces them; it needs the launches captured in a graph (or fewer of them) to win.
   // (round 2: the rounds are fused - one launch per round below 2^17 leaves - and the device transcript is the default;
   // MSBB_HOST_FRI=1 restores the host-driven rounds)
-  // (rounds of arity above 2, max_log_arity > 1, are host-driven)
-  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && prm.max_log_arity == 1 && !getenv("MSBB_HOST_FRI");
+  // (rounds of arity above 2, max_log_arity > 1: on the device transcript too since the end of round 4, one round at a time - wide
+  // leaves, tree and challenger step in bb_commit_pairs, then the round's folds with beta^(2^j) from the round's record; no
+  // fused rounds. MSBB_HOST_WIDE_FRI=1: host-driven)
+  const bool wide = prm.max_log_arity > 1;
+  const bool dev_rounds = prm.commit_pow_bits == 0 && ch.input.size() < 8 && !(wide && getenv("MSBB_HOST_WIDE_FRI")) && !getenv("MSBB_HOST_FRI");
+  const unsigned log_final_height = (unsigned)(prm.log_blowup + prm.log_final_poly_len);
+  // p3-fri compute_log_arity_for_round: as far as max_log_arity allows without stepping over the next input or the final height
+  auto round_arity = [&](size_t n, size_t ni) {
+    const unsigned lh = log2_strict(n);
+    unsigned la = std::min<unsigned>((unsigned)prm.max_log_arity, lh - log_final_height);
+    if (ni < inputs.size()) la = std::min(la, lh - log2_strict(inputs[ni].second));
+    if (la < 1) throw std::runtime_error("FRI: two inputs of one height");
+    return la;
+  };
   DBuf<DevChallenger> d_ch;
   DBuf<FriBeta> d_betas;
-  size_t n_rounds = 0;
-  for (size_t l = cur_len; l > stop; l /= 2) n_rounds++;  // (binary rounds: only used by the device transcript)
+  size_t n_rounds = 0;  // (only used by the device transcript)
+  {
+    size_t ni = 1;
+    for (size_t l = cur_len; l > stop;) {
+      l >>= round_arity(l, ni);
+      if (ni < inputs.size() && inputs[ni].second == l) ni++;
+      n_rounds++;
+    }
+  }
   if (dev_rounds && n_rounds) {
     DevChallenger hc;
     for (int k = 0; k < 16; k++) hc.state[k] = ch.state[k];
@@ -682,19 +701,14 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
   size_t round = 0;
   bool tree_done = false;  // the previous round's fused launch already built this round's tree and ran its challenger step
   std::vector<unsigned> arities;  // log2 of every round's arity
-  const unsigned log_final_height = (unsigned)(prm.log_blowup + prm.log_final_poly_len);
   while (cur_len > stop) {
-    // p3-fri compute_log_arity_for_round: as far as max_log_arity allows without stepping over the next input or the final height
-    const unsigned lh = log2_strict(cur_len);
-    unsigned la = std::min<unsigned>((unsigned)prm.max_log_arity, lh - log_final_height);
-    if (next_in < inputs.size()) la = std::min(la, lh - log2_strict(inputs[next_in].second));
-    if (la < 1) throw std::runtime_error("FRI: two inputs of one height");
+    const unsigned la = round_arity(cur_len, next_in);
     arities.push_back(la);
     size_t rows = cur_len >> la;
     if (!tree_done) {
       fri_trees.emplace_back();
       if (dev_rounds)  // the launch that produces the root also observes it and samples beta
-        bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back(), d_ch.p, d_betas.p + round);
+        bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back(), d_ch.p, d_betas.p + round, la);
       else
         bb_commit_pairs(ctx, sys.d_perm.p, cur, rows, (unsigned)prm.cap_height, fri_trees.back(), nullptr, nullptr, la);
     }
@@ -702,7 +716,17 @@ void pcs_open(BSystem& sys, const std::vector<OpenRound>& rounds, Challenger& ch
     const E4* roll = nullptr;
     if (next_in < inputs.size() && inputs[next_in].second == rows) roll = inputs[next_in++].first;
     DBuf<E4> out(ctx, rows);
-    if (dev_rounds) {
+    if (dev_rounds && wide) {
+      const E4* src = cur;
+      DBuf<E4> step;
+      for (unsigned j = 0; j + 1 < la; j++) {
+        DBuf<E4> nxt(ctx, cur_len >> (j + 1));
+        bb_fri_fold_dev(ctx, src, cur_len >> (j + 1), d_betas.p + round, nullptr, nxt.p, j);
+        step = std::move(nxt);
+        src = step.p;
+      }
+      bb_fri_fold_dev(ctx, src, rows, d_betas.p + round, roll, out.p, la - 1);
+    } else if (dev_rounds) {
       if (rows > stop && bb_fri_round_fusable(rows, (unsigned)prm.cap_height)) {
         // the next round - this fold, its leaf digests, its tree, its challenger step - is ONE launch
         fri_trees.emplace_back();
