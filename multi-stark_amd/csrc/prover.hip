@@ -602,7 +602,11 @@ class PackPool {
   void start(const u64* in, uint8_t* out, unsigned pb, size_t cnt, size_t chunks, size_t run_words = 0) {
     job_mu_.lock();  // one job at a time (contexts on other threads wait here); released by finish()
     std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return busy_ == 0; });  // the previous job's last workers have left (finish() does not wait for them)
     in_ = in, out_ = out, pb_ = pb, cnt_ = cnt;
+    caller_ = std::this_thread::get_id();
+    straggle_us_ = getenv("MSAMD_PACK_STRAGGLE_US") ? (unsigned)atoi(getenv("MSAMD_PACK_STRAGGLE_US")) : 0;  // (per job: tests flip it)
+    wait_all_ = getenv("MSAMD_PACK_WAIT_ALL") != nullptr;
     n_chunks = std::max<size_t>(1, std::min(chunks, MAX_CHUNKS));
     run_words_ = run_words;
     if (run_words) {
@@ -617,25 +621,43 @@ class PackPool {
     acc_.store(0);
     nsub_ = 2 * threads_.size();  // pieces per chunk
     for (size_t k = 0; k < n_chunks; k++) left_[k].store((int)nsub_);
+    for (size_t i = 0; i < n_chunks * nsub_; i++) state_[i].store(0, std::memory_order_relaxed);
     busy_ = (int)threads_.size();
     gen_++;
     cv_.notify_all();
   }
   size_t chunk_begin(size_t k) const { return std::min(cnt_, k * per_chunk_); }
   // waits until chunk k is complete; false = some value read so far does not fit `pb` bytes
-  // (the caller narrows pieces itself while it waits: it is awake, the workers may still be waking up)
+  // (the caller narrows pieces itself while it waits: it is awake, the workers may still be waking up. A piece whose worker
+  // has been descheduled - the host cores are shared with the pool's other tenants - does not hold the chunk up either: once
+  // every piece of the chunk has been claimed, pieces still in work after a grace period are narrowed AGAIN by the caller; both
+  // write the same bytes, whoever finishes first counts)
   bool wait_chunk(size_t k) {
-    while (left_[k].load(std::memory_order_acquire) != 0)
+    double all_claimed_at = 0;
+    while (left_[k].load(std::memory_order_acquire) != 0) {
+      if (next_.load(std::memory_order_relaxed) >= (k + 1) * nsub_) {  // every piece of this chunk has a taker
+        const double now = now_ms();
+        if (all_claimed_at == 0) all_claimed_at = now;
+        if (now - all_claimed_at > 0.03 && !wait_all_) {  // 30 us: a healthy worker finishes a piece in 3-5 us
+          for (size_t sub = 0; sub < nsub_ && left_[k].load(std::memory_order_acquire) != 0; sub++)
+            if (state_[k * nsub_ + sub].load(std::memory_order_acquire) == 1) work_piece(k * nsub_ + sub, true);
+          continue;
+        }
+      }
       if (!take_piece()) std::this_thread::yield();
+    }
     return (acc_.load() >> (8 * pb_)) == 0;
   }
-  // every worker has left the job (its buffers may be reused or freed)
+  // the job is over for its caller. Workers that are late (still waking up, or descheduled inside a piece the caller has redone)
+  // leave on their own: the next start() and quiesce() wait for them
   void finish() {
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      done_cv_.wait(lk, [&] { return busy_ == 0; });
-    }
+    if (wait_all_) quiesce();  // MSAMD_PACK_WAIT_ALL=1: as before round 4's last change (every worker checks out, no second taker)
     job_mu_.unlock();
+  }
+  // no worker is inside a job (the buffers of finished jobs may be freed)
+  void quiesce() {
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return busy_ == 0; });
   }
   struct Job {  // start ... finish, also when an error unwinds the caller
     PackPool& p;
@@ -660,23 +682,31 @@ class PackPool {
   bool take_piece() {
     const size_t it = next_.fetch_add(1);
     if (it >= n_chunks * nsub_) return false;
+    work_piece(it, false);
+    return true;
+  }
+  // narrows piece `it` (again: the caller's second go at a piece whose worker is late). The piece counts once.
+  void work_piece(size_t it, bool again) {
     const size_t k = it / nsub_, sub = it % nsub_;
+    if (!again) {
+      state_[it].store(1, std::memory_order_release);
+      if (straggle_us_ && sub == 3 && std::this_thread::get_id() != caller_)  // diagnostics: one piece per chunk is held back on its worker
+        std::this_thread::sleep_for(std::chrono::microseconds(straggle_us_));
+    }
+    u64 acc = 0;
     if (run_words_) {
       const size_t per = (runs_per_chunk_ + nsub_ - 1) / nsub_;
       const size_t m0 = std::min(runs_per_chunk_, sub * per), m1 = std::min(runs_per_chunk_, m0 + per);
-      u64 acc = 0;
       for (size_t m = m0; m < m1; m++)
         acc |= narrow_range(in_ + m * run_stride_ + k * run_words_, out_ + (k * per_chunk_ + m * run_words_) * pb_, pb_, run_words_);
-      if (m1 > m0) acc_.fetch_or(acc);
-      left_[k].fetch_sub(1, std::memory_order_release);
-      return true;
+    } else {
+      const size_t b = chunk_begin(k), e = chunk_begin(k + 1);
+      const size_t piece = (((e - b) + nsub_ - 1) / nsub_ + 7) & ~size_t(7);
+      const size_t lo = std::min(e, b + sub * piece), hi = std::min(e, lo + piece);
+      if (hi > lo) acc = narrow_range(in_ + lo, out_ + lo * pb_, pb_, hi - lo);
     }
-    const size_t b = chunk_begin(k), e = chunk_begin(k + 1);
-    const size_t piece = (((e - b) + nsub_ - 1) / nsub_ + 7) & ~size_t(7);
-    const size_t lo = std::min(e, b + sub * piece), hi = std::min(e, lo + piece);
-    if (hi > lo) acc_.fetch_or(narrow_range(in_ + lo, out_ + lo * pb_, pb_, hi - lo));
-    left_[k].fetch_sub(1, std::memory_order_release);
-    return true;
+    if (acc) acc_.fetch_or(acc);
+    if (state_[it].exchange(2, std::memory_order_acq_rel) != 2) left_[k].fetch_sub(1, std::memory_order_release);
   }
   void run() {
     uint64_t seen = 0;
@@ -704,6 +734,10 @@ class PackPool {
   unsigned pb_ = 1;
   size_t cnt_ = 0, per_chunk_ = 0, nsub_ = 1;
   size_t run_words_ = 0, run_stride_ = 0, runs_per_chunk_ = 0;
+  std::atomic<uint8_t> state_[MAX_CHUNKS * 128];  // per piece: 0 unclaimed, 1 in work, 2 done
+  std::thread::id caller_;
+  unsigned straggle_us_ = 0;  // MSAMD_PACK_STRAGGLE_US (diagnostics)
+  bool wait_all_ = false;
   std::atomic<size_t> next_{0};
   std::atomic<u64> acc_{0};
   std::atomic<int> left_[MAX_CHUNKS];
@@ -736,6 +770,10 @@ HWitness::~HWitness() {
   for (auto& st : stage)
     for (auto& e : st.ev)
       if (e) (void)hipEventDestroy(e);
+  bool any_packed = false;
+  for (uint8_t* p : h_packed) any_packed = any_packed || p != nullptr;
+  if (any_packed)
+    if (PackPool* pool = PackPool::get()) pool->quiesce();  // a late worker of the last proof may still be inside its piece
   for (void* p : registered) host_range_unpin(p);
   for (uint8_t* p : h_packed)
     if (p) (void)hipHostFree(p);

@@ -300,6 +300,36 @@ def test_host_resident_witness_row_groups(pkg, ctx, oracle, fe, log_h, case, mon
         assert g.prove_multiple_claims(hw).to_bytes() == want
 
 
+# A worker of the narrowing pool that is descheduled inside its piece (shared host cores) must not hold its chunk up: once every
+# piece of a chunk has a taker, pieces still in work after 30 us are narrowed again by the calling thread, and late workers
+# leave on their own (the next job and the witness's destructor wait for them). MSAMD_PACK_STRAGGLE_US holds one piece per
+# chunk back on its worker: same bytes, and a proof does not pay the eight sleeps
+def test_late_pack_workers_do_not_hold_the_upload(pkg, ctx, oracle, fe, monkeypatch):
+    import time
+
+    monkeypatch.setenv("MSAMD_PACK_MIN_BYTES", "0")
+    traces, claims = fe.u32_add_bench_witness(1 << 16)
+    g = pkg.System.new(ctx, fe.bench_params(), fe.u32_add_system_inputs())
+    packed = fe.pack_claims(claims)
+    hw = g.host_witness(traces, packed)
+    want = g.prove_multiple_claims(g.witness(traces, packed)).to_bytes()
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    t0 = time.perf_counter()
+    for _ in range(3):
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+    plain_ms = (time.perf_counter() - t0) / 3 * 1e3
+    monkeypatch.setenv("MSAMD_PACK_STRAGGLE_US", "20000")
+    t0 = time.perf_counter()
+    assert g.prove_multiple_claims(hw).to_bytes() == want   # (the FIRST proof under it: later ones wait for this one's sleepers to leave)
+    late_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(2):
+        assert g.prove_multiple_claims(hw).to_bytes() == want
+    monkeypatch.delenv("MSAMD_PACK_STRAGGLE_US")
+    assert g.prove_multiple_claims(hw).to_bytes() == want
+    assert late_ms < plain_ms + 10.0, (plain_ms, late_ms)   # one sleep is 20 ms, eight chunks would have waited for eight
+    del hw   # (the destructor waits for any worker still inside a piece)
+
+
 # Two host-resident witnesses made from the SAME buffers share one page lock, counted per range: when the first one goes, the
 # second must still upload from locked memory (a second hipHostRegister of a range only reports "already registered"; before
 # round 4's count the first witness's unregister left the second one's asynchronous copies reading memory the GPU could no longer
