@@ -649,7 +649,8 @@ class PackPool {
     return (acc_.load() >> (8 * pb_)) == 0;
   }
   // the job is over for its caller. Workers that are late (still waking up, or descheduled inside a piece the caller has redone)
-  // leave on their own: the next start() and quiesce() wait for them
+  // leave on their own: the next start() and quiesce() wait for them (so a SECOND large trace of the same proof still waits for
+  // the first one's late worker: one job at a time)
   void finish() {
     if (wait_all_) quiesce();  // MSAMD_PACK_WAIT_ALL=1: as before round 4's last change (every worker checks out, no second taker)
     job_mu_.unlock();
