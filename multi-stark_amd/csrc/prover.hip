@@ -593,7 +593,7 @@ class PackPool {
     }();
     return pool;
   }
-  static constexpr size_t MAX_CHUNKS = 64;
+  static constexpr size_t MAX_CHUNKS = 64, MAX_SUB = 128;
   size_t n_chunks = 0;
   // starts narrowing in[0 .. cnt) into out; chunk k covers elements [chunk_begin(k), chunk_begin(k + 1))
   // (run_words != 0, "row groups": `in` is a sequence of blocks of run_stride words and chunk k is made of the k-th run of
@@ -619,7 +619,7 @@ class PackPool {
     }
     next_.store(0);
     acc_.store(0);
-    nsub_ = 2 * threads_.size();  // pieces per chunk
+    nsub_ = std::min<size_t>(2 * threads_.size(), MAX_SUB);  // pieces per chunk
     for (size_t k = 0; k < n_chunks; k++) left_[k].store((int)nsub_);
     for (size_t i = 0; i < n_chunks * nsub_; i++) state_[i].store(0, std::memory_order_relaxed);
     busy_ = (int)threads_.size();
@@ -735,7 +735,7 @@ class PackPool {
   unsigned pb_ = 1;
   size_t cnt_ = 0, per_chunk_ = 0, nsub_ = 1;
   size_t run_words_ = 0, run_stride_ = 0, runs_per_chunk_ = 0;
-  std::atomic<uint8_t> state_[MAX_CHUNKS * 128];  // per piece: 0 unclaimed, 1 in work, 2 done
+  std::atomic<uint8_t> state_[MAX_CHUNKS * MAX_SUB];  // per piece: 0 unclaimed, 1 in work, 2 done
   std::thread::id caller_;
   unsigned straggle_us_ = 0;  // MSAMD_PACK_STRAGGLE_US (diagnostics)
   bool wait_all_ = false;
