@@ -640,7 +640,7 @@ class PackPool {
         if (all_claimed_at == 0) all_claimed_at = now;
         if (now - all_claimed_at > 0.03 && !wait_all_) {  // 30 us: a healthy worker finishes a piece in 3-5 us
           for (size_t sub = 0; sub < nsub_ && left_[k].load(std::memory_order_acquire) != 0; sub++)
-            if (state_[k * nsub_ + sub].load(std::memory_order_acquire) == 1) work_piece(k * nsub_ + sub, true);
+            if (state_[k * nsub_ + sub].load(std::memory_order_acquire) != 2) work_piece(k * nsub_ + sub, true);  // (claimed: in work, or its worker not even started)
           continue;
         }
       }
@@ -690,7 +690,8 @@ class PackPool {
   void work_piece(size_t it, bool again) {
     const size_t k = it / nsub_, sub = it % nsub_;
     if (!again) {
-      state_[it].store(1, std::memory_order_release);
+      uint8_t unclaimed = 0;
+      if (!state_[it].compare_exchange_strong(unclaimed, 1, std::memory_order_acq_rel)) return;  // the caller has taken this piece over already
       if (straggle_us_ && sub == 3 && std::this_thread::get_id() != caller_)  // diagnostics: one piece per chunk is held back on its worker
         std::this_thread::sleep_for(std::chrono::microseconds(straggle_us_));
     }
