@@ -46,7 +46,8 @@ int32_t msbb_witness_create(msbb_system* sys, const uint32_t* const* traces, con
                             const uint64_t* claim_offsets, const uint32_t* claim_data, msbb_witness** out);
 /* A SystemWitness that STAYS in host memory - what the reference's prove() is handed (src/prover.rs:290-295; the setup closure
  * of a criterion bench builds it). Values are validated and the caller's trace buffers page-locked here (*pinned = 1 when
- * every range could be); they must stay valid and unchanged until msbb_witness_destroy. Every msbb_prove on such a witness
+ * every range could be; otherwise the uploads go through a page-locked bounce buffer; the locks are counted per range as for
+ * ms_witness_create_host); they must stay valid and unchanged until msbb_witness_destroy. Every msbb_prove on such a witness
  * uploads traces and claims, runs from_stage_1 on the device and releases the device copies: its wall time is the reference's
  * timed region (witness in host memory at the start, proof bytes in host memory at the end). */
 int32_t msbb_witness_create_host(msbb_system* sys, const uint32_t* const* traces, const uint64_t* heights, size_t n_claims,

@@ -617,7 +617,7 @@ void Ctx::d2h_queue(void* dst, const void* src, size_t n) {
   if (down_used + need > pinned_half) {
     // the staging half is full. Wrapping it (synchronise, deliver, start again at offset 0) would let the segments queued
     // next overwrite a view handed out by d2h_queue_staged that its caller has not read yet: with such a view pending, this
-    // read-back goes straight to its destination instead (staged by the runtime; the next synchronisation is a real one)
+    // read-back goes to its destination at once instead, through the bounce buffer
     bool view_pending = false;
     for (auto& d : down_pending) view_pending = view_pending || d.dst == nullptr;
     if (view_pending) {
