@@ -578,20 +578,29 @@ std::vector<int> cpus_near(const void* addr) {
 
 class PackPool {
  public:
+  // One pool per DEVICE (created on first use, never destroyed): a process that drives several GPUs from thread ranks
+  // (ms_comm_local_*, `bench.py --gpus N` without a launcher) narrows every rank's trace at the same time instead of one job
+  // after the other - a pool runs one job at a time. Contexts that share a device share its pool, as before.
   // `near`: an address inside the first trace that will be narrowed. With MSAMD_PACK_AFFINITY=1 the workers are kept on
   // the NUMA node that holds it; by default the scheduler places them
-  static PackPool* get(const void* near = nullptr) {
-    static PackPool* pool = [near]() -> PackPool* {
+  static PackPool* get(int device, const void* near = nullptr) {
+    static std::mutex mu;
+    static std::map<int, PackPool*> pools;
+    static const int n_threads = []() {
       int n = 16;
       if (const char* e = getenv("MSAMD_PACK_THREADS")) n = atoi(e);
-      if (n <= 0) return nullptr;
-      if (n > 64) n = 64;
-      // (measured: left to the scheduler the workers do as well or better - 6.99 against 7.34 ms per proof on one box of the
-      // pool, a tie on another; confining sixteen busy threads to the node of the trace crowds the runtime's own threads there.
-      // Polling workers between proofs instead of sleeping ones was worse still: 12-19 ms stalls every twenty proofs.)
-      return new PackPool(n, getenv("MSAMD_PACK_AFFINITY") ? cpus_near(near) : std::vector<int>());  // never destroyed
+      return n > 64 ? 64 : n;
     }();
-    return pool;
+    if (n_threads <= 0) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pools.find(device);
+    if (it != pools.end()) return it->second;
+    // (measured: left to the scheduler the workers do as well or better - 6.99 against 7.34 ms per proof on one box of the
+    // pool, a tie on another; confining sixteen busy threads to the node of the trace crowds the runtime's own threads there.
+    // Polling workers between proofs instead of sleeping ones was worse still: 12-19 ms stalls every twenty proofs.)
+    PackPool* p = new PackPool(n_threads, getenv("MSAMD_PACK_AFFINITY") ? cpus_near(near) : std::vector<int>());
+    pools[device] = p;
+    return p;
   }
   static constexpr size_t MAX_CHUNKS = 64, MAX_SUB = 128;
   size_t n_chunks = 0;
@@ -775,7 +784,7 @@ HWitness::~HWitness() {
   bool any_packed = false;
   for (uint8_t* p : h_packed) any_packed = any_packed || p != nullptr;
   if (any_packed)
-    if (PackPool* pool = PackPool::get()) pool->quiesce();  // a late worker of the last proof may still be inside its piece
+    if (PackPool* pool = PackPool::get(sys && sys->ctx ? sys->ctx->device : 0)) pool->quiesce();  // a late worker of the last proof may still be inside its piece
   for (void* p : registered) host_range_unpin(p);
   for (uint8_t* p : h_packed)
     if (p) (void)hipHostFree(p);
@@ -803,7 +812,7 @@ std::unique_ptr<HWitness> witness_create_host(HSystem& sys, const u64* const* tr
   const void* first_trace = nullptr;  // the tallest one
   for (size_t ci = 0, best = 0; ci < C; ci++)
     if (heights[ci] > best && traces[ci]) first_trace = traces[ci], best = heights[ci];
-  const bool may_pack = !getenv("MSAMD_NO_PACK") && PackPool::get(first_trace) != nullptr;
+  const bool may_pack = !getenv("MSAMD_NO_PACK") && PackPool::get(ctx.device, first_trace) != nullptr;
   for (size_t ci = 0; ci < C; ci++) {
     const HCircuit& c = sys.circuits[ci];
     const size_t h = heights[ci];
@@ -959,7 +968,7 @@ struct HostUpload {
       const size_t cnt = h * c.main_width;
       st.traces[ci] = DBuf<u64>(ctx, cnt);
       const unsigned pb = w.pack_bytes[ci];
-      PackPool* pool = pb && !w.prefetch ? PackPool::get() : nullptr;  // (a prefetch already travels behind the running proof)
+      PackPool* pool = pb && !w.prefetch ? PackPool::get(ctx.device) : nullptr;  // (a prefetch already travels behind the running proof)
       bool sent = false;
       if (pool) {
         // the host threads narrow chunk k + 1 while chunk k crosses the link; the device widens the whole trace afterwards
